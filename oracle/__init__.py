@@ -1,0 +1,224 @@
+"""ctypes bindings of the parity oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product package (lidar_processing_amd) never does.
+
+  liboracle.so       CPU restatement of the reference hot path (oracle/lidar_oracle.c)
+  _ref/libkdref.so   the reference's own kdtree.hpp/queue.hpp compiled unmodified (ref_driver.cpp)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+UNKNOWN, GROUND, OBSTACLE = 0, 1, 2
+UNDEFINED = -(2**31)
+INVALID = -1
+SEG_OK, SEG_TOO_FEW_POINTS, SEG_ALL_OBSTACLE = 0, 1, 2
+ERR_RANGE = -2
+
+
+class SegCfg(C.Structure):
+    """mirrors SegmentationConfiguration (reference src/segmentation.hpp:48-56)"""
+
+    _fields_ = [
+        ("sensor_height_m", C.c_float),
+        ("orthogonal_distance_threshold", C.c_float),
+        ("initial_seed_threshold", C.c_float),
+        ("number_of_iterations", C.c_uint32),
+        ("number_of_planar_partitions", C.c_uint32),
+        ("number_of_lower_point_representatives", C.c_uint32),
+    ]
+
+    def __init__(self, sensor_height_m=1.73, orthogonal_distance_threshold=0.3, initial_seed_threshold=0.6,
+                 number_of_iterations=3, number_of_planar_partitions=2, number_of_lower_point_representatives=5000):
+        super().__init__(sensor_height_m, orthogonal_distance_threshold, initial_seed_threshold,
+                         number_of_iterations, number_of_planar_partitions, number_of_lower_point_representatives)
+
+
+class CluCfg(C.Structure):
+    """mirrors ClusteringConfiguration (reference src/clustering.hpp:42-48)"""
+
+    _fields_ = [
+        ("distance_squared", C.c_float),
+        ("cluster_quality", C.c_float),
+        ("min_cluster_size", C.c_uint32),
+        ("max_cluster_size", C.c_uint32),
+    ]
+
+    def __init__(self, distance_squared=0.18, cluster_quality=0.5, min_cluster_size=4, max_cluster_size=2**32 - 1):
+        super().__init__(distance_squared, cluster_quality, min_cluster_size, max_cluster_size)
+
+
+def build(force=False):
+    """(Re)build liboracle.so and, when /root/reference is present, _ref/libkdref.so."""
+    if force or not os.path.exists(os.path.join(_HERE, "liboracle.so")) or (
+            os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(_HERE, "_ref", "libkdref.so"))):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        _lib.orc_segment.restype = C.c_int
+        _lib.orc_cluster_stats.restype = C.c_int
+    return _lib
+
+
+def ref():
+    """The compiled reference kd-tree driver; None if it has not been built (no /root/reference)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libkdref.so")
+        if not os.path.exists(path):
+            build()
+        if not os.path.exists(path):
+            return None
+        _ref = C.CDLL(path)
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _as_points(points):
+    """(n,k>=3) float32 C-contiguous array -> (array, stride_bytes)"""
+    a = np.ascontiguousarray(points, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] >= 3
+    return a, a.shape[1] * 4
+
+
+def segment(points, cfg=None):
+    """Segmenter::segment restated.  Returns dict(labels, ground_idx, obstacle_idx, planes, status, rc)."""
+    cfg = cfg or SegCfg()
+    a, stride = _as_points(points)
+    n = a.shape[0]
+    P = cfg.number_of_planar_partitions
+    labels = np.zeros(n, np.uint32)
+    gi = np.zeros(max(n, 1), np.uint32)
+    oi = np.zeros(max(n, 1), np.uint32)
+    ng = C.c_uint32(0)
+    no = C.c_uint32(0)
+    planes = np.zeros((max(P, 1), 4), np.float32)
+    status = np.zeros(max(P, 1), np.uint32)
+    rc = lib().orc_segment(_p(a), C.c_size_t(stride), C.c_uint32(n), C.byref(cfg), _p(labels), _p(gi), C.byref(ng),
+                           _p(oi), C.byref(no), _p(planes), _p(status))
+    return dict(labels=labels, ground_idx=gi[:ng.value].copy(), obstacle_idx=oi[:no.value].copy(),
+                planes=planes[:P], status=status[:P], rc=rc)
+
+
+def cluster(points, cfg=None, stats=False):
+    """Clusterer::cluster restated.  Returns (labels int32, n_clusters[, expansions, visits])."""
+    cfg = cfg or CluCfg()
+    a, stride = _as_points(points)
+    m = a.shape[0]
+    labels = np.zeros(m, np.int32)
+    nc = C.c_uint32(0)
+    ne = C.c_uint64(0)
+    nv = C.c_uint64(0)
+    rc = lib().orc_cluster_stats(_p(a), C.c_size_t(stride), C.c_uint32(m), C.byref(cfg), _p(labels), C.byref(nc),
+                                 C.byref(ne), C.byref(nv))
+    assert rc == 0
+    if stats:
+        return labels, nc.value, ne.value, nv.value
+    return labels, nc.value
+
+
+def _xyz(points):
+    return np.ascontiguousarray(np.asarray(points, dtype=np.float32)[:, :3])
+
+
+def kd_preorder(points):
+    xyz = _xyz(points)
+    out = np.zeros(xyz.shape[0], np.uint32)
+    assert lib().orc_kd_preorder(_p(xyz), C.c_uint32(xyz.shape[0]), _p(out)) == 0
+    return out
+
+
+def kd_layout(points):
+    xyz = _xyz(points)
+    out = np.zeros(xyz.shape[0], np.uint32)
+    assert lib().orc_kd_layout(_p(xyz), C.c_uint32(xyz.shape[0]), _p(out)) == 0
+    return out
+
+
+def radius_search(points, target, r2):
+    xyz = _xyz(points)
+    m = xyz.shape[0]
+    idx = np.zeros(max(m, 1), np.uint32)
+    dist = np.zeros(max(m, 1), np.float32)
+    cnt = C.c_uint32(0)
+    t = np.ascontiguousarray(target, dtype=np.float32)
+    lib().orc_radius_search(_p(xyz), C.c_uint32(m), _p(t), C.c_float(r2), _p(idx), _p(dist), C.byref(cnt))
+    return idx[:cnt.value].copy(), dist[:cnt.value].copy()
+
+
+def nth_element(keys, payload, first, nth, last):
+    k = np.array(keys, dtype=np.float32)
+    p = np.array(payload, dtype=np.uint32)
+    lib().orc_nth_element_u32(_p(k), _p(p), C.c_uint32(first), C.c_uint32(nth), C.c_uint32(last))
+    return k, p
+
+
+def plane_from_points(xyz):
+    a = _xyz(xyz)
+    plane = np.zeros(4, np.float32)
+    rc = lib().orc_plane_from_points(_p(a), C.c_uint32(a.shape[0]), _p(plane))
+    return plane, rc
+
+
+def jacobi_svd3(mat):
+    a = np.ascontiguousarray(mat, dtype=np.float32).reshape(9)
+    v = np.zeros(9, np.float32)
+    s = np.zeros(3, np.float32)
+    lib().orc_jacobi_svd3(_p(a), _p(v), _p(s))
+    return v.reshape(3, 3), s
+
+
+# ---- compiled reference (kdtree.hpp / queue.hpp) -------------------------------------------------
+
+def ref_kd_preorder(points):
+    xyz = _xyz(points)
+    out = np.zeros(xyz.shape[0], np.uint32)
+    assert ref().ref_kd_preorder(_p(xyz), C.c_uint32(xyz.shape[0]), _p(out)) == 0
+    return out
+
+
+def ref_radius_search(points, target, r2):
+    xyz = _xyz(points)
+    m = xyz.shape[0]
+    idx = np.zeros(max(m, 1), np.uint32)
+    dist = np.zeros(max(m, 1), np.float32)
+    cnt = C.c_uint32(0)
+    t = np.ascontiguousarray(target, dtype=np.float32)
+    ref().ref_radius_search(_p(xyz), C.c_uint32(m), _p(t), C.c_float(r2), _p(idx), _p(dist), C.byref(cnt))
+    return idx[:cnt.value].copy(), dist[:cnt.value].copy()
+
+
+def ref_nth_element(keys, payload, first, nth, last):
+    k = np.array(keys, dtype=np.float32)
+    p = np.array(payload, dtype=np.uint32)
+    ref().ref_nth_element_u32(_p(k), _p(p), C.c_uint32(first), C.c_uint32(nth), C.c_uint32(last))
+    return k, p
+
+
+def ref_fec(points, cfg=None):
+    cfg = cfg or CluCfg()
+    xyz = _xyz(points)
+    m = xyz.shape[0]
+    labels = np.zeros(m, np.int32)
+    nc = C.c_uint32(0)
+    rc = ref().ref_fec(_p(xyz), C.c_uint32(m), C.c_float(cfg.distance_squared), C.c_float(cfg.cluster_quality),
+                       C.c_uint32(cfg.min_cluster_size), C.c_uint32(cfg.max_cluster_size), _p(labels), C.byref(nc))
+    assert rc == 0
+    return labels, nc.value
