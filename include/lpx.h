@@ -1,0 +1,158 @@
+/*
+ * lpx.h -- C-ABI of the MI355X-native ground-segmentation + obstacle-clustering hot path.
+ *
+ * Drop-in boundary for the reference's two calls in src/processor.cpp:
+ *     segmenter_.segment(cloud_in_, segmentation_labels_, ground_points_, obstacle_points_);   (:150)
+ *     clusterer_.cluster(*obstacle_cloud, cluster_labels);                                     (:178)
+ * The header-only C++ classes in include/lidar_processing/{segmentation,clustering}.hpp keep the
+ * reference's names and signatures (src/segmentation.hpp:58-70, src/clustering.hpp:50-75) and call
+ * the functions below; INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain pointers and sizes only, no C++ or torch types; every function returns
+ * LPX_OK (0) or a negative LPX_ERR_* code and never throws; lpx_last_error() gives a message.
+ * A context is bound to one HIP device and one stream; it is not thread-safe (one in-flight call
+ * per context, like the reference objects).  "_device" entry points take device
+ * pointers, enqueue on the context stream and do NOT synchronise; host entry points are
+ * synchronous at return.
+ */
+#ifndef LPX_H
+#define LPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lpx_ctx lpx_ctx;
+
+/* mirrors lidar_processing::SegmentationConfiguration (reference src/segmentation.hpp:48-56) */
+typedef struct
+{
+    float sensor_height_m;                          /* 1.73  */
+    float orthogonal_distance_threshold;            /* 0.3   */
+    float initial_seed_threshold;                   /* 0.6   */
+    uint32_t number_of_iterations;                  /* 3     */
+    uint32_t number_of_planar_partitions;           /* 2     */
+    uint32_t number_of_lower_point_representatives; /* 5000  */
+} lpx_seg_cfg;
+
+/* mirrors lidar_processing::ClusteringConfiguration (reference src/clustering.hpp:42-48) */
+typedef struct
+{
+    float distance_squared;    /* 0.18 */
+    float cluster_quality;     /* 0.5  */
+    uint32_t min_cluster_size; /* 4    */
+    uint32_t max_cluster_size; /* UINT32_MAX */
+} lpx_clu_cfg;
+
+/* SegmentationLabel (reference src/segmentation.hpp:41-46) */
+#define LPX_LABEL_UNKNOWN 0u
+#define LPX_LABEL_GROUND 1u
+#define LPX_LABEL_OBSTACLE 2u
+/* Clusterer::UNDEFINED / INVALID (reference src/clustering.hpp:53-54) */
+#define LPX_CLUSTER_UNDEFINED INT32_MIN
+#define LPX_CLUSTER_INVALID (-1)
+
+#define LPX_OK 0
+#define LPX_ERR_ARG (-1)      /* bad argument */
+#define LPX_ERR_RANGE (-2)    /* a coordinate is non-finite or |v| >= 2048 m (fixed-point moment range) */
+#define LPX_ERR_HIP (-3)      /* HIP runtime error, see lpx_last_error() */
+#define LPX_ERR_CAPACITY (-4) /* workspace too small and could not be grown */
+#define LPX_ERR_NO_DEVICE (-5)
+#define LPX_ERR_INTERNAL (-6)
+
+#define LPX_MAX_PARTITIONS 256u
+#define LPX_MAX_ITERATIONS 64u
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device` with its own stream.  Fails loudly (LPX_ERR_NO_DEVICE)
+ * when no GPU is present: there is no CPU fallback. */
+int lpx_create(int device, lpx_ctx **out);
+/* As lpx_create but enqueues on an existing hipStream_t (passed as void*; NULL = default stream). */
+int lpx_create_on_stream(int device, void *hip_stream, lpx_ctx **out);
+void lpx_destroy(lpx_ctx *ctx);
+/* Segmenter::reserve_memory / Clusterer::reserve_memory (src/segmentation.cpp:44-60,
+ * src/clustering.cpp:37-45): pre-size all device scratch for n points.  Scratch also grows on
+ * demand.  neighbours_per_point sizes the radius-neighbour lists (0 = default 256). */
+int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_per_point);
+const char *lpx_last_error(const lpx_ctx *ctx);
+/* blocks until everything enqueued on the context stream has finished */
+int lpx_synchronize(lpx_ctx *ctx);
+
+/* ---- host entry points (synchronous; what the C++ wrappers call) ---------------------------- */
+
+/* Segmenter::segment (reference src/segmentation.cpp:311-345).
+ * pts: n records of stride_bytes, float32 x,y,z at byte offsets 0,4,8 (pcl::PointXYZ = 16 B,
+ * PointXYZI = 32 B).  labels[n]; ground_idx/obstacle_idx[n]: original indices in the order the
+ * reference appends to ground_cloud / obstacle_cloud (:331-343).  planes may be NULL, else
+ * [number_of_planar_partitions*4] (a,b,c,d of the last plane fitted per segment). */
+int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint32_t n, const lpx_seg_cfg *cfg,
+                uint32_t *labels, uint32_t *ground_idx, uint32_t *n_ground, uint32_t *obstacle_idx,
+                uint32_t *n_obstacle, float *planes);
+
+/* Clusterer::cluster (reference src/clustering.cpp:47-125).  labels[m] (int32, dense 0..L-1 in
+ * seed order, LPX_CLUSTER_INVALID for rejected groups); n_clusters may be NULL. */
+int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint32_t m, const lpx_clu_cfg *cfg,
+                int32_t *labels, uint32_t *n_clusters);
+
+/* Both calls back to back with the obstacle cloud kept on the device between them (what
+ * Processor::process does at :150-178).  cluster_labels[i] belongs to obstacle_idx[i]. */
+int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint32_t n, const lpx_seg_cfg *seg_cfg,
+                        const lpx_clu_cfg *clu_cfg, uint32_t *labels, uint32_t *ground_idx, uint32_t *n_ground,
+                        uint32_t *obstacle_idx, uint32_t *n_obstacle, float *planes, int32_t *cluster_labels,
+                        uint32_t *n_clusters);
+
+/* ---- device-resident entry points (asynchronous on the context stream) ---------------------- */
+
+/* Same as lpx_segment_cluster with every pointer a DEVICE pointer; counts[4] receives
+ * {n_ground, n_obstacle, n_clusters, status(0 = ok, else -LPX_ERR_*)} on the device.
+ * planes/cluster_labels may be NULL.  Nothing is copied to the host and nothing synchronises. */
+int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride_bytes, uint32_t n,
+                               const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, uint32_t *d_labels,
+                               uint32_t *d_ground_idx, uint32_t *d_obstacle_idx, float *d_planes,
+                               int32_t *d_cluster_labels, uint32_t *d_counts);
+int lpx_segment_device(lpx_ctx *ctx, const void *d_pts, size_t stride_bytes, uint32_t n, const lpx_seg_cfg *cfg,
+                       uint32_t *d_labels, uint32_t *d_ground_idx, uint32_t *d_obstacle_idx, float *d_planes,
+                       uint32_t *d_counts);
+int lpx_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride_bytes, uint32_t m, const lpx_clu_cfg *cfg,
+                       int32_t *d_labels, uint32_t *d_counts);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* Stage timing with HIP events on the context stream.  enable=1 records an event pair around
+ * every stage of subsequent calls (adds a few microseconds per stage; leave off when timing
+ * whole-frame throughput). */
+int lpx_profile_enable(lpx_ctx *ctx, int enable);
+/* number of stages; names are static strings */
+int lpx_profile_stage_count(void);
+const char *lpx_profile_stage_name(int stage);
+/* Synchronises, then returns for each stage the accumulated milliseconds and number of launches
+ * since the last reset; arrays of lpx_profile_stage_count() entries. */
+int lpx_profile_read(lpx_ctx *ctx, float *ms, uint32_t *launches, int reset);
+
+/* ---- stage-level entry points used by the parity tests (host pointers, synchronous) --------- */
+
+/* stable LSD radix sort of (key, value) pairs on the device; bits = number of low key bits used */
+int lpx_dbg_sort_pairs(lpx_ctx *ctx, uint32_t *keys, uint32_t *values, uint32_t n, uint32_t bits);
+int lpx_dbg_sort_keys64(lpx_ctx *ctx, uint64_t *keys, uint32_t n, uint32_t bits);
+/* exclusive scan of u32 -> u32, returns total in *total */
+int lpx_dbg_scan(lpx_ctx *ctx, uint32_t *data, uint32_t n, uint64_t *total);
+/* kd-tree array layout (reference KDTree::rebuild, src/kdtree.hpp:174-225): original index per node */
+int lpx_dbg_kd_layout(lpx_ctx *ctx, const float *xyz, uint32_t m, uint32_t *layout_idx);
+/* radius-neighbour lists of every point in kd-tree pre-order (src/kdtree.hpp:292-341) as CSR;
+ * offsets[m+1]; idx/dist hold `capacity` entries.  Returns LPX_ERR_CAPACITY if too small
+ * (offsets[m] still holds the required size). */
+int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint64_t *offsets, uint32_t *idx,
+                       float *dist, uint64_t capacity);
+/* connected-component root (smallest original index of the component) per point */
+int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint32_t *root);
+/* plane from points through the device moment/Jacobi path */
+int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPX_H */

@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+`Segmenter` / `Clusterer` keep the reference's method names, argument meaning, defaults and error
+behaviour (reference src/segmentation.hpp:48-70, src/clustering.hpp:42-75); point clouds are
+(n, k>=3) float32 arrays whose first three columns are x, y, z (k = 4 for PointXYZ's 16-byte
+record, 8 for the 32-byte PointXYZI / PointXYZRGBL records).  Everything computes on the GPU
+through liblpx.so; nothing here falls back to the CPU.
+"""
+import ctypes as C
+import enum
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+UNDEFINED = -(2 ** 31)  # Clusterer::UNDEFINED, src/clustering.hpp:53
+INVALID = -1            # Clusterer::INVALID,   src/clustering.hpp:54
+
+_ERRORS = {-1: "LPX_ERR_ARG", -2: "LPX_ERR_RANGE", -3: "LPX_ERR_HIP", -4: "LPX_ERR_CAPACITY",
+           -5: "LPX_ERR_NO_DEVICE", -6: "LPX_ERR_INTERNAL"}
+
+
+class LpxError(RuntimeError):
+    def __init__(self, code, message=""):
+        self.code = code
+        super().__init__(f"{_ERRORS.get(code, code)}: {message}")
+
+
+class SegmentationLabel(enum.IntEnum):
+    """src/segmentation.hpp:41-46"""
+    UNKNOWN = 0
+    GROUND = 1
+    OBSTACLE = 2
+
+
+@dataclass
+class SegmentationConfiguration:
+    """src/segmentation.hpp:48-56 (same defaults)"""
+    sensor_height_m: float = 1.73
+    orthogonal_distance_threshold: float = 0.3
+    initial_seed_threshold: float = 0.6
+    number_of_iterations: int = 3
+    number_of_planar_partitions: int = 2
+    number_of_lower_point_representatives: int = 5000
+
+    def _c(self):
+        return _lib.SegCfg(self.sensor_height_m, self.orthogonal_distance_threshold, self.initial_seed_threshold,
+                           self.number_of_iterations, self.number_of_planar_partitions,
+                           self.number_of_lower_point_representatives)
+
+
+@dataclass
+class ClusteringConfiguration:
+    """src/clustering.hpp:42-48 (same defaults)"""
+    distance_squared: float = 0.18
+    cluster_quality: float = 0.5
+    min_cluster_size: int = 4
+    max_cluster_size: int = 2 ** 32 - 1
+
+    def _c(self):
+        return _lib.CluCfg(self.distance_squared, self.cluster_quality, self.min_cluster_size, self.max_cluster_size)
+
+
+def _points(cloud):
+    a = np.asarray(cloud)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("point cloud must be an (n, k>=3) array with x, y, z in the first three columns")
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.shape[1] * 4
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP device + stream + scratch (lpx_ctx).  Not thread-safe, like the reference objects."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        if stream is None:
+            rc = self._L.lpx_create(int(device), C.byref(h))
+        else:
+            rc = self._L.lpx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h))
+        if rc != 0:
+            raise LpxError(rc, "no usable GPU: the MI355X path has no CPU fallback" if rc == -5 else "lpx_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lpx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise LpxError(rc, self._L.lpx_last_error(self._h).decode())
+
+    def reserve(self, n_points, neighbours_per_point=0):
+        self.check(self._L.lpx_reserve(self._h, int(n_points), int(neighbours_per_point)))
+
+    def synchronize(self):
+        self.check(self._L.lpx_synchronize(self._h))
+
+    # ---- profiling ----
+    def profile_enable(self, on=True):
+        self.check(self._L.lpx_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        n = self._L.lpx_profile_stage_count()
+        ms = np.zeros(n, np.float32)
+        cnt = np.zeros(n, np.uint32)
+        self.check(self._L.lpx_profile_read(self._h, _vp(ms), _vp(cnt), 1 if reset else 0))
+        names = [self._L.lpx_profile_stage_name(i).decode() for i in range(n)]
+        return {names[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+    # ---- host entry points ----
+    def segment(self, cloud, cfg):
+        a, stride = _points(cloud)
+        n = a.shape[0]
+        P = cfg.number_of_planar_partitions
+        labels = np.zeros(n, np.uint32)
+        gi = np.zeros(max(n, 1), np.uint32)
+        oi = np.zeros(max(n, 1), np.uint32)
+        planes = np.zeros((max(P, 1), 4), np.float32)
+        ng, no = C.c_uint32(0), C.c_uint32(0)
+        c = cfg._c()
+        self.check(self._L.lpx_segment(self._h, _vp(a), stride, n, C.byref(c), _vp(labels), _vp(gi), C.byref(ng),
+                                       _vp(oi), C.byref(no), _vp(planes)))
+        return labels, gi[:ng.value].copy(), oi[:no.value].copy(), planes[:P]
+
+    def cluster(self, cloud, cfg):
+        a, stride = _points(cloud)
+        m = a.shape[0]
+        labels = np.full(m, UNDEFINED, np.int32)
+        nc = C.c_uint32(0)
+        c = cfg._c()
+        self.check(self._L.lpx_cluster(self._h, _vp(a), stride, m, C.byref(c), _vp(labels), C.byref(nc)))
+        return labels, nc.value
+
+    def segment_cluster(self, cloud, seg_cfg, clu_cfg):
+        a, stride = _points(cloud)
+        n = a.shape[0]
+        P = seg_cfg.number_of_planar_partitions
+        labels = np.zeros(n, np.uint32)
+        gi = np.zeros(max(n, 1), np.uint32)
+        oi = np.zeros(max(n, 1), np.uint32)
+        cl = np.full(max(n, 1), UNDEFINED, np.int32)
+        planes = np.zeros((max(P, 1), 4), np.float32)
+        ng, no, nc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        sc, cc = seg_cfg._c(), clu_cfg._c()
+        self.check(self._L.lpx_segment_cluster(self._h, _vp(a), stride, n, C.byref(sc), C.byref(cc), _vp(labels),
+                                               _vp(gi), C.byref(ng), _vp(oi), C.byref(no), _vp(planes), _vp(cl),
+                                               C.byref(nc)))
+        return dict(labels=labels, ground_idx=gi[:ng.value].copy(), obstacle_idx=oi[:no.value].copy(),
+                    planes=planes[:P], cluster_labels=cl[:no.value].copy(), n_clusters=nc.value)
+
+    # ---- stage-level entry points (parity tests) ----
+    def dbg_sort_pairs(self, keys, values, bits=32):
+        k = np.array(keys, dtype=np.uint32)
+        v = np.array(values, dtype=np.uint32)
+        self.check(self._L.lpx_dbg_sort_pairs(self._h, _vp(k), _vp(v), k.shape[0], bits))
+        return k, v
+
+    def dbg_sort_keys64(self, keys, bits=64):
+        k = np.array(keys, dtype=np.uint64)
+        self.check(self._L.lpx_dbg_sort_keys64(self._h, _vp(k), k.shape[0], bits))
+        return k
+
+    def dbg_scan(self, data):
+        d = np.array(data, dtype=np.uint32)
+        tot = C.c_uint64(0)
+        self.check(self._L.lpx_dbg_scan(self._h, _vp(d), d.shape[0], C.byref(tot)))
+        return d, tot.value
+
+    def dbg_kd_layout(self, xyz):
+        a = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32)[:, :3])
+        out = np.zeros(a.shape[0], np.uint32)
+        self.check(self._L.lpx_dbg_kd_layout(self._h, _vp(a), a.shape[0], _vp(out)))
+        return out
+
+    def dbg_neighbours(self, xyz, r2, capacity=None):
+        a = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32)[:, :3])
+        m = a.shape[0]
+        cap = int(capacity if capacity is not None else max(1024, 512 * m))
+        off = np.zeros(m + 1, np.uint64)
+        idx = np.zeros(cap, np.uint32)
+        dist = np.zeros(cap, np.float32)
+        rc = self._L.lpx_dbg_neighbours(self._h, _vp(a), m, C.c_float(r2), _vp(off), _vp(idx), _vp(dist), cap)
+        if rc == -4 and capacity is None:
+            return self.dbg_neighbours(xyz, r2, capacity=int(off[m]) + 16)
+        self.check(rc)
+        tot = int(off[m])
+        return off, idx[:tot].copy(), dist[:tot].copy()
+
+    def dbg_components(self, xyz, r2):
+        a = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32)[:, :3])
+        root = np.zeros(a.shape[0], np.uint32)
+        self.check(self._L.lpx_dbg_components(self._h, _vp(a), a.shape[0], C.c_float(r2), _vp(root)))
+        return root
+
+    def dbg_plane(self, xyz):
+        a = np.ascontiguousarray(np.asarray(xyz, dtype=np.float32)[:, :3])
+        plane = np.zeros(4, np.float32)
+        rc = self._L.lpx_dbg_plane(self._h, _vp(a), a.shape[0], _vp(plane))
+        if rc < 0:
+            self.check(rc)
+        return plane, rc
+
+
+_default_ctx = {}
+
+
+def _ctx(device):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class Segmenter:
+    """Mirror of lidar_processing::Segmenter (src/segmentation.hpp:58-70)."""
+
+    def __init__(self, device=0, context=None):
+        self._ctx = context or _ctx(device)
+        self.configuration = SegmentationConfiguration()
+        self.reserve_memory()
+
+    def update_configuration(self, configuration):
+        self.configuration = configuration
+        self.reserve_memory()
+
+    def reserve_memory(self, number_of_points=200_000):
+        self._ctx.reserve(number_of_points)
+
+    def segment(self, cloud_in):
+        """Returns (labels, ground_cloud, obstacle_cloud) -- the three outputs of Segmenter::segment
+        (src/segmentation.cpp:311-345); the clouds keep every column of cloud_in."""
+        a = np.asarray(cloud_in)
+        labels, gi, oi, _ = self._ctx.segment(a, self.configuration)
+        return labels, a[gi], a[oi]
+
+    def segment_indices(self, cloud_in):
+        """labels, ground indices, obstacle indices (output-cloud order) and the fitted planes"""
+        return self._ctx.segment(cloud_in, self.configuration)
+
+
+class Clusterer:
+    """Mirror of lidar_processing::Clusterer (src/clustering.hpp:50-75)."""
+    UNDEFINED = UNDEFINED
+    INVALID = INVALID
+
+    def __init__(self, device=0, context=None):
+        self._ctx = context or _ctx(device)
+        self.configuration = ClusteringConfiguration()
+        self.reserve_memory()
+
+    def update_configuration(self, configuration):
+        self.configuration = configuration
+
+    def reserve_memory(self, number_of_points=200_000):
+        self._ctx.reserve(number_of_points)
+
+    def cluster(self, cloud_in):
+        """labels (int32, one per point) as Clusterer::cluster writes them (src/clustering.cpp:47-125)"""
+        a = np.asarray(cloud_in)
+        if a.shape[0] == 0:
+            return np.zeros(0, np.int32)
+        labels, _ = self._ctx.cluster(a, self.configuration)
+        return labels

@@ -1,0 +1,734 @@
+// lpx_api.hip -- C-ABI (include/lpx.h), context / workspace management, host staging, profiling.
+#include "lpx_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+int lpx_kd_layout_copy(lpx_ctx *ctx, uint32_t m, uint32_t *d_out);
+
+// ------------------------------------------------------------------------------------------------
+// errors, buffers
+// ------------------------------------------------------------------------------------------------
+int lpx_fail(lpx_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx)
+    {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+const char *lpx_last_error(const lpx_ctx *ctx)
+{
+    return ctx ? ctx->err : "no context";
+}
+
+int lpx_ensure(lpx_ctx *ctx, Buf &b, size_t bytes)
+{
+    if (b.bytes >= bytes && b.p)
+        return LPX_OK;
+    if (b.p)
+    {
+        LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LPX_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    bytes = (bytes + 255) & ~(size_t)255;
+    LPX_HIP(ctx, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return LPX_OK;
+}
+
+int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
+{
+    int rc = LPX_OK;
+    if (n > ctx->cap_n)
+    {
+        const size_t n4 = sizeof(uint32_t) * ((size_t)n + 16);
+        Buf *four[] = {&ctx->X,      &ctx->Y,      &ctx->Z,       &ctx->XS,     &ctx->YS,    &ctx->ZS,
+                       &ctx->OX,     &ctx->OY,     &ctx->OZ,      &ctx->key_a,  &ctx->key_b, &ctx->val_a,
+                       &ctx->val_b,  &ctx->lpos,   &ctx->rpos,    &ctx->nb_len, &ctx->nb_off, &ctx->parent,
+                       &ctx->cc_lo,  &ctx->cc_hi,  &ctx->seed_of, &ctx->queue,  &ctx->valid, &ctx->d_labels,
+                       &ctx->d_gidx, &ctx->d_oidx, &ctx->d_clabels};
+        for (Buf *b : four)
+            if ((rc = lpx_ensure(ctx, *b, n4)))
+                return rc;
+        if ((rc = lpx_ensure(ctx, ctx->key64_a, 2 * n4)) || (rc = lpx_ensure(ctx, ctx->key64_b, 2 * n4)) ||
+            (rc = lpx_ensure(ctx, ctx->nodes, 4 * n4)) || (rc = lpx_ensure(ctx, ctx->flags, (size_t)n + 64)) ||
+            (rc = lpx_ensure(ctx, ctx->state, (size_t)n + 64)))
+            return rc;
+        ctx->cap_n = n;
+    }
+    if (nb > ctx->cap_nb)
+    {
+        if ((rc = lpx_ensure(ctx, ctx->nb_idx, sizeof(uint32_t) * (nb + 64))) ||
+            (rc = lpx_ensure(ctx, ctx->nb_dist, sizeof(float) * (nb + 64))))
+            return rc;
+        ctx->cap_nb = nb;
+    }
+    return LPX_OK;
+}
+
+static int ensure_for(lpx_ctx *ctx, uint32_t n)
+{
+    uint64_t nb = (uint64_t)n * ctx->nb_per_point;
+    if (nb > 0xfffffff0ull)
+        nb = 0xfffffff0ull;  // offsets are 32-bit
+    return lpx_ensure_capacity(ctx, n, nb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling
+// ------------------------------------------------------------------------------------------------
+static const char *k_stage_names[ST_COUNT] = {"ingest",   "xsort",   "gather",  "zsort", "seeds",  "plane_passes", "compact",
+                                              "kd_build", "nb_count", "nb_scan", "nb_fill", "components", "replay", "labels"};
+
+StageTimer::StageTimer(lpx_ctx *c, int s) : ctx(c), stage(s)
+{
+    if (!ctx->profiling)
+        return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+    {
+        a = b = nullptr;
+        return;
+    }
+    hipEventRecord(a, ctx->stream);
+}
+
+StageTimer::~StageTimer()
+{
+    if (!a)
+        return;
+    hipEventRecord(b, ctx->stream);
+    if (ctx->n_pending == ctx->cap_pending)
+    {
+        const int nc = ctx->cap_pending ? ctx->cap_pending * 2 : 256;
+        ctx->pending = (lpx_ctx::Pending *)realloc(ctx->pending, sizeof(lpx_ctx::Pending) * nc);
+        ctx->cap_pending = nc;
+    }
+    ctx->pending[ctx->n_pending++] = {stage, a, b};
+}
+
+extern "C" int lpx_profile_enable(lpx_ctx *ctx, int enable)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    ctx->profiling = enable != 0;
+    return LPX_OK;
+}
+
+extern "C" int lpx_profile_stage_count(void)
+{
+    return ST_COUNT;
+}
+
+extern "C" const char *lpx_profile_stage_name(int stage)
+{
+    return (stage >= 0 && stage < ST_COUNT) ? k_stage_names[stage] : "";
+}
+
+extern "C" int lpx_profile_read(lpx_ctx *ctx, float *ms, uint32_t *launches, int reset)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ctx->n_pending; ++i)
+    {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, ctx->pending[i].a, ctx->pending[i].b) == hipSuccess)
+        {
+            ctx->st_ms[ctx->pending[i].stage] += t;
+            ctx->st_launches[ctx->pending[i].stage] += 1;
+        }
+        hipEventDestroy(ctx->pending[i].a);
+        hipEventDestroy(ctx->pending[i].b);
+    }
+    ctx->n_pending = 0;
+    for (int s = 0; s < ST_COUNT; ++s)
+    {
+        if (ms)
+            ms[s] = ctx->st_ms[s];
+        if (launches)
+            launches[s] = ctx->st_launches[s];
+        if (reset)
+        {
+            ctx->st_ms[s] = 0.0f;
+            ctx->st_launches[s] = 0;
+        }
+    }
+    return LPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lifetime
+// ------------------------------------------------------------------------------------------------
+static int create_common(int device, hipStream_t stream, bool own, lpx_ctx **out)
+{
+    if (!out)
+        return LPX_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return LPX_ERR_NO_DEVICE;  // no CPU fallback: fail loudly
+    if (device < 0 || device >= count)
+        return LPX_ERR_ARG;
+    lpx_ctx *ctx = new (std::nothrow) lpx_ctx();
+    if (!ctx)
+        return LPX_ERR_INTERNAL;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess)
+    {
+        delete ctx;
+        return LPX_ERR_HIP;
+    }
+    if (own)
+    {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+        {
+            delete ctx;
+            return LPX_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    else
+        ctx->stream = stream;
+    int rc;
+    if ((rc = lpx_ensure(ctx, ctx->frame, sizeof(FrameState))) ||
+        (rc = lpx_ensure(ctx, ctx->seg_state, sizeof(SegState) * LPX_MAX_PARTITIONS)) ||
+        (rc = lpx_ensure(ctx, ctx->seg_acc, (sizeof(long long) * LPX_ACC_WORDS + sizeof(uint32_t)) * LPX_MAX_PARTITIONS)) ||
+        (rc = lpx_ensure(ctx, ctx->d_planes, sizeof(float) * 4 * LPX_MAX_PARTITIONS)) ||
+        (rc = lpx_ensure(ctx, ctx->d_counts, 64)) || (rc = lpx_ensure(ctx, ctx->hist, 1 << 16)))
+    {
+        lpx_destroy(ctx);
+        return rc;
+    }
+    hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream);
+    *out = ctx;
+    return LPX_OK;
+}
+
+extern "C" int lpx_create(int device, lpx_ctx **out)
+{
+    return create_common(device, nullptr, true, out);
+}
+
+extern "C" int lpx_create_on_stream(int device, void *hip_stream, lpx_ctx **out)
+{
+    return create_common(device, (hipStream_t)hip_stream, false, out);
+}
+
+extern "C" void lpx_destroy(lpx_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    Buf *all[] = {&ctx->in_aos, &ctx->X,        &ctx->Y,        &ctx->Z,      &ctx->key_a,   &ctx->key_b,  &ctx->val_a,
+                  &ctx->val_b,  &ctx->key64_a,  &ctx->key64_b,  &ctx->XS,     &ctx->YS,      &ctx->ZS,     &ctx->flags,
+                  &ctx->hist,   &ctx->seg_state, &ctx->seg_acc, &ctx->blk_counts, &ctx->d_labels, &ctx->d_gidx,
+                  &ctx->d_oidx, &ctx->d_planes, &ctx->d_counts, &ctx->OX,     &ctx->OY,      &ctx->OZ,     &ctx->nodes,
+                  &ctx->lpos,   &ctx->rpos,     &ctx->nb_len,   &ctx->nb_off, &ctx->nb_idx,  &ctx->nb_dist, &ctx->parent,
+                  &ctx->cc_lo,  &ctx->cc_hi,    &ctx->state,    &ctx->seed_of, &ctx->queue,  &ctx->valid,  &ctx->d_clabels,
+                  &ctx->frame};
+    for (Buf *b : all)
+        if (b->p)
+            hipFree(b->p);
+    for (int i = 0; i < ctx->n_pending; ++i)
+    {
+        hipEventDestroy(ctx->pending[i].a);
+        hipEventDestroy(ctx->pending[i].b);
+    }
+    free(ctx->pending);
+    if (ctx->own_stream)
+        hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_per_point)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if (neighbours_per_point)
+        ctx->nb_per_point = neighbours_per_point;
+    return ensure_for(ctx, n_points);
+}
+
+extern "C" int lpx_synchronize(lpx_ctx *ctx)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// argument checks
+// ------------------------------------------------------------------------------------------------
+static int check_seg(lpx_ctx *ctx, const lpx_seg_cfg *c, size_t stride)
+{
+    if (!c || stride < 12 || (stride & 3))
+        return lpx_fail(ctx, LPX_ERR_ARG, "stride must be a multiple of 4 and at least 12 bytes");
+    if (c->number_of_planar_partitions == 0 || c->number_of_planar_partitions > LPX_MAX_PARTITIONS ||
+        c->number_of_iterations > LPX_MAX_ITERATIONS)
+        return lpx_fail(ctx, LPX_ERR_ARG, "partitions must be 1..%u and iterations 0..%u", LPX_MAX_PARTITIONS,
+                        LPX_MAX_ITERATIONS);
+    return LPX_OK;
+}
+
+static int check_clu(lpx_ctx *ctx, const lpx_clu_cfg *c, size_t stride)
+{
+    if (!c || stride < 12 || (stride & 3))
+        return lpx_fail(ctx, LPX_ERR_ARG, "stride must be a multiple of 4 and at least 12 bytes");
+    if (!(c->distance_squared >= 0.0f) || !(c->distance_squared < 3.0e38f))
+        return lpx_fail(ctx, LPX_ERR_ARG, "distance_squared must be finite and >= 0");
+    return LPX_OK;
+}
+
+static int status_to_rc(lpx_ctx *ctx, uint32_t status)
+{
+    if (status == 0)
+        return LPX_OK;
+    const int rc = -(int)status;
+    if (rc == LPX_ERR_RANGE)
+        return lpx_fail(ctx, rc, "a coordinate is non-finite or |v| >= 2048 m");
+    if (rc == LPX_ERR_CAPACITY)
+        return lpx_fail(ctx, rc, "neighbour workspace too small");
+    return lpx_fail(ctx, rc, "device status %u", status);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int lpx_segment_device(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
+                                  uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes,
+                                  uint32_t *d_counts)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    int rc = check_seg(ctx, cfg, stride);
+    if (rc)
+        return rc;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_for(ctx, n)))
+        return rc;
+    if ((rc = lpx_run_segment(ctx, d_pts, stride, n, cfg, d_labels, d_gidx, d_oidx, d_planes)))
+        return rc;
+    if (d_counts)
+        LPX_HIP(ctx, hipMemcpyAsync(d_counts, ctx->frame.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
+    return LPX_OK;
+}
+
+extern "C" int lpx_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m, const lpx_clu_cfg *cfg,
+                                  int32_t *d_labels, uint32_t *d_counts)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    int rc = check_clu(ctx, cfg, stride);
+    if (rc)
+        return rc;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_for(ctx, m)))
+        return rc;
+    LPX_HIP(ctx, hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream));
+    if ((rc = lpx_ingest_obstacles(ctx, d_pts, stride, m)))
+        return rc;
+    if ((rc = lpx_run_cluster(ctx, m, cfg, d_labels)))
+        return rc;
+    if (d_counts)
+        LPX_HIP(ctx, hipMemcpyAsync(d_counts, ctx->frame.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
+    return LPX_OK;
+}
+
+extern "C" int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n,
+                                          const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, uint32_t *d_labels,
+                                          uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes, int32_t *d_clabels,
+                                          uint32_t *d_counts)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    int rc = check_seg(ctx, seg_cfg, stride);
+    if (rc || (rc = check_clu(ctx, clu_cfg, stride)))
+        return rc;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_for(ctx, n)))
+        return rc;
+    if ((rc = lpx_run_segment(ctx, d_pts, stride, n, seg_cfg, d_labels, d_gidx, d_oidx, d_planes)))
+        return rc;
+    if (!d_clabels)
+        d_clabels = (int32_t *)ctx->d_clabels.p;
+    if ((rc = lpx_run_cluster(ctx, n, clu_cfg, d_clabels)))  // n bounds the obstacle count
+        return rc;
+    if (d_counts)
+        LPX_HIP(ctx, hipMemcpyAsync(d_counts, ctx->frame.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
+    return LPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------------
+static int upload(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n)
+{
+    int rc = lpx_ensure(ctx, ctx->in_aos, stride * (size_t)n + 64);
+    if (rc)
+        return rc;
+    if (n)
+        LPX_HIP(ctx, hipMemcpyAsync(ctx->in_aos.p, pts, stride * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    return LPX_OK;
+}
+
+static int read_frame(lpx_ctx *ctx, FrameState *fs)
+{
+    LPX_HIP(ctx, hipMemcpyAsync(fs, ctx->frame.p, sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LPX_OK;
+}
+
+static int download_segment(lpx_ctx *ctx, uint32_t n, uint32_t P, uint32_t *labels, uint32_t *gidx, uint32_t *n_ground,
+                            uint32_t *oidx, uint32_t *n_obstacle, float *planes, FrameState *fs)
+{
+    if (labels && n)
+        LPX_HIP(ctx, hipMemcpyAsync(labels, ctx->d_labels.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (planes)
+        LPX_HIP(ctx, hipMemcpyAsync(planes, ctx->d_planes.p, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = read_frame(ctx, fs);
+    if (rc)
+        return rc;
+    if ((rc = status_to_rc(ctx, fs->status)) && rc != LPX_ERR_CAPACITY)
+        return rc;
+    if (gidx && fs->n_ground)
+        LPX_HIP(ctx, hipMemcpyAsync(gidx, ctx->d_gidx.p, sizeof(uint32_t) * fs->n_ground, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    if (oidx && fs->n_obstacle)
+        LPX_HIP(ctx, hipMemcpyAsync(oidx, ctx->d_oidx.p, sizeof(uint32_t) * fs->n_obstacle, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_ground)
+        *n_ground = fs->n_ground;
+    if (n_obstacle)
+        *n_obstacle = fs->n_obstacle;
+    return LPX_OK;
+}
+
+extern "C" int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
+                           uint32_t *labels, uint32_t *gidx, uint32_t *n_ground, uint32_t *oidx, uint32_t *n_obstacle,
+                           float *planes)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    if (n_ground)
+        *n_ground = 0;
+    if (n_obstacle)
+        *n_obstacle = 0;
+    int rc = check_seg(ctx, cfg, stride);
+    if (rc)
+        return rc;
+    if (n && !pts)
+        return lpx_fail(ctx, LPX_ERR_ARG, "null points");
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_for(ctx, n)) || (rc = upload(ctx, pts, stride, n)))
+        return rc;
+    if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, n, cfg, (uint32_t *)ctx->d_labels.p,
+                              (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
+        return rc;
+    FrameState fs;
+    return download_segment(ctx, n, cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle, planes,
+                            &fs);
+}
+
+// run the clustering of the obstacle SoA resident in ctx; grows the neighbour workspace on demand
+static int cluster_resident(lpx_ctx *ctx, uint32_t m, const lpx_clu_cfg *cfg, int32_t *labels, uint32_t *n_clusters)
+{
+    int rc;
+    FrameState fs;
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+        if ((rc = lpx_run_cluster(ctx, m, cfg, (int32_t *)ctx->d_clabels.p)))
+            return rc;
+        if ((rc = read_frame(ctx, &fs)))
+            return rc;
+        if (fs.status == (uint32_t)(-LPX_ERR_CAPACITY) && attempt == 0)
+        {
+            if (fs.nb_total > 0xfffffff0ull)
+                return lpx_fail(ctx, LPX_ERR_CAPACITY, "neighbour lists need %llu entries (> 2^32)",
+                                (unsigned long long)fs.nb_total);
+            uint64_t want = fs.nb_total + fs.nb_total / 8 + 1024;
+            if (want > 0xfffffff0ull)
+                want = 0xfffffff0ull;
+            if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, want)))
+                return rc;
+            const uint32_t zero = 0;
+            LPX_HIP(ctx, hipMemcpyAsync(&((FrameState *)ctx->frame.p)->status, &zero, 4, hipMemcpyHostToDevice,
+                                        ctx->stream));
+            continue;
+        }
+        break;
+    }
+    if ((rc = status_to_rc(ctx, fs.status)))
+        return rc;
+    if (labels && m)
+        LPX_HIP(ctx, hipMemcpyAsync(labels, ctx->d_clabels.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_clusters)
+        *n_clusters = fs.n_clusters;
+    return LPX_OK;
+}
+
+extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t m, const lpx_clu_cfg *cfg,
+                           int32_t *labels, uint32_t *n_clusters)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    if (n_clusters)
+        *n_clusters = 0;
+    int rc = check_clu(ctx, cfg, stride);
+    if (rc)
+        return rc;
+    if (m == 0)  // src/clustering.cpp:51-54
+        return LPX_OK;
+    if (!pts)
+        return lpx_fail(ctx, LPX_ERR_ARG, "null points");
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_for(ctx, m)) || (rc = upload(ctx, pts, stride, m)))
+        return rc;
+    LPX_HIP(ctx, hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream));
+    if ((rc = lpx_ingest_obstacles(ctx, ctx->in_aos.p, stride, m)))
+        return rc;
+    return cluster_resident(ctx, m, cfg, labels, n_clusters);
+}
+
+extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *seg_cfg,
+                                   const lpx_clu_cfg *clu_cfg, uint32_t *labels, uint32_t *gidx, uint32_t *n_ground,
+                                   uint32_t *oidx, uint32_t *n_obstacle, float *planes, int32_t *cluster_labels,
+                                   uint32_t *n_clusters)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    if (n_ground)
+        *n_ground = 0;
+    if (n_obstacle)
+        *n_obstacle = 0;
+    if (n_clusters)
+        *n_clusters = 0;
+    int rc = check_seg(ctx, seg_cfg, stride);
+    if (rc || (rc = check_clu(ctx, clu_cfg, stride)))
+        return rc;
+    if (n && !pts)
+        return lpx_fail(ctx, LPX_ERR_ARG, "null points");
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_for(ctx, n)) || (rc = upload(ctx, pts, stride, n)))
+        return rc;
+    if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, n, seg_cfg, (uint32_t *)ctx->d_labels.p,
+                              (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
+        return rc;
+    FrameState fs;
+    if ((rc = download_segment(ctx, n, seg_cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle,
+                               planes, &fs)))
+        return rc;
+    if (fs.n_obstacle == 0)
+        return LPX_OK;
+    return cluster_resident(ctx, fs.n_obstacle, clu_cfg, cluster_labels, n_clusters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-level entry points for the parity tests
+// ------------------------------------------------------------------------------------------------
+extern "C" int lpx_dbg_sort_pairs(lpx_ctx *ctx, uint32_t *keys, uint32_t *values, uint32_t n, uint32_t bits)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    int rc = ensure_for(ctx, n);
+    if (rc || n == 0)
+        return rc;
+    LPX_HIP(ctx, hipMemcpyAsync(ctx->key_a.p, keys, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    LPX_HIP(ctx, hipMemcpyAsync(ctx->val_a.p, values, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *ko, *vo;
+    if ((rc = lpx_sort_pairs(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_b.p, (uint32_t *)ctx->val_a.p,
+                             (uint32_t *)ctx->val_b.p, n, nullptr, bits, &ko, &vo)))
+        return rc;
+    LPX_HIP(ctx, hipMemcpyAsync(keys, ko, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipMemcpyAsync(values, vo, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LPX_OK;
+}
+
+extern "C" int lpx_dbg_sort_keys64(lpx_ctx *ctx, uint64_t *keys, uint32_t n, uint32_t bits)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    int rc = ensure_for(ctx, n);
+    if (rc || n == 0)
+        return rc;
+    LPX_HIP(ctx, hipMemcpyAsync(ctx->key64_a.p, keys, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t *ko;
+    if ((rc = lpx_sort_keys64(ctx, (uint64_t *)ctx->key64_a.p, (uint64_t *)ctx->key64_b.p, n, bits, &ko)))
+        return rc;
+    LPX_HIP(ctx, hipMemcpyAsync(keys, ko, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LPX_OK;
+}
+
+extern "C" int lpx_dbg_scan(lpx_ctx *ctx, uint32_t *data, uint32_t n, uint64_t *total)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    int rc = ensure_for(ctx, n);
+    if (rc)
+        return rc;
+    if (n)
+        LPX_HIP(ctx, hipMemcpyAsync(ctx->key_a.p, data, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t *d_total = (uint64_t *)ctx->d_counts.p;
+    if ((rc = lpx_exclusive_scan(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_a.p, n, nullptr, d_total)))
+        return rc;
+    if (n)
+        LPX_HIP(ctx, hipMemcpyAsync(data, ctx->key_a.p, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipMemcpyAsync(total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LPX_OK;
+}
+
+static int upload_xyz_as_obstacles(lpx_ctx *ctx, const float *xyz, uint32_t m)
+{
+    int rc = ensure_for(ctx, m);
+    if (rc || (rc = upload(ctx, xyz, 12, m)))
+        return rc;
+    LPX_HIP(ctx, hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream));
+    return lpx_ingest_obstacles(ctx, ctx->in_aos.p, 12, m);
+}
+
+extern "C" int lpx_dbg_kd_layout(lpx_ctx *ctx, const float *xyz, uint32_t m, uint32_t *layout_idx)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    if (m == 0)
+        return LPX_OK;
+    int rc = upload_xyz_as_obstacles(ctx, xyz, m);
+    if (rc || (rc = lpx_kd_build(ctx, m)) || (rc = lpx_kd_layout_copy(ctx, m, (uint32_t *)ctx->key_a.p)))
+        return rc;
+    LPX_HIP(ctx, hipMemcpyAsync(layout_idx, ctx->key_a.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LPX_OK;
+}
+
+extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint64_t *offsets,
+                                  uint32_t *idx, float *dist, uint64_t capacity)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    offsets[0] = 0;
+    if (m == 0)
+        return LPX_OK;
+    int rc = upload_xyz_as_obstacles(ctx, xyz, m);
+    if (rc || (rc = lpx_kd_build(ctx, m)))
+        return rc;
+    FrameState fs;
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+        if ((rc = lpx_neighbours(ctx, m, r2, false)) || (rc = read_frame(ctx, &fs)))
+            return rc;
+        if (fs.status == (uint32_t)(-LPX_ERR_CAPACITY) && attempt == 0 && fs.nb_total <= 0xfffffff0ull)
+        {
+            if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, fs.nb_total + 1024)))
+                return rc;
+            const uint32_t zero = 0;
+            LPX_HIP(ctx, hipMemcpyAsync(&((FrameState *)ctx->frame.p)->status, &zero, 4, hipMemcpyHostToDevice,
+                                        ctx->stream));
+            continue;
+        }
+        break;
+    }
+    if ((rc = status_to_rc(ctx, fs.status)))
+        return rc;
+    uint32_t *off32 = (uint32_t *)malloc(4 * ((size_t)m + 1));
+    LPX_HIP(ctx, hipMemcpyAsync(off32, ctx->nb_off.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < m; ++i)
+        offsets[i] = off32[i];
+    offsets[m] = fs.nb_total;
+    free(off32);
+    if (fs.nb_total > capacity)
+        return lpx_fail(ctx, LPX_ERR_CAPACITY, "caller buffers hold %llu entries, %llu needed",
+                        (unsigned long long)capacity, (unsigned long long)fs.nb_total);
+    if (fs.nb_total)
+    {
+        LPX_HIP(ctx, hipMemcpyAsync(idx, ctx->nb_idx.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
+        LPX_HIP(ctx, hipMemcpyAsync(dist, ctx->nb_dist.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LPX_OK;
+}
+
+__global__ void dbg_roots_kernel(uint32_t *parent, uint32_t m, uint32_t *root)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m)
+        return;
+    uint32_t x = i;
+    while (parent[x] != x)
+        x = parent[x];
+    root[i] = x;
+}
+
+extern "C" int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint32_t *root)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    if (m == 0)
+        return LPX_OK;
+    int rc = upload_xyz_as_obstacles(ctx, xyz, m);
+    if (rc || (rc = lpx_kd_build(ctx, m)))
+        return rc;
+    FrameState fs;
+    for (int attempt = 0; attempt < 2; ++attempt)
+    {
+        if ((rc = lpx_neighbours(ctx, m, r2, true)) || (rc = read_frame(ctx, &fs)))
+            return rc;
+        if (fs.status == (uint32_t)(-LPX_ERR_CAPACITY) && attempt == 0 && fs.nb_total <= 0xfffffff0ull)
+        {
+            if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, fs.nb_total + 1024)))
+                return rc;
+            const uint32_t zero = 0;
+            LPX_HIP(ctx, hipMemcpyAsync(&((FrameState *)ctx->frame.p)->status, &zero, 4, hipMemcpyHostToDevice,
+                                        ctx->stream));
+            continue;
+        }
+        break;
+    }
+    if ((rc = status_to_rc(ctx, fs.status)))
+        return rc;
+    hipLaunchKernelGGL(dbg_roots_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t *)ctx->parent.p, m,
+                       (uint32_t *)ctx->key_a.p);
+    LPX_HIP(ctx, hipMemcpyAsync(root, ctx->key_a.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LPX_OK;
+}
+
+int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out);
+
+// plane of all n points through the device moment + Jacobi path; returns 1 if the fit failed (n < 3)
+extern "C" int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    int rc = ensure_for(ctx, n);
+    if (rc || (rc = upload(ctx, xyz, 12, n)))
+        return rc;
+    if ((rc = lpx_dbg_plane_run(ctx, ctx->in_aos.p, n, (float *)ctx->d_planes.p)))
+        return rc;
+    float out[5];
+    LPX_HIP(ctx, hipMemcpyAsync(out, ctx->d_planes.p, sizeof out, hipMemcpyDeviceToHost, ctx->stream));
+    FrameState fs;
+    if ((rc = read_frame(ctx, &fs)))
+        return rc;
+    if ((rc = status_to_rc(ctx, fs.status)))
+        return rc;
+    memcpy(plane, out, 16);
+    return out[4] != 0.0f ? 1 : 0;
+}

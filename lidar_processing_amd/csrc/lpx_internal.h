@@ -1,0 +1,222 @@
+// lpx_internal.h -- shared declarations of the MI355X (gfx950) hot-path library.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "lpx.h"
+
+// ------------------------------------------------------------------------------------------------
+// stages (for lpx_profile_*)
+// ------------------------------------------------------------------------------------------------
+enum lpx_stage
+{
+    ST_INGEST = 0,   // AoS -> SoA + x keys
+    ST_XSORT,        // radix sort by (x, index)
+    ST_GATHER,       // x-sorted SoA + composite (segment, z) keys
+    ST_ZSORT,        // radix sort of (segment, z) keys
+    ST_SEEDS,        // per-segment seed thresholds
+    ST_PLANE,        // fused inlier test + moment accumulation + 3x3 solve (I launches + seed pass)
+    ST_COMPACT,      // final flags -> labels, ground/obstacle lists, obstacle SoA
+    ST_KD_BUILD,     // kd-tree layout (libstdc++ introselect order)
+    ST_NB_COUNT,     // radius neighbour count
+    ST_NB_SCAN,      // CSR offsets
+    ST_NB_FILL,      // radius neighbour fill + union-find hooking
+    ST_CC,           // flatten roots, sort members by (root, index), component ranges
+    ST_REPLAY,       // ordered FEC replay, one wavefront per component
+    ST_LABELS,       // dense relabel
+    ST_COUNT
+};
+
+// ------------------------------------------------------------------------------------------------
+// device-side frame state (one per context, lives in HBM)
+// ------------------------------------------------------------------------------------------------
+struct FrameState
+{
+    uint32_t n_ground;
+    uint32_t n_obstacle;  // M: number of points handed to clustering
+    uint32_t n_clusters;
+    uint32_t status;      // 0 ok, else -LPX_ERR_*
+    uint64_t nb_total;    // total neighbour entries required
+    uint32_t pad[2];
+};
+
+#define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
+
+struct SegState  // per segment
+{
+    float lo_excl;   // seeds: z > lo_excl
+    float hi_incl;   //        z <= hi_incl
+    uint32_t has_seeds;
+    uint32_t failed;  // sticky: treat everything as obstacle (reference src/segmentation.cpp:251-259)
+    float plane[4];
+    uint32_t fitted;  // at least one plane was fitted
+    float thr;        // orthogonal_distance_threshold * |normal| of `plane`
+    uint32_t pad[2];
+};
+
+struct Buf
+{
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct lpx_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char err[512] = {0};
+
+    uint32_t cap_n = 0;        // points
+    uint64_t cap_nb = 0;       // neighbour entries
+    uint32_t nb_per_point = 256;
+
+    // ---- segmentation buffers (cap_n) ----
+    Buf in_aos;                // staging for host input
+    Buf X, Y, Z;               // original order SoA
+    Buf key_a, key_b;          // u32 keys ping-pong
+    Buf val_a, val_b;          // u32 values ping-pong
+    Buf key64_a, key64_b;      // u64 keys ping-pong
+    Buf XS, YS, ZS;            // x-sorted SoA
+    Buf flags;                 // u8 per sorted position
+    Buf hist;                  // radix histograms / scan scratch
+    Buf seg_state;             // SegState[LPX_MAX_PARTITIONS]
+    Buf seg_acc;               // int64 [LPX_MAX_PARTITIONS][LPX_ACC_WORDS] + tickets
+    Buf blk_counts;            // per block ground / obstacle counts
+    Buf d_labels, d_gidx, d_oidx, d_planes, d_counts;  // outputs for host API
+    // ---- clustering buffers ----
+    Buf OX, OY, OZ;            // obstacle SoA (cap_n)
+    Buf nodes;                 // float4 kd nodes
+    Buf lpos, rpos;            // partition scratch
+    Buf nb_len, nb_off;        // u32 len, u32 off (cap_n + 1)
+    Buf nb_idx, nb_dist;       // cap_nb
+    Buf parent;                // union-find
+    Buf cc_lo, cc_hi;          // member range per root
+    Buf state;                 // u8 replay state
+    Buf seed_of;               // i32
+    Buf queue;                 // u32
+    Buf valid;                 // u32 per seed
+    Buf d_clabels;
+    Buf frame;                 // FrameState
+    // ---- pinned host staging ----
+    void *h_pinned = nullptr;
+    size_t h_pinned_bytes = 0;
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev_a[ST_COUNT], ev_b[ST_COUNT];
+    bool ev_ready = false;
+    float st_ms[ST_COUNT] = {0};
+    uint32_t st_launches[ST_COUNT] = {0};
+    // deferred event pairs recorded in the current call
+    struct Pending { int stage; hipEvent_t a, b; };
+    Pending *pending = nullptr;
+    int n_pending = 0, cap_pending = 0;
+};
+
+int lpx_fail(lpx_ctx *ctx, int code, const char *fmt, ...);
+int lpx_ensure(lpx_ctx *ctx, Buf &b, size_t bytes);
+int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb);
+
+#define LPX_HIP(ctx, call)                                                                                          \
+    do                                                                                                              \
+    {                                                                                                               \
+        hipError_t e_ = (call);                                                                                     \
+        if (e_ != hipSuccess)                                                                                       \
+            return lpx_fail((ctx), LPX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                            __LINE__);                                                                              \
+    } while (0)
+
+struct StageTimer
+{
+    lpx_ctx *ctx;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(lpx_ctx *c, int s);
+    ~StageTimer();
+};
+
+// ------------------------------------------------------------------------------------------------
+// primitives (lpx_primitives.hip)
+// ------------------------------------------------------------------------------------------------
+// stable LSD radix sort, 8 bits per pass over key bits [0, bits); result ends in the *_a buffers
+// (function copies if the pass count is odd).  n is a host upper bound; d_n (optional) the device count.
+int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
+                   const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out);
+int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, uint32_t bits, uint64_t **keys_out);
+// exclusive scan (u32 in, u32 out, in place allowed); total (u64) written to *d_total if not null.
+int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n,
+                       uint64_t *d_total);
+
+// ------------------------------------------------------------------------------------------------
+// pipeline stages
+// ------------------------------------------------------------------------------------------------
+int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
+                    uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes);
+// clustering of the obstacle SoA already in ctx->OX/OY/OZ, count in frame->n_obstacle (bound m_max)
+int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels);
+// AoS (device) -> ctx->OX/OY/OZ, sets frame->n_obstacle = m
+int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m);
+
+int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max);
+int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook);
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+#define WAVE 64
+
+// order-preserving key of a float under operator< with -0 == +0 (ties are broken by index later)
+__device__ __forceinline__ uint32_t lpx_float_key(float f)
+{
+    f = f + 0.0f;  // -0 -> +0
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float lpx_key_float(uint32_t k)
+{
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+__device__ __forceinline__ unsigned long long lpx_lanemask_lt()
+{
+    const unsigned lane = __lane_id();
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+__device__ __forceinline__ long long lpx_wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ uint32_t lpx_wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// inclusive scan inside a wave
+__device__ __forceinline__ uint32_t lpx_wave_incl_scan_u32(uint32_t v)
+{
+    const unsigned lane = __lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= (unsigned)o)
+            v += t;
+    }
+    return v;
+}
+
+#endif  // __HIPCC__

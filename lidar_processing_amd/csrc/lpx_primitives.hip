@@ -1,0 +1,254 @@
+// lpx_primitives.hip -- stable LSD radix sort and exclusive scan for gfx950 (wave64).
+//
+// Replaces the two std::sort(std::execution::par, ...) index sorts of the reference
+// (src/segmentation.cpp:119-122, :165-168) and orders component members for the FEC replay.
+// Sorting iota by key with a STABLE sort gives the canonical (key, index) tie order.
+//
+// Layout: a tile is 4 wavefronts x ITEMS rounds x 64 lanes; element order inside a tile is
+// (wave, round, lane), i.e. ascending address, so ranks computed per (wave, digit) are stable.
+// Per pass: histogram (digit-major [256][blocks]) -> single-block exclusive scan -> scatter.
+#include "lpx_internal.h"
+
+namespace
+{
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / WAVE;
+constexpr int SORT_ITEMS = 8;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
+constexpr int RADIX = 256;
+
+template <typename KeyT>
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__restrict__ keys, uint32_t n_max,
+                                                                   const uint32_t *__restrict__ d_n, uint32_t shift,
+                                                                   uint32_t *__restrict__ hist, uint32_t nblocks)
+{
+    __shared__ uint32_t h[RADIX];
+    const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r)
+    {
+        const uint32_t e = base + r * SORT_THREADS + threadIdx.x;
+        if (e < n)
+            atomicAdd(&h[(uint32_t)(keys[e] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename KeyT, bool HAS_VALS>
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT *__restrict__ keys_in,
+                                                                      KeyT *__restrict__ keys_out,
+                                                                      const uint32_t *__restrict__ vals_in,
+                                                                      uint32_t *__restrict__ vals_out, uint32_t n_max,
+                                                                      const uint32_t *__restrict__ d_n, uint32_t shift,
+                                                                      const uint32_t *__restrict__ offs,
+                                                                      uint32_t nblocks)
+{
+    __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
+    const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t w = tid / WAVE, lane = tid % WAVE;
+    for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS)
+        (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const uint32_t chunk = blockIdx.x * SORT_TILE + w * (SORT_ITEMS * WAVE);
+    const unsigned long long lt = lpx_lanemask_lt();
+    KeyT k[SORT_ITEMS];
+    uint32_t v[SORT_ITEMS];
+    uint32_t loc[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r)
+    {
+        const uint32_t e = chunk + r * WAVE + lane;
+        const bool valid = e < n;
+        k[r] = valid ? keys_in[e] : (KeyT)0;
+        if (HAS_VALS)
+            v[r] = valid ? vals_in[e] : 0u;
+        const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+        {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        if (!valid)
+            m = 0;
+        const uint32_t rank = __popcll(m & lt);
+        uint32_t old = 0;
+        if (valid)
+            old = wcnt[w][d];
+        // every lane of the group has read before the leader writes: one wave, in-order LDS
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0)
+            wcnt[w][d] = old + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        loc[r] = old + rank;
+    }
+    __syncthreads();
+    // digit `tid`: exclusive prefix over waves + global offset of this (digit, block)
+    {
+        uint32_t run = offs[tid * nblocks + blockIdx.x];
+#pragma unroll
+        for (int ww = 0; ww < SORT_WAVES; ++ww)
+        {
+            const uint32_t c = wcnt[ww][tid];
+            wcnt[ww][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r)
+    {
+        const uint32_t e = chunk + r * WAVE + lane;
+        if (e < n)
+        {
+            const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
+            const uint32_t dst = wcnt[w][d] + loc[r];
+            keys_out[dst] = k[r];
+            if (HAS_VALS)
+                vals_out[dst] = v[r];
+        }
+    }
+}
+
+// single-block exclusive scan; SCAN_THREADS x 4 elements per iteration
+constexpr int SCAN_THREADS = 1024;
+
+// in == out is allowed (no __restrict__): every thread reads its 4 inputs before it writes them
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint32_t *in, uint32_t *out, uint32_t n_max,
+                                                             const uint32_t *d_n, uint64_t *d_total)
+{
+    __shared__ uint32_t wsum[SCAN_THREADS / WAVE];
+    __shared__ unsigned long long carry_s;
+    const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
+    const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
+    if (tid == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += SCAN_THREADS * 4)
+    {
+        const uint32_t e = base + tid * 4;
+        uint32_t a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = (e + i < n) ? in[e + i] : 0u;
+        const uint32_t tsum = a[0] + a[1] + a[2] + a[3];
+        const uint32_t incl = lpx_wave_incl_scan_u32(tsum);
+        if (lane == WAVE - 1)
+            wsum[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, blk = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_THREADS / WAVE; ++i)
+        {
+            const uint32_t s = wsum[i];
+            if (i < (int)w)
+                wbase += s;
+            blk += s;
+        }
+        const unsigned long long carry = carry_s;
+        uint32_t run = (uint32_t)carry + wbase + (incl - tsum);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            if (e + i < n)
+                out[e + i] = run;
+            run += a[i];
+        }
+        __syncthreads();
+        if (tid == 0)
+            carry_s = carry + blk;
+        __syncthreads();
+    }
+    if (tid == 0 && d_total)
+        *d_total = carry_s;
+}
+
+__global__ void copy_u32_kernel(const uint32_t *__restrict__ a, uint32_t *__restrict__ b, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        b[i] = a[i];
+}
+}  // namespace
+
+static inline uint32_t sort_blocks(uint32_t n)
+{
+    return n == 0 ? 1u : (n + SORT_TILE - 1) / SORT_TILE;
+}
+
+static int ensure_hist(lpx_ctx *ctx, uint32_t nblocks)
+{
+    return lpx_ensure(ctx, ctx->hist, (size_t)RADIX * nblocks * sizeof(uint32_t) + 64);
+}
+
+int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n,
+                       uint64_t *d_total)
+{
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, d_total);
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
+                   const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out)
+{
+    const uint32_t nblocks = sort_blocks(n);
+    int rc = ensure_hist(ctx, nblocks);
+    if (rc)
+        return rc;
+    uint32_t *hist = (uint32_t *)ctx->hist.p;
+    uint32_t *ka = keys_a, *kb = keys_b, *va = vals_a, *vb = vals_b;
+    for (uint32_t shift = 0; shift < bits; shift += 8)
+    {
+        hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
+                           d_n, shift, hist, nblocks);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist, RADIX * nblocks,
+                           (const uint32_t *)nullptr, (uint64_t *)nullptr);
+        hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream,
+                           ka, kb, va, vb, n, d_n, shift, hist, nblocks);
+        uint32_t *t = ka;
+        ka = kb;
+        kb = t;
+        t = va;
+        va = vb;
+        vb = t;
+    }
+    LPX_HIP(ctx, hipGetLastError());
+    *keys_out = ka;
+    *vals_out = va;
+    return LPX_OK;
+}
+
+int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, uint32_t bits, uint64_t **keys_out)
+{
+    const uint32_t nblocks = sort_blocks(n);
+    int rc = ensure_hist(ctx, nblocks);
+    if (rc)
+        return rc;
+    uint32_t *hist = (uint32_t *)ctx->hist.p;
+    uint64_t *ka = keys_a, *kb = keys_b;
+    for (uint32_t shift = 0; shift < bits; shift += 8)
+    {
+        hipLaunchKernelGGL((radix_hist_kernel<uint64_t>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
+                           (const uint32_t *)nullptr, shift, hist, nblocks);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist, RADIX * nblocks,
+                           (const uint32_t *)nullptr, (uint64_t *)nullptr);
+        hipLaunchKernelGGL((radix_scatter_kernel<uint64_t, false>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream,
+                           ka, kb, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, (const uint32_t *)nullptr, shift,
+                           hist, nblocks);
+        uint64_t *t = ka;
+        ka = kb;
+        kb = t;
+    }
+    LPX_HIP(ctx, hipGetLastError());
+    *keys_out = ka;
+    return LPX_OK;
+}

@@ -1,0 +1,834 @@
+// lpx_segment.hip -- ground segmentation on gfx950.
+//
+// Replaces Segmenter::segment (reference src/segmentation.cpp:311-345) and what it calls:
+//   form_planar_partitions :104-149   -> ingest + radix sort by (x, index) + x-sorted SoA gather
+//   extract_initial_seeds  :151-217   -> radix sort of (segment, z) keys + seed_kernel
+//   estimate_plane_coefficients :62-102 and fit_ground_plane :219-309
+//                                     -> plane_pass_kernel (inlier test fused with the moment
+//                                        accumulation of the next fit; last block solves the 3x3)
+//   label / cloud scatter  :327-344   -> compact_kernel
+//
+// Data layout in HBM: SoA float arrays in x-sorted order (XS, YS, ZS), so a segment is one
+// contiguous range and every pass is a coalesced stream of 12 B/point.  Moments are exact integers
+// (coordinates rounded to 2^-16 m, |q| < 2^27): int64 lanes, wave64 shuffle reduction, one set of
+// 64-bit atomics per block -- the sums do not depend on the order of accumulation, so the plane
+// is bit-identical to the oracle's.
+#include "lpx_internal.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace
+{
+constexpr int SEG_THREADS = 256;
+constexpr int SEG_WAVES = SEG_THREADS / WAVE;
+constexpr uint32_t SEG_CHUNK = 4096;  // points per block (16 per thread; bound for int64 lanes is 256)
+constexpr float FIX_SCALE = 65536.0f;
+constexpr float FIX_LIMIT = 2048.0f;
+
+struct SegParams
+{
+    uint32_t n;        // points in the frame
+    uint32_t n_per;    // points per segment (n / P)
+    uint32_t P;
+    uint32_t I;
+    uint32_t bps;      // blocks per segment
+    uint32_t chunk;    // points per block
+    float z_floor;     // -1.5 * sensor_height
+    float seed_thr;    // initial_seed_threshold
+    float odt;         // orthogonal_distance_threshold
+    uint32_t n_lpr;
+};
+
+// ------------------------------------------------------------------------------------------------
+// K0 ingest: strided AoS -> SoA, x keys, iota; range check
+// ------------------------------------------------------------------------------------------------
+__global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, uint32_t n, float *__restrict__ X,
+                              float *__restrict__ Y, float *__restrict__ Z, uint32_t *__restrict__ key,
+                              uint32_t *__restrict__ val, FrameState *__restrict__ frame)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float *p = (const float *)(pts + (size_t)i * stride);
+    const float x = p[0], y = p[1], z = p[2];
+    X[i] = x;
+    Y[i] = y;
+    Z[i] = z;
+    if (key)
+    {
+        key[i] = lpx_float_key(x);
+        val[i] = i;
+    }
+    if (!(fabsf(x) < FIX_LIMIT) || !(fabsf(y) < FIX_LIMIT) || !(fabsf(z) < FIX_LIMIT))
+        frame->status = (uint32_t)(-LPX_ERR_RANGE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather into x-sorted SoA + composite (segment, z) keys
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float *__restrict__ X,
+                              const float *__restrict__ Y, const float *__restrict__ Z, float *__restrict__ XS,
+                              float *__restrict__ YS, float *__restrict__ ZS, uint64_t *__restrict__ zkey,
+                              SegParams prm)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= prm.n)
+        return;
+    const uint32_t i = sidx[p];
+    const float z = Z[i];
+    XS[p] = X[i];
+    YS[p] = Y[i];
+    ZS[p] = z;
+    uint32_t seg = prm.n_per ? p / prm.n_per : prm.P;
+    if (seg > prm.P)
+        seg = prm.P;  // the N mod P tail (Q2) sorts behind every segment
+    zkey[p] = ((uint64_t)seg << 32) | lpx_float_key(z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// seeds: one block per segment over the z-sorted keys (extract_initial_seeds, :151-217)
+// ------------------------------------------------------------------------------------------------
+constexpr int SEED_LDS = 4096;
+
+__global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__restrict__ zsorted, SegParams prm,
+                                                            SegState *__restrict__ st, long long *__restrict__ acc,
+                                                            uint32_t *__restrict__ ticket)
+{
+    __shared__ float zbuf[SEED_LDS];
+    __shared__ float s_sum;
+    __shared__ uint32_t s_cut;
+    const uint32_t s = blockIdx.x;
+    const uint32_t ns = prm.n_per;
+    const uint64_t *zs = zsorted + (size_t)s * ns;
+    const uint32_t tid = threadIdx.x;
+
+    if (tid < LPX_ACC_WORDS)
+        acc[s * LPX_ACC_WORDS + tid] = 0;
+    if (tid == 0)
+        ticket[s] = 0;
+
+    // first index with z > z_floor (sorted ascending): upper bound
+    if (tid == 0)
+    {
+        uint32_t lo = 0, hi = ns;
+        while (lo < hi)
+        {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            const float z = lpx_key_float((uint32_t)zs[mid]);
+            if (z > prm.z_floor)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        s_cut = (lo < ns) ? lo : 0u;  // :171-182 no point above the floor -> nothing dropped
+        s_sum = 0.0f;
+    }
+    __syncthreads();
+    const uint32_t cut = s_cut;
+    const uint32_t nrem = ns - cut;
+    const uint32_t n_rep = min(nrem, prm.n_lpr);
+    // sequential float sum in ascending z (:193-197): staged through LDS, added by one lane
+    for (uint32_t base = 0; base < n_rep; base += SEED_LDS)
+    {
+        const uint32_t cnt = min((uint32_t)SEED_LDS, n_rep - base);
+        for (uint32_t i = tid; i < cnt; i += SEG_THREADS)
+            zbuf[i] = lpx_key_float((uint32_t)zs[cut + base + i]);
+        __syncthreads();
+        if (tid == 0)
+        {
+            float sum = s_sum;
+            for (uint32_t i = 0; i < cnt; ++i)
+                sum += zbuf[i];
+            s_sum = sum;
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+    {
+        const float z_mean = s_sum / (float)n_rep;
+        const float z_max = z_mean + prm.seed_thr;
+        // first index in the remainder with z > z_max; none -> no seeds (Q4)
+        uint32_t lo = 0, hi = nrem;
+        while (lo < hi)
+        {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            const float z = lpx_key_float((uint32_t)zs[cut + mid]);
+            if (z > z_max)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const uint32_t n_seed = (lo < nrem) ? lo : 0u;
+        SegState o;
+        o.lo_excl = (cut > 0) ? prm.z_floor : -INFINITY;
+        o.hi_incl = z_max;
+        o.has_seeds = n_seed > 0;
+        o.failed = (ns < 3) ? 2u : 0u;  // :224-229 nothing is labelled
+        o.plane[0] = o.plane[1] = o.plane[2] = o.plane[3] = 0.0f;
+        o.fitted = 0;
+        o.thr = 0.0f;
+        o.pad[0] = o.pad[1] = 0;
+        st[s] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 Jacobi SVD (Eigen 3.4 JacobiSVD<Matrix3f> algorithm as used at src/segmentation.cpp:87-94)
+// ------------------------------------------------------------------------------------------------
+struct JRot
+{
+    float c, s;
+};
+
+__device__ JRot make_jacobi(float x, float y, float z)
+{
+    JRot j;
+    const float deno = 2.0f * fabsf(y);
+    if (deno < FLT_MIN)
+    {
+        j.c = 1.0f;
+        j.s = 0.0f;
+        return j;
+    }
+    const float tau = (x - z) / deno;
+    const float w = sqrtf(tau * tau + 1.0f);
+    float t;
+    if (tau > 0.0f)
+        t = 1.0f / (tau + w);
+    else
+        t = 1.0f / (tau - w);
+    const float sign_t = t > 0.0f ? 1.0f : -1.0f;
+    const float n = 1.0f / sqrtf(t * t + 1.0f);
+    j.s = -sign_t * (y / fabsf(y)) * fabsf(t) * n;
+    j.c = n;
+    return j;
+}
+
+__device__ void rot_left(float *w, int p, int q, JRot j)
+{
+    if (j.c == 1.0f && j.s == 0.0f)
+        return;
+    for (int i = 0; i < 3; ++i)
+    {
+        const float xi = w[p * 3 + i], yi = w[q * 3 + i];
+        w[p * 3 + i] = j.c * xi + j.s * yi;
+        w[q * 3 + i] = -j.s * xi + j.c * yi;
+    }
+}
+
+__device__ void rot_right(float *w, int p, int q, JRot j)
+{
+    const float c = j.c, s = -j.s;
+    if (c == 1.0f && s == 0.0f)
+        return;
+    for (int i = 0; i < 3; ++i)
+    {
+        const float xi = w[i * 3 + p], yi = w[i * 3 + q];
+        w[i * 3 + p] = c * xi + s * yi;
+        w[i * 3 + q] = -s * xi + c * yi;
+    }
+}
+
+// returns false if the matrix is not finite
+__device__ bool jacobi_svd3(const float *a, float *v)
+{
+    float w[9];
+    float scale = 0.0f;
+    for (int i = 0; i < 9; ++i)
+    {
+        const float m = fabsf(a[i]);
+        if (!(m <= scale))
+            scale = m;
+    }
+    if (!isfinite(scale))
+        return false;
+    if (scale == 0.0f)
+        scale = 1.0f;
+    for (int i = 0; i < 9; ++i)
+        w[i] = a[i] / scale;
+    for (int i = 0; i < 9; ++i)
+        v[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    const float precision = 2.0f * FLT_EPSILON;
+    const float consider_as_zero = FLT_MIN;
+    float max_diag = fmaxf(fabsf(w[0]), fmaxf(fabsf(w[4]), fabsf(w[8])));
+    bool finished = false;
+    while (!finished)
+    {
+        finished = true;
+        for (int p = 1; p < 3; ++p)
+            for (int q = 0; q < p; ++q)
+            {
+                const float threshold = fmaxf(consider_as_zero, precision * max_diag);
+                if (fabsf(w[p * 3 + q]) > threshold || fabsf(w[q * 3 + p]) > threshold)
+                {
+                    finished = false;
+                    float m00 = w[p * 3 + p], m01 = w[p * 3 + q], m10 = w[q * 3 + p], m11 = w[q * 3 + q];
+                    JRot rot1;
+                    const float t = m00 + m11;
+                    const float d = m10 - m01;
+                    if (fabsf(d) < FLT_MIN)
+                    {
+                        rot1.s = 0.0f;
+                        rot1.c = 1.0f;
+                    }
+                    else
+                    {
+                        const float u = t / d;
+                        const float tmp = sqrtf(1.0f + u * u);
+                        rot1.s = 1.0f / tmp;
+                        rot1.c = u / tmp;
+                    }
+                    if (!(rot1.c == 1.0f && rot1.s == 0.0f))
+                    {
+                        const float a0 = m00, a1 = m01, b0 = m10, b1 = m11;
+                        m00 = rot1.c * a0 + rot1.s * b0;
+                        m01 = rot1.c * a1 + rot1.s * b1;
+                        m10 = -rot1.s * a0 + rot1.c * b0;
+                        m11 = -rot1.s * a1 + rot1.c * b1;
+                    }
+                    const JRot j_right = make_jacobi(m00, m01, m11);
+                    JRot j_left;
+                    {
+                        const float c2 = j_right.c, s2 = -j_right.s;
+                        j_left.c = rot1.c * c2 - rot1.s * s2;
+                        j_left.s = rot1.c * s2 + rot1.s * c2;
+                    }
+                    rot_left(w, p, q, j_left);
+                    rot_right(w, p, q, j_right);
+                    rot_right(v, p, q, j_right);
+                    max_diag = fmaxf(max_diag, fmaxf(fabsf(w[p * 3 + p]), fabsf(w[q * 3 + q])));
+                }
+            }
+    }
+    float sv[3];
+    for (int i = 0; i < 3; ++i)
+        sv[i] = fabsf(w[i * 3 + i]) * scale;
+    for (int i = 0; i < 3; ++i)
+    {
+        int pos = i;
+        float best = sv[i];
+        for (int k = i + 1; k < 3; ++k)
+            if (sv[k] > best)
+            {
+                best = sv[k];
+                pos = k;
+            }
+        if (best == 0.0f)
+            break;
+        if (pos != i)
+        {
+            const float ts = sv[i];
+            sv[i] = sv[pos];
+            sv[pos] = ts;
+            for (int r = 0; r < 3; ++r)
+            {
+                const float tv = v[r * 3 + i];
+                v[r * 3 + i] = v[r * 3 + pos];
+                v[r * 3 + pos] = tv;
+            }
+        }
+    }
+    return true;
+}
+
+typedef __int128 i128;
+
+__device__ double i128_to_double(i128 v)
+{
+    const bool neg = v < 0;
+    const unsigned __int128 mag = neg ? (unsigned __int128)0 - (unsigned __int128)v : (unsigned __int128)v;
+    const uint64_t hi = (uint64_t)(mag >> 64), lo = (uint64_t)mag;
+    const double d = (double)hi * 18446744073709551616.0 + (double)lo;
+    return neg ? -d : d;
+}
+
+// moments words: 0 n, 1 sx, 2 sy, 3 sz, 4.. (hi, lo) of xx, xy, xz, yy, yz, zz
+__device__ bool plane_from_moments(const long long *m, float *plane)
+{
+    const uint64_t cnt = (uint64_t)m[0];
+    if (cnt < 3)
+        return false;
+    const i128 sx = m[1], sy = m[2], sz = m[3];
+    i128 q[6];
+    for (int i = 0; i < 6; ++i)
+        q[i] = ((i128)m[4 + 2 * i] << 32) + (i128)m[5 + 2 * i];
+    const double n = (double)cnt;
+    const double den = n * (double)(cnt - 1);
+    const double inv16 = 1.0 / 65536.0, inv32 = inv16 * inv16;
+    const float cx = (float)((i128_to_double(sx) / n) * inv16);
+    const float cy = (float)((i128_to_double(sy) / n) * inv16);
+    const float cz = (float)((i128_to_double(sz) / n) * inv16);
+    const i128 N = (i128)cnt;
+    const float cxx = (float)((i128_to_double(N * q[0] - sx * sx) / den) * inv32);
+    const float cxy = (float)((i128_to_double(N * q[1] - sx * sy) / den) * inv32);
+    const float cxz = (float)((i128_to_double(N * q[2] - sx * sz) / den) * inv32);
+    const float cyy = (float)((i128_to_double(N * q[3] - sy * sy) / den) * inv32);
+    const float cyz = (float)((i128_to_double(N * q[4] - sy * sz) / den) * inv32);
+    const float czz = (float)((i128_to_double(N * q[5] - sz * sz) / den) * inv32);
+    const float cov[9] = {cxx, cxy, cxz, cxy, cyy, cyz, cxz, cyz, czz};
+    float v[9];
+    if (!jacobi_svd3(cov, v))
+        return false;
+    const float a = v[2], b = v[5], c = v[8];
+    plane[0] = a;
+    plane[1] = b;
+    plane[2] = c;
+    plane[3] = (a * cx + b * cy) + c * cz;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2+K3 fused pass.  Pass t tests every point of the segment against predicate t
+//   t == 0 : seed predicate (z window)                         (:243, :199-216)
+//   t >= 1 : signed distance to plane t-1 < thr * |normal|     (:287-307, Q1)
+// and, unless FINAL, accumulates the moments of the members for plane t (:261-273).  The last
+// block of a segment to finish solves the 3x3 problem and publishes plane t for the next launch.
+// FINAL writes the per-point flag and per-block ground/obstacle counts for the compaction.
+// ------------------------------------------------------------------------------------------------
+template <bool FINAL>
+__global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__restrict__ XS,
+                                                                  const float *__restrict__ YS,
+                                                                  const float *__restrict__ ZS, SegParams prm,
+                                                                  uint32_t t, SegState *st, long long *acc,
+                                                                  uint32_t *ticket, uint8_t *__restrict__ flags,
+                                                                  uint32_t *__restrict__ blk_counts)
+{
+    __shared__ long long red[SEG_WAVES][LPX_ACC_WORDS];
+    __shared__ uint32_t s_last;
+    const uint32_t s = blockIdx.y, b = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
+    const uint32_t seg_lo = s * prm.n_per;
+    const uint32_t lo = seg_lo + b * prm.chunk;
+    const uint32_t hi = min(lo + prm.chunk, seg_lo + prm.n_per);
+
+    const SegState sst = st[s];
+    const bool skip = sst.failed == 2;       // < 3 points: nothing labelled
+    const bool dead = sst.failed != 0;       // all obstacle
+    const float pa = sst.plane[0], pb = sst.plane[1], pc = sst.plane[2], pd = sst.plane[3];
+    const float thr = sst.thr;
+    const bool use_seed = (t == 0);
+    const bool seeds_ok = sst.has_seeds != 0;
+
+    long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
+    uint32_t cnt_g = 0, cnt_o = 0;
+
+    for (uint32_t p = lo + tid; p < hi; p += SEG_THREADS)
+    {
+        const float x = XS[p], y = YS[p], z = ZS[p];
+        bool member;
+        if (use_seed)
+            member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
+        else
+        {
+            const float dist = ((x * pa + y * pb) + z * pc) - pd;
+            member = dist < thr;
+        }
+        member = member && !dead;
+        if (FINAL)
+        {
+            // number_of_iterations == 0: seeds are ground, the rest stays UNKNOWN (:243-247)
+            const uint8_t f = skip ? 0 : (member ? 1 : ((prm.I == 0 && !dead) ? 0 : 2));
+            flags[p] = f;
+            cnt_g += (f == 1);
+            cnt_o += (f == 2);
+        }
+        else if (member)
+        {
+            const int qx = __float2int_rn(x * FIX_SCALE);
+            const int qy = __float2int_rn(y * FIX_SCALE);
+            const int qz = __float2int_rn(z * FIX_SCALE);
+            a_n += 1;
+            a_x += qx;
+            a_y += qy;
+            a_z += qz;
+            a_xx += (long long)qx * qx;
+            a_xy += (long long)qx * qy;
+            a_xz += (long long)qx * qz;
+            a_yy += (long long)qy * qy;
+            a_yz += (long long)qy * qz;
+            a_zz += (long long)qz * qz;
+        }
+    }
+
+    if (FINAL)
+    {
+        cnt_g = lpx_wave_sum_u32(cnt_g);
+        cnt_o = lpx_wave_sum_u32(cnt_o);
+        if (lane == 0)
+        {
+            red[w][0] = cnt_g;
+            red[w][1] = cnt_o;
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            uint32_t g = 0, o = 0;
+            for (int i = 0; i < SEG_WAVES; ++i)
+            {
+                g += (uint32_t)red[i][0];
+                o += (uint32_t)red[i][1];
+            }
+            const uint32_t nb = prm.P * prm.bps;
+            blk_counts[s * prm.bps + b] = g;
+            blk_counts[nb + s * prm.bps + b] = o;
+        }
+        return;
+    }
+
+    // 16 words: n, sx, sy, sz, then (hi, lo) limbs of the six second moments
+    long long v[LPX_ACC_WORDS];
+    v[0] = a_n;
+    v[1] = a_x;
+    v[2] = a_y;
+    v[3] = a_z;
+    const long long sm[6] = {a_xx, a_xy, a_xz, a_yy, a_yz, a_zz};
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+    {
+        v[4 + 2 * i] = sm[i] >> 32;
+        v[5 + 2 * i] = sm[i] & 0xffffffffLL;
+    }
+#pragma unroll
+    for (int i = 0; i < LPX_ACC_WORDS; ++i)
+    {
+        v[i] = lpx_wave_sum_i64(v[i]);
+        if (lane == 0)
+            red[w][i] = v[i];
+    }
+    __syncthreads();
+    if (tid < LPX_ACC_WORDS)
+    {
+        long long tot = 0;
+#pragma unroll
+        for (int i = 0; i < SEG_WAVES; ++i)
+            tot += red[i][tid];
+        if (tot != 0)
+            atomicAdd((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], (unsigned long long)tot);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0)
+    {
+        const uint32_t old = atomicAdd(&ticket[s], 1u);
+        s_last = (old == prm.bps - 1);
+    }
+    __syncthreads();
+    if (!s_last)
+        return;
+    __threadfence();
+    // last block of the segment: solve and publish plane t, reset the accumulators
+    if (tid == 0)
+    {
+        long long m[LPX_ACC_WORDS];
+        for (int i = 0; i < LPX_ACC_WORDS; ++i)
+        {
+            m[i] = (long long)atomicAdd((unsigned long long *)&acc[s * LPX_ACC_WORDS + i], 0ull);
+            atomicExch((unsigned long long *)&acc[s * LPX_ACC_WORDS + i], 0ull);
+        }
+        atomicExch(&ticket[s], 0u);
+        SegState o = sst;
+        if (!dead)
+        {
+            float plane[4];
+            // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
+            if (!plane_from_moments(m, plane))
+                o.failed = 1;
+            else
+            {
+                o.plane[0] = plane[0];
+                o.plane[1] = plane[1];
+                o.plane[2] = plane[2];
+                o.plane[3] = plane[3];
+                o.thr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
+                o.fitted = 1;
+            }
+            st[s] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction: flags -> labels (original order), ground / obstacle index lists in output-cloud
+// order (:331-343, Q7) and the obstacle SoA handed to clustering.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__restrict__ flags,
+                                                               const uint32_t *__restrict__ sidx,
+                                                               const float *__restrict__ XS,
+                                                               const float *__restrict__ YS,
+                                                               const float *__restrict__ ZS, SegParams prm,
+                                                               const uint32_t *__restrict__ blk_offs,
+                                                               uint32_t *__restrict__ labels,
+                                                               uint32_t *__restrict__ gidx, uint32_t *__restrict__ oidx,
+                                                               float *__restrict__ OX, float *__restrict__ OY,
+                                                               float *__restrict__ OZ, const SegState *__restrict__ st,
+                                                               float *__restrict__ planes, FrameState *frame)
+{
+    __shared__ uint32_t wg[SEG_WAVES], wo[SEG_WAVES];
+    const uint32_t s = blockIdx.y, b = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
+    const uint32_t nb = prm.P * prm.bps;
+    const uint32_t seg_lo = s * prm.n_per;
+    const uint32_t lo = seg_lo + b * prm.chunk;
+    const uint32_t hi = min(lo + prm.chunk, seg_lo + prm.n_per);
+    const uint32_t total_g = blk_offs[nb];  // exclusive scan over [G blocks | O blocks]
+    const uint32_t gbase = blk_offs[s * prm.bps + b];
+    const uint32_t obase = blk_offs[nb + s * prm.bps + b] - total_g;
+    const unsigned long long lt = lpx_lanemask_lt();
+
+    // each wave owns a contiguous quarter of the chunk
+    const uint32_t span = hi > lo ? hi - lo : 0;
+    const uint32_t per_w = (span + SEG_WAVES - 1) / SEG_WAVES;
+    const uint32_t wlo = min(lo + w * per_w, hi), whi = min(wlo + per_w, hi);
+    uint32_t cg = 0, co = 0;
+    for (uint32_t p0 = wlo; p0 < whi; p0 += WAVE)
+    {
+        const uint32_t p = p0 + lane;
+        const uint8_t f = (p < whi) ? flags[p] : 0;
+        cg += __popcll(__ballot(f == 1));
+        co += __popcll(__ballot(f == 2));
+    }
+    if (lane == 0)
+    {
+        wg[w] = cg;
+        wo[w] = co;
+    }
+    __syncthreads();
+    uint32_t gpos = gbase, opos = obase;
+    for (uint32_t i = 0; i < w; ++i)
+    {
+        gpos += wg[i];
+        opos += wo[i];
+    }
+    for (uint32_t p0 = wlo; p0 < whi; p0 += WAVE)
+    {
+        const uint32_t p = p0 + lane;
+        const bool in = p < whi;
+        const uint8_t f = in ? flags[p] : 0;
+        const unsigned long long mg = __ballot(f == 1), mo = __ballot(f == 2);
+        if (in)
+        {
+            const uint32_t i = sidx[p];
+            labels[i] = f;
+            if (f == 1)
+                gidx[gpos + __popcll(mg & lt)] = i;
+            else if (f == 2)
+            {
+                const uint32_t d = opos + __popcll(mo & lt);
+                oidx[d] = i;
+                OX[d] = XS[p];
+                OY[d] = YS[p];
+                OZ[d] = ZS[p];
+            }
+        }
+        gpos += __popcll(mg);
+        opos += __popcll(mo);
+    }
+    if (s == 0 && b == 0)
+    {
+        // the N mod P highest-x points belong to no segment (Q2); written UNKNOWN (Q3)
+        for (uint32_t p = prm.P * prm.n_per + tid; p < prm.n; p += SEG_THREADS)
+            labels[sidx[p]] = LPX_LABEL_UNKNOWN;
+        if (tid == 0)
+        {
+            const uint32_t total = blk_offs[2 * nb];
+            frame->n_ground = total_g;
+            frame->n_obstacle = total - total_g;
+        }
+        if (planes)
+            for (uint32_t i = tid; i < prm.P * 4; i += SEG_THREADS)
+                planes[i] = st[i / 4].plane[i % 4];
+    }
+}
+
+__global__ void dbg_all_seed_kernel(SegState *st, long long *acc, uint32_t *ticket)
+{
+    if (threadIdx.x < LPX_ACC_WORDS)
+        acc[threadIdx.x] = 0;
+    if (threadIdx.x == 0)
+    {
+        ticket[0] = 0;
+        SegState o;
+        o.lo_excl = -INFINITY;
+        o.hi_incl = INFINITY;
+        o.has_seeds = 1;
+        o.failed = 0;
+        o.plane[0] = o.plane[1] = o.plane[2] = o.plane[3] = 0.0f;
+        o.fitted = 0;
+        o.thr = 0.0f;
+        o.pad[0] = o.pad[1] = 0;
+        st[0] = o;
+    }
+}
+
+__global__ void dbg_plane_out_kernel(const SegState *st, float *out)
+{
+    if (threadIdx.x < 4)
+        out[threadIdx.x] = st[0].plane[threadIdx.x];
+    if (threadIdx.x == 4)
+        out[4] = st[0].failed ? 1.0f : 0.0f;
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = v;
+}
+}  // namespace
+
+static uint32_t bits_for(uint32_t v)  // number of bits needed to represent values 0..v
+{
+    uint32_t b = 0;
+    while (v)
+    {
+        ++b;
+        v >>= 1;
+    }
+    return b ? b : 1;
+}
+
+// plane of ALL n points (stride-12 device input) through the moment + Jacobi path; out[0..3] plane, out[4] failed
+int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
+{
+    FrameState *frame = (FrameState *)ctx->frame.p;
+    SegParams prm;
+    prm.n = n;
+    prm.n_per = n;
+    prm.P = 1;
+    prm.I = 1;
+    prm.chunk = SEG_CHUNK;
+    prm.bps = n ? (n + SEG_CHUNK - 1) / SEG_CHUNK : 1;
+    prm.z_floor = 0.0f;
+    prm.seed_thr = 0.0f;
+    prm.odt = 0.0f;
+    prm.n_lpr = 0;
+    float *XS = (float *)ctx->XS.p, *YS = (float *)ctx->YS.p, *ZS = (float *)ctx->ZS.p;
+    SegState *sst = (SegState *)ctx->seg_state.p;
+    long long *acc = (long long *)ctx->seg_acc.p;
+    uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
+    LPX_HIP(ctx, hipMemsetAsync(frame, 0, sizeof(FrameState), ctx->stream));
+    if (n)
+        hipLaunchKernelGGL(ingest_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const char *)d_pts,
+                           (size_t)12, n, XS, YS, ZS, (uint32_t *)nullptr, (uint32_t *)nullptr, frame);
+    hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, acc, ticket);
+    hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
+                       0u, sst, acc, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(dbg_plane_out_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, d_out);
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m)
+{
+    FrameState *frame = (FrameState *)ctx->frame.p;
+    if (m)
+    {
+        hipLaunchKernelGGL(ingest_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (const char *)d_pts,
+                           stride, m, (float *)ctx->OX.p, (float *)ctx->OY.p, (float *)ctx->OZ.p,
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, frame);
+    }
+    LPX_HIP(ctx, hipMemcpyAsync(&frame->n_obstacle, &m, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
+                    uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes)
+{
+    FrameState *frame = (FrameState *)ctx->frame.p;
+    const uint32_t P = cfg->number_of_planar_partitions;
+    const uint32_t I = cfg->number_of_iterations;
+    if (P == 0 || P > LPX_MAX_PARTITIONS || I > LPX_MAX_ITERATIONS)
+        return lpx_fail(ctx, LPX_ERR_ARG, "partitions must be 1..%u and iterations 0..%u", LPX_MAX_PARTITIONS,
+                        LPX_MAX_ITERATIONS);
+    hipStream_t st = ctx->stream;
+    LPX_HIP(ctx, hipMemsetAsync(frame, 0, sizeof(FrameState), st));
+    if (d_planes)
+        LPX_HIP(ctx, hipMemsetAsync(d_planes, 0, sizeof(float) * 4 * P, st));
+    if (n == 0)
+        return LPX_OK;
+
+    SegParams prm;
+    prm.n = n;
+    prm.n_per = n / P;
+    prm.P = P;
+    prm.I = I;
+    prm.chunk = SEG_CHUNK;
+    prm.bps = prm.n_per ? (prm.n_per + SEG_CHUNK - 1) / SEG_CHUNK : 1;
+    prm.z_floor = -1.5f * cfg->sensor_height_m;
+    prm.seed_thr = cfg->initial_seed_threshold;
+    prm.odt = cfg->orthogonal_distance_threshold;
+    prm.n_lpr = cfg->number_of_lower_point_representatives;
+
+    float *X = (float *)ctx->X.p, *Y = (float *)ctx->Y.p, *Z = (float *)ctx->Z.p;
+    float *XS = (float *)ctx->XS.p, *YS = (float *)ctx->YS.p, *ZS = (float *)ctx->ZS.p;
+    const dim3 blk(256), grd((n + 255) / 256);
+
+    {
+        StageTimer tm(ctx, ST_INGEST);
+        hipLaunchKernelGGL(ingest_kernel, grd, blk, 0, st, (const char *)d_pts, stride, n, X, Y, Z,
+                           (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->val_a.p, frame);
+    }
+    uint32_t *skeys = nullptr, *sidx = nullptr;
+    {
+        StageTimer tm(ctx, ST_XSORT);
+        int rc = lpx_sort_pairs(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_b.p, (uint32_t *)ctx->val_a.p,
+                                (uint32_t *)ctx->val_b.p, n, nullptr, 32, &skeys, &sidx);
+        if (rc)
+            return rc;
+    }
+    if (prm.n_per == 0)
+    {
+        // fewer points than partitions: no segment holds a point, every label is UNKNOWN
+        hipLaunchKernelGGL(fill_u32_kernel, grd, blk, 0, st, d_labels, LPX_LABEL_UNKNOWN, n);
+        LPX_HIP(ctx, hipGetLastError());
+        return LPX_OK;
+    }
+    {
+        StageTimer tm(ctx, ST_GATHER);
+        hipLaunchKernelGGL(gather_kernel, grd, blk, 0, st, sidx, X, Y, Z, XS, YS, ZS, (uint64_t *)ctx->key64_a.p, prm);
+    }
+    uint64_t *zsorted = nullptr;
+    {
+        StageTimer tm(ctx, ST_ZSORT);
+        int rc = lpx_sort_keys64(ctx, (uint64_t *)ctx->key64_a.p, (uint64_t *)ctx->key64_b.p, n, 32 + bits_for(P),
+                                 &zsorted);
+        if (rc)
+            return rc;
+    }
+    SegState *sst = (SegState *)ctx->seg_state.p;
+    long long *acc = (long long *)ctx->seg_acc.p;
+    uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
+    {
+        StageTimer tm(ctx, ST_SEEDS);
+        hipLaunchKernelGGL(seed_kernel, dim3(P), dim3(SEG_THREADS), 0, st, zsorted, prm, sst, acc, ticket);
+    }
+    const uint32_t nb = P * prm.bps;
+    int rc = lpx_ensure(ctx, ctx->blk_counts, sizeof(uint32_t) * (2 * (size_t)nb + 2));
+    if (rc)
+        return rc;
+    uint32_t *blk_counts = (uint32_t *)ctx->blk_counts.p;
+    {
+        StageTimer tm(ctx, ST_PLANE);
+        const dim3 g2(prm.bps, P);
+        for (uint32_t t = 0; t < I; ++t)
+            hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, t, sst, acc,
+                               ticket, (uint8_t *)ctx->flags.p, blk_counts);
+        hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, I, sst, acc,
+                           ticket, (uint8_t *)ctx->flags.p, blk_counts);
+    }
+    {
+        StageTimer tm(ctx, ST_COMPACT);
+        // one exclusive scan over [ground counts | obstacle counts | sentinel]
+        hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, blk_counts + 2 * nb, 0u, 1u);
+        rc = lpx_exclusive_scan(ctx, blk_counts, blk_counts, 2 * nb + 1, nullptr, nullptr);
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL(compact_kernel, dim3(prm.bps, P), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p,
+                           sidx, XS, YS, ZS, prm, blk_counts, d_labels, d_gidx, d_oidx, (float *)ctx->OX.p,
+                           (float *)ctx->OY.p, (float *)ctx->OZ.p, sst, d_planes, frame);
+    }
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}

@@ -222,12 +222,12 @@ void orc_jacobi_svd3(const float *a, float *v, float *sigma)
 
 /* ------------------------------------------------------------------------------------------ */
 /* plane estimate: src/segmentation.cpp:62-102, canonical arithmetic                          */
-/*   centroid / covariance from EXACT integer moments of coordinates rounded to 2^-20 m        */
+/*   centroid / covariance from EXACT integer moments of coordinates rounded to 2^-16 m        */
 /*   (order independent, so a parallel accumulation reproduces it bit for bit), then the       */
 /*   float 3x3 Jacobi SVD above; normal = V.col(2), d = normal . centroid.                     */
 /* ------------------------------------------------------------------------------------------ */
 
-#define FIX_SCALE 1048576.0f /* 2^20 */
+#define FIX_SCALE 65536.0f /* 2^16: |q| < 2^27, products < 2^54 (fits the GPU's int64 lanes) */
 #define FIX_LIMIT 2048.0f
 
 typedef __int128 i128;
@@ -280,7 +280,7 @@ static int plane_from_moments(const moments *m, float *plane)
         return 1;
     const double n = (double)m->n;
     const double den = n * (double)(m->n - 1);
-    const double inv20 = 1.0 / 1048576.0, inv40 = inv20 * inv20;
+    const double inv20 = 1.0 / 65536.0, inv40 = inv20 * inv20; /* 2^-16, 2^-32 */
     const float cx = (float)((i128_to_double(m->sx) / n) * inv20);
     const float cy = (float)((i128_to_double(m->sy) / n) * inv20);
     const float cz = (float)((i128_to_double(m->sz) / n) * inv20);
@@ -335,6 +335,13 @@ int orc_segment(const void *pts, size_t stride, uint32_t n, const orc_seg_cfg *c
             seg_status[s] = ORC_SEG_TOO_FEW_POINTS;
     if (n == 0 || P == 0)
         return ORC_OK;
+    /* canonical arithmetic needs every coordinate finite and |v| < 2048 m */
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const float *p = pt_at(pts, stride, i);
+        if (!(fabsf(p[0]) < FIX_LIMIT) || !(fabsf(p[1]) < FIX_LIMIT) || !(fabsf(p[2]) < FIX_LIMIT))
+            return ORC_ERR_RANGE;
+    }
 
     /* form_planar_partitions, :104-149: argsort by x (canonical ties: by index), P equal slabs */
     key_idx *sx = (key_idx *)malloc(sizeof(key_idx) * n);

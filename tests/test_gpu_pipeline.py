@@ -1,0 +1,270 @@
+"""GPU parity tests of the two drop-in calls, through the C-ABI host entry points
+(lpx_segment, lpx_cluster, lpx_segment_cluster) and the Python mirror of Segmenter / Clusterer.
+
+Bar: ground/obstacle masks and index lists bit-exact, planes bit-exact against the oracle (and so
+within the 1e-4 normal tolerance of BASELINE.json), cluster labels identical (not only up to a
+permutation: the dense seed-order numbering of src/clustering.cpp:120-123 is reproduced)."""
+import numpy as np
+import pytest
+
+import oracle
+from lidar_processing_amd import (ClusteringConfiguration, Clusterer, LpxError, SegmentationConfiguration, Segmenter,
+                                  INVALID, UNDEFINED)
+from util import FRAMES, gold, load_frame, partition_signature, synthetic_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def seg_cfgs(**kw):
+    return SegmentationConfiguration(**kw), oracle.SegCfg(**kw)
+
+
+def check_segment(ctx, pts, **kw):
+    cfg, ocfg = seg_cfgs(**kw)
+    labels, gi, oi, planes = ctx.segment(pts, cfg)
+    r = oracle.segment(pts, ocfg)
+    assert r["rc"] == 0
+    assert np.array_equal(labels, r["labels"]), f"{(labels != r['labels']).sum()} labels differ"
+    assert np.array_equal(gi, r["ground_idx"])
+    assert np.array_equal(oi, r["obstacle_idx"])
+    assert np.array_equal(planes.view(np.uint32), r["planes"].view(np.uint32)), (planes, r["planes"])
+    return labels, gi, oi, planes
+
+
+@pytest.mark.parametrize("frame", FRAMES)
+@pytest.mark.parametrize("P,I", [(2, 3), (3, 3), (6, 5)])
+def test_segment_real_frames(ctx, frame, P, I):
+    pts = load_frame(frame)
+    labels, gi, oi, planes = check_segment(ctx, pts, number_of_planar_partitions=P, number_of_iterations=I)
+    g = gold()
+    name = {(2, 3): "p2i3", (3, 3): "p3i3", (6, 5): "p6i5"}[(P, I)]
+    assert np.array_equal(labels.astype(np.uint8), g[f"seg_{frame}_{name}_labels"])
+    assert np.array_equal(planes, g[f"seg_{frame}_{name}_planes"])
+    assert planes[:, 2].min() > 0.99  # normals point up (sign convention of the Jacobi SVD)
+
+
+def test_segment_pointxyz_stride16(ctx):
+    pts = load_frame("0000000000")[:, :4].copy()  # 16-byte records like pcl::PointXYZ
+    check_segment(ctx, pts)
+    wide = np.zeros((pts.shape[0], 8), np.float32)  # 32-byte records like pcl::PointXYZI
+    wide[:, :4] = pts
+    check_segment(ctx, wide)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 6, 7, 100, 1001])
+@pytest.mark.parametrize("P", [1, 2, 3, 7])
+def test_segment_small_and_ragged(ctx, n, P):
+    """empty input, fewer points than partitions, N mod P != 0 (Q2), <3 points per segment (Q5)"""
+    rng = np.random.default_rng(100 * n + P)
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = np.round(rng.random(n) * 40 - 20, 2)
+    pts[:, 1] = np.round(rng.random(n) * 40 - 20, 2)
+    pts[:, 2] = np.round(-1.7 + rng.normal(0, 0.05, n), 3)
+    pts[: n // 3, 2] += 1.5
+    check_segment(ctx, pts, number_of_planar_partitions=P)
+
+
+def test_segment_no_seed_quirk(ctx):
+    """every z within initial_seed_threshold of the mean: the cut-off index stays 0 -> no seeds ->
+    the whole segment is obstacle (src/segmentation.cpp:202-216, :251-259)"""
+    rng = np.random.default_rng(3)
+    n = 4000
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = rng.random(n) * 50
+    pts[:, 1] = rng.random(n) * 50
+    pts[:, 2] = -1.7 + rng.random(n) * 0.2
+    labels, gi, oi, _ = check_segment(ctx, pts, number_of_planar_partitions=2)
+    assert len(gi) == 0 and len(oi) == n and (labels == 2).all()
+
+
+def test_segment_below_floor_and_zero_iterations(ctx):
+    rng = np.random.default_rng(4)
+    n = 5000
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = rng.random(n) * 50
+    pts[:, 1] = rng.random(n) * 50
+    pts[:, 2] = -1.7 + rng.normal(0, 0.05, n)
+    pts[:500, 2] = -5.0  # below -1.5 * sensor_height: dropped from the seed candidates
+    pts[500:900, 2] += 2.0
+    check_segment(ctx, pts)
+    check_segment(ctx, pts, number_of_lower_point_representatives=10)
+    check_segment(ctx, pts, sensor_height_m=0.5)
+    # all points below the floor: nothing is dropped (:171-182)
+    check_segment(ctx, pts, sensor_height_m=-10.0)
+    cfg, ocfg = seg_cfgs(number_of_iterations=0)
+    labels, gi, oi, _ = ctx.segment(pts, cfg)
+    r = oracle.segment(pts, ocfg)
+    assert np.array_equal(labels, r["labels"])
+    assert len(oi) == 0 and set(gi.tolist()) == set(r["ground_idx"].tolist())  # z-order ties unspecified
+
+
+def test_segment_coplanar_duplicates(ctx):
+    n = 3000
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = np.arange(n) % 50
+    pts[:, 1] = np.arange(n) // 50
+    pts[:, 2] = -1.7
+    pts[-300:, 2] = 0.0
+    check_segment(ctx, pts)
+    pts[:] = pts[0]  # all identical points
+    pts[-5:, 2] = 1.0
+    check_segment(ctx, pts, number_of_planar_partitions=1)
+
+
+def test_segment_range_error(ctx):
+    pts = load_frame("0000000000")[:1000].copy()
+    pts[10, 1] = 5000.0
+    with pytest.raises(LpxError) as e:
+        ctx.segment(pts, SegmentationConfiguration())
+    assert e.value.code == -2
+    pts[10, 1] = np.nan
+    with pytest.raises(LpxError):
+        ctx.segment(pts, SegmentationConfiguration())
+    assert oracle.segment(pts)["rc"] == oracle.ERR_RANGE
+
+
+def test_segment_synthetic_1m(ctx):
+    """BASELINE config 3: 1M-point plane + boxes, 12 segments"""
+    pts = synthetic_scene(600_000, 2000, 200, 20240601)
+    check_segment(ctx, pts, number_of_planar_partitions=12, number_of_iterations=3)
+
+
+def check_cluster(ctx, obs, d2, q, mn=4, mx=2 ** 32 - 1):
+    lab, nc = ctx.cluster(obs, ClusteringConfiguration(d2, q, mn, mx))
+    want, wn = oracle.cluster(obs, oracle.CluCfg(d2, q, mn, mx))
+    assert nc == wn
+    assert np.array_equal(lab, want), f"{(lab != want).sum()} labels differ"
+    assert (lab != UNDEFINED).all()
+    return lab
+
+
+@pytest.mark.parametrize("frame", FRAMES)
+@pytest.mark.parametrize("sname,skw", [("p2i3", dict(number_of_planar_partitions=2, number_of_iterations=3)),
+                                       ("p6i5", dict(number_of_planar_partitions=6, number_of_iterations=5))])
+@pytest.mark.parametrize("cname,d2,q", [("d018q05", 0.18, 0.5), ("d025q05", 0.25, 0.5)])
+def test_cluster_real_frames_vs_reference_golden(ctx, frame, sname, skw, cname, d2, q):
+    """labels equal the goldens produced by the REFERENCE's own kdtree.hpp/queue.hpp build"""
+    pts = load_frame(frame)
+    obs = pts[oracle.segment(pts, oracle.SegCfg(**skw))["obstacle_idx"]]
+    lab, nc = ctx.cluster(obs, ClusteringConfiguration(d2, q))
+    g = gold()
+    assert nc == int(g[f"clu_{frame}_{sname}_{cname}_n"][0])
+    want = g[f"clu_{frame}_{sname}_{cname}_labels"]
+    assert np.array_equal(partition_signature(lab), partition_signature(want))
+    assert np.array_equal(lab, want)
+
+
+def test_cluster_exact_ec_quality_one(ctx):
+    pts = load_frame("0000000000")
+    obs = pts[oracle.segment(pts)["obstacle_idx"]]
+    lab, nc = ctx.cluster(obs, ClusteringConfiguration(0.18, 1.0))
+    g = gold()
+    assert nc == int(g["clu_0000000000_p2i3_d018q10_n"][0])
+    assert np.array_equal(lab, g["clu_0000000000_p2i3_d018q10_labels"])
+
+
+@pytest.mark.parametrize("q", [0.0, 0.3, 0.5, 0.9, 1.0])
+@pytest.mark.parametrize("mn,mx", [(1, 2 ** 32 - 1), (4, 2 ** 32 - 1), (4, 60)])
+def test_cluster_quality_and_size_limits(ctx, q, mn, mx):
+    rng = np.random.default_rng(int(q * 10) + mn)
+    m = 6000
+    obs = np.zeros((m, 4), np.float32)
+    centres = rng.random((150, 3)) * [60, 60, 2]
+    obs[:, :3] = np.round(centres[rng.integers(0, 150, m)] + rng.normal(0, 0.25, (m, 3)), 3)
+    check_cluster(ctx, obs, 0.18, q, mn, mx)
+
+
+def test_cluster_edge_cases(ctx):
+    assert ctx.cluster(np.zeros((0, 4), np.float32), ClusteringConfiguration())[0].shape == (0,)
+    one = np.zeros((1, 4), np.float32)
+    assert ctx.cluster(one, ClusteringConfiguration())[0][0] == INVALID
+    assert ctx.cluster(one, ClusteringConfiguration(min_cluster_size=1))[0][0] == 0
+    # duplicates (dist 0), two points exactly at distance d (inclusive <=, src/kdtree.hpp:315)
+    obs = np.zeros((8, 4), np.float32)
+    obs[1, 0] = 0.5
+    obs[2] = obs[1]
+    obs[3, 0] = 1.0
+    obs[4, 0] = 10.0
+    obs[5, 0] = 10.25
+    obs[6, 0] = 20.0
+    obs[7, 0] = 20.0 + 0.5 + 1e-4
+    for q in (0.0, 0.5, 1.0):
+        for mn in (1, 2, 3, 4):
+            check_cluster(ctx, obs, 0.25, q, mn)
+    # 2- and 3-point components: touch counts 3 and >= 5 (Q8)
+    obs2 = np.zeros((5, 4), np.float32)
+    obs2[:, 0] = [0, 0.3, 5, 5.3, 5.6]
+    lab = check_cluster(ctx, obs2, 0.18, 1.0, 4)
+    assert (lab[:2] == INVALID).all() and (lab[2:] == 0).all()
+
+
+def test_cluster_all_point_types_strides(ctx):
+    pts = load_frame("0000000077")
+    obs = pts[oracle.segment(pts)["obstacle_idx"]][:20000]
+    a = check_cluster(ctx, obs[:, :4].copy(), 0.18, 0.5)       # 16-byte records (PointXYZ)
+    wide = np.zeros((obs.shape[0], 8), np.float32)              # 32-byte records (XYZI/XYZL/XYZRGB/XYZRGBL)
+    wide[:, :3] = obs[:, :3]
+    b = check_cluster(ctx, wide, 0.18, 0.5)
+    assert np.array_equal(a, b)
+
+
+def test_cluster_dense_neighbour_workspace_grows(ctx):
+    """more neighbours than the reserved workspace: the host entry point grows it and retries"""
+    rng = np.random.default_rng(9)
+    obs = np.zeros((3000, 4), np.float32)
+    obs[:, :3] = rng.random((3000, 3)) * 0.3
+    from lidar_processing_amd import Context
+    c = Context(0)
+    c.reserve(3000, 8)
+    lab, nc = c.cluster(obs, ClusteringConfiguration(0.18, 0.5))
+    want, wn = oracle.cluster(obs, oracle.CluCfg(0.18, 0.5))
+    assert nc == wn and np.array_equal(lab, want)
+    c.close()
+
+
+@pytest.mark.parametrize("frame", FRAMES)
+def test_fused_segment_cluster(ctx, frame):
+    """lpx_segment_cluster == the two reference calls back to back (src/processor.cpp:150-178)"""
+    pts = load_frame(frame)
+    scfg, oscfg = seg_cfgs(number_of_planar_partitions=6, number_of_iterations=5)
+    out = ctx.segment_cluster(pts, scfg, ClusteringConfiguration(0.25, 0.5))
+    r = oracle.segment(pts, oscfg)
+    assert np.array_equal(out["labels"], r["labels"])
+    assert np.array_equal(out["obstacle_idx"], r["obstacle_idx"])
+    want, wn = oracle.cluster(pts[r["obstacle_idx"]], oracle.CluCfg(0.25, 0.5))
+    assert out["n_clusters"] == wn
+    assert np.array_equal(out["cluster_labels"], want)
+
+
+def test_python_mirror_classes(ctx):
+    pts = load_frame("0000000000")
+    seg = Segmenter(context=ctx)
+    seg.update_configuration(SegmentationConfiguration(number_of_planar_partitions=3))
+    labels, ground, obstacle = seg.segment(pts)
+    r = oracle.segment(pts, oracle.SegCfg(number_of_planar_partitions=3))
+    assert np.array_equal(labels, r["labels"])
+    assert np.array_equal(ground, pts[r["ground_idx"]]) and np.array_equal(obstacle, pts[r["obstacle_idx"]])
+    clu = Clusterer(context=ctx)
+    lab = clu.cluster(obstacle)
+    assert np.array_equal(lab, oracle.cluster(obstacle)[0])
+    assert clu.cluster(np.zeros((0, 4), np.float32)).shape == (0,)
+
+
+def test_full_size_properties_1m(ctx):
+    """BASELINE config 3 at full size: properties that do not need the (slow) CPU replay --
+    every point labelled, labels dense, clusters are unions of whole... subsets of d-components,
+    idempotent, and the q=1 partition equals the connected components with >= min touches."""
+    pts = synthetic_scene(600_000, 2000, 200, 20240601)
+    scfg = SegmentationConfiguration(number_of_planar_partitions=12, number_of_iterations=3)
+    out = ctx.segment_cluster(pts, scfg, ClusteringConfiguration(0.09, 0.5))
+    out2 = ctx.segment_cluster(pts, scfg, ClusteringConfiguration(0.09, 0.5))
+    for k in ("labels", "obstacle_idx", "cluster_labels"):
+        assert np.array_equal(out[k], out2[k])  # deterministic / idempotent
+    cl = out["cluster_labels"]
+    assert (cl >= -1).all()
+    valid = cl[cl >= 0]
+    assert valid.size and np.array_equal(np.unique(valid), np.arange(out["n_clusters"]))
+    # labels are numbered in seed order: first occurrence of label k comes before that of k+1
+    first = np.full(out["n_clusters"], cl.size, np.int64)
+    np.minimum.at(first, valid, np.nonzero(cl >= 0)[0])
+    assert (np.diff(first) > 0).all()

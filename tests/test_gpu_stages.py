@@ -1,0 +1,133 @@
+"""GPU parity tests, stage by stage, through the C-ABI (lpx_dbg_* entry points of include/lpx.h).
+Each stage is compared with the oracle (oracle/) on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import oracle
+from util import brute_components, gold, load_frame, synthetic_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_extension_loaded(ctx):
+    from lidar_processing_amd import _lib
+    assert _lib.lib() is not None
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 5000, 123_398, 1_000_003])
+def test_scan(ctx, n):
+    rng = np.random.default_rng(n)
+    d = rng.integers(0, 1000, n, dtype=np.uint32)
+    out, tot = ctx.dbg_scan(d)
+    ref = np.concatenate([[0], np.cumsum(d, dtype=np.uint64)[:-1]]).astype(np.uint32) if n else d
+    assert tot == int(d.sum(dtype=np.uint64))
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 32), (64, 32), (300, 8), (2048, 32), (2049, 32), (123_398, 32), (600_000, 20)])
+def test_sort_pairs_stable(ctx, n, bits):
+    rng = np.random.default_rng(n + bits)
+    hi = (1 << bits) - 1
+    keys = rng.integers(0, min(hi, 5000) + 1, n, dtype=np.uint32)  # many ties
+    if n > 10:
+        keys[: n // 2] = rng.integers(0, hi + 1, n // 2, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    k, v = ctx.dbg_sort_pairs(keys, vals, bits)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k, keys[order])
+    assert np.array_equal(v, vals[order])
+
+
+@pytest.mark.parametrize("n", [1, 777, 4096, 123_398])
+def test_sort_keys64(ctx, n):
+    rng = np.random.default_rng(n)
+    keys = (rng.integers(0, 7, n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 2 ** 32, n, dtype=np.uint64)
+    k = ctx.dbg_sort_keys64(keys, 35)
+    assert np.array_equal(k, np.sort(keys))
+
+
+def _cloud(kind, m, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return (rng.random((m, 3)) * 40 - 20).astype(np.float32)
+    if kind == "ties":  # 5 cm grid: every coordinate heavily tied, exercises nth_element tie placement
+        return (rng.integers(-40, 40, (m, 3)) * 0.05).astype(np.float32)
+    if kind == "dups":
+        base = (rng.random((max(m // 4, 1), 3)) * 10).astype(np.float32)
+        return base[rng.integers(0, base.shape[0], m)]
+    if kind == "sorted":
+        return np.sort((rng.random((m, 3)) * 30).astype(np.float32), axis=0)
+    if kind == "const":
+        return np.full((m, 3), 1.5, np.float32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "ties", "dups", "sorted", "const"])
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 16, 17, 33, 64, 100, 511, 512, 513, 1025, 4095, 4097, 10_000, 50_021])
+def test_kd_layout_matches_reference_order(ctx, kind, m):
+    """KDTree::rebuild (src/kdtree.hpp:174-225): identical node array, hence identical pre-order"""
+    xyz = _cloud(kind, m, 7 * m + len(kind))
+    got = ctx.dbg_kd_layout(xyz)
+    want = oracle.kd_layout(xyz)
+    assert np.array_equal(got, want), f"first mismatch at {np.argmax(got != want)}"
+
+
+def test_kd_layout_real_frame(ctx):
+    pts = load_frame("0000000000")
+    r = oracle.segment(pts)
+    obs = pts[r["obstacle_idx"]]
+    got = ctx.dbg_kd_layout(obs)
+    assert np.array_equal(got, oracle.kd_layout(obs))
+
+
+@pytest.mark.parametrize("kind,m,r2", [("uniform", 3000, 4.0), ("ties", 3000, 0.04), ("dups", 2000, 0.5),
+                                       ("const", 300, 0.1), ("uniform", 1, 1.0), ("uniform", 2, 1e9)])
+def test_neighbour_lists_match_radius_search(ctx, kind, m, r2):
+    """every list equals KDTree::radius_search (src/kdtree.hpp:292-341): same members, same order, same dist"""
+    xyz = _cloud(kind, m, m + 11)
+    off, idx, dist = ctx.dbg_neighbours(xyz, r2)
+    assert off[0] == 0 and off[-1] == len(idx)
+    rng = np.random.default_rng(1)
+    for j in (range(m) if m <= 300 else rng.integers(0, m, 200)):
+        wi, wd = oracle.radius_search(xyz, xyz[j], r2)
+        gi, gd = idx[off[j]:off[j + 1]], dist[off[j]:off[j + 1]]
+        assert np.array_equal(gi, wi), f"query {j}"
+        assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32)), f"query {j} distances"
+    # brute force, mirrors test/test_kdtree.cpp:97-187 (float32, inclusive <=)
+    j = 0
+    d = xyz - xyz[j]
+    bd = d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + (d[:, 2] * d[:, 2] + np.float32(0)))
+    assert set(idx[off[j]:off[j + 1]].tolist()) == set(np.nonzero(bd <= np.float32(r2))[0].tolist())
+
+
+def test_neighbour_lists_real_frame(ctx):
+    pts = load_frame("0000000000")
+    obs = pts[oracle.segment(pts)["obstacle_idx"]]
+    off, idx, dist = ctx.dbg_neighbours(obs, 0.18)
+    rng = np.random.default_rng(5)
+    for j in rng.integers(0, obs.shape[0], 300):
+        wi, wd = oracle.radius_search(obs, obs[j], 0.18)
+        assert np.array_equal(idx[off[j]:off[j + 1]], wi)
+        assert np.array_equal(dist[off[j]:off[j + 1]].view(np.uint32), wd.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind,m,r2", [("uniform", 5000, 1.0), ("ties", 5000, 0.0026), ("dups", 3000, 0.05)])
+def test_components(ctx, kind, m, r2):
+    xyz = _cloud(kind, m, m + 3)
+    root = ctx.dbg_components(xyz, r2)
+    assert np.array_equal(root, brute_components(xyz, r2))
+
+
+@pytest.mark.parametrize("n", [3, 10, 1000, 50_000])
+def test_plane_bit_exact(ctx, n):
+    """moments (int64 lanes, atomics) + Jacobi on the device == oracle, bit for bit"""
+    rng = np.random.default_rng(n)
+    xyz = np.zeros((n, 3), np.float32)
+    xyz[:, 0] = rng.random(n) * 80 - 40
+    xyz[:, 1] = rng.random(n) * 80 - 40
+    xyz[:, 2] = -1.7 + 0.02 * xyz[:, 0] - 0.01 * xyz[:, 1] + rng.normal(0, 0.03, n)
+    got, rc = ctx.dbg_plane(xyz)
+    want, rc2 = oracle.plane_from_points(xyz)
+    assert rc == rc2 == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (got, want)
+    assert got[2] > 0.99
