@@ -163,6 +163,15 @@ class Context:
         return dict(labels=labels, ground_idx=gi[:ng.value].copy(), obstacle_idx=oi[:no.value].copy(),
                     planes=planes[:P], cluster_labels=cl[:no.value].copy(), n_clusters=nc.value)
 
+    # ---- device-resident entry point (asynchronous on the context stream) ----
+    def segment_cluster_device(self, d_pts, stride_bytes, n, seg_cfg, clu_cfg, d_labels, d_ground_idx, d_obstacle_idx,
+                               d_planes, d_cluster_labels, d_counts):
+        """lpx_segment_cluster_device: every d_* is a raw device pointer (int); nothing synchronises."""
+        sc, cc = seg_cfg._c(), clu_cfg._c()
+        self.check(self._L.lpx_segment_cluster_device(self._h, d_pts, stride_bytes, n, C.byref(sc), C.byref(cc),
+                                                      d_labels, d_ground_idx, d_obstacle_idx, d_planes,
+                                                      d_cluster_labels, d_counts))
+
     # ---- stage-level entry points (parity tests) ----
     def dbg_sort_pairs(self, keys, values, bits=32):
         k = np.array(keys, dtype=np.uint32)
