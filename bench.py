@@ -47,9 +47,9 @@ def algorithmic_bytes(stage, N, M, E, I, P):
         "plane_passes": N * 12 * (I + 1) + N,        # I+1 streams of the SoA + flag write
         "compact": N * (1 + 4 + 4 + 4) + M * 12,     # flag, index, label, list, obstacle SoA
         "kd_build": M * 16 * 2 * 17,                 # ~log2(M) levels, each reads + writes the node array
-        "nb_count": M * (12 + 16 + 4),
-        "nb_scan": M * 8,
-        "nb_fill": M * (12 + 16 + 4) + E * 8 + M * 8,  # queries, nodes, offsets, (index, distance) lists, parents
+        "kd_preorder": M * 32,                       # node array read + pre-order copy write
+        "cc_hook": E * 4 + M * (8 + 8),              # list indices read, offsets/lengths, parents
+        "neighbours": M * 16 + E * 8 + M * 8,        # nodes read once, (index, distance) lists written, off/len
         "components": M * (4 + 4 + 4 + 1 + 4 + 8) + 3 * M * 24,
         "replay": E * 8 + M * (1 + 4 + 4 + 4),
         "labels": M * (4 + 4 + 4 + 4),

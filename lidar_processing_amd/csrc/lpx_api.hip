@@ -61,7 +61,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             if ((rc = lpx_ensure(ctx, *b, n4)))
                 return rc;
         if ((rc = lpx_ensure(ctx, ctx->key64_a, 2 * n4)) || (rc = lpx_ensure(ctx, ctx->key64_b, 2 * n4)) ||
-            (rc = lpx_ensure(ctx, ctx->nodes, 4 * n4)) || (rc = lpx_ensure(ctx, ctx->flags, (size_t)n + 64)) ||
+            (rc = lpx_ensure(ctx, ctx->nodes, 4 * n4)) || (rc = lpx_ensure(ctx, ctx->nodes_pre, 4 * n4)) || (rc = lpx_ensure(ctx, ctx->flags, (size_t)n + 64)) ||
             (rc = lpx_ensure(ctx, ctx->state, (size_t)n + 64)))
             return rc;
         ctx->cap_n = n;
@@ -88,7 +88,7 @@ static int ensure_for(lpx_ctx *ctx, uint32_t n)
 // profiling
 // ------------------------------------------------------------------------------------------------
 static const char *k_stage_names[ST_COUNT] = {"ingest",   "xsort",   "gather",  "zsort", "seeds",  "plane_passes", "compact",
-                                              "kd_build", "nb_count", "nb_scan", "nb_fill", "components", "replay", "labels"};
+                                              "kd_build", "kd_preorder", "cc_hook", "neighbours", "components", "replay", "labels"};
 
 StageTimer::StageTimer(lpx_ctx *c, int s) : ctx(c), stage(s)
 {
@@ -233,7 +233,7 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
     Buf *all[] = {&ctx->in_aos, &ctx->X,        &ctx->Y,        &ctx->Z,      &ctx->key_a,   &ctx->key_b,  &ctx->val_a,
                   &ctx->val_b,  &ctx->key64_a,  &ctx->key64_b,  &ctx->XS,     &ctx->YS,      &ctx->ZS,     &ctx->flags,
                   &ctx->hist,   &ctx->seg_state, &ctx->seg_acc, &ctx->blk_counts, &ctx->d_labels, &ctx->d_gidx,
-                  &ctx->d_oidx, &ctx->d_planes, &ctx->d_counts, &ctx->OX,     &ctx->OY,      &ctx->OZ,     &ctx->nodes,
+                  &ctx->d_oidx, &ctx->d_planes, &ctx->d_counts, &ctx->OX,     &ctx->OY,      &ctx->OZ,     &ctx->nodes, &ctx->nodes_pre,
                   &ctx->lpos,   &ctx->rpos,     &ctx->nb_len,   &ctx->nb_off, &ctx->nb_idx,  &ctx->nb_dist, &ctx->parent,
                   &ctx->cc_lo,  &ctx->cc_hi,    &ctx->state,    &ctx->seed_of, &ctx->queue,  &ctx->valid,  &ctx->d_clabels,
                   &ctx->frame};
@@ -464,9 +464,8 @@ static int cluster_resident(lpx_ctx *ctx, uint32_t m, const lpx_clu_cfg *cfg, in
                 want = 0xfffffff0ull;
             if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, want)))
                 return rc;
-            const uint32_t zero = 0;
-            LPX_HIP(ctx, hipMemcpyAsync(&((FrameState *)ctx->frame.p)->status, &zero, 4, hipMemcpyHostToDevice,
-                                        ctx->stream));
+            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->status, 0, 4, ctx->stream));
+            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->nb_total, 0, 8, ctx->stream));
             continue;
         }
         break;
@@ -535,6 +534,31 @@ extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride,
     if (fs.n_obstacle == 0)
         return LPX_OK;
     return cluster_resident(ctx, fs.n_obstacle, clu_cfg, cluster_labels, n_clusters);
+}
+
+// tools only: per-group statistics of the neighbour kernel ({T, intervals, queries, hits, cycles to
+// allocation, cycles total, -, -} per group); pass n_groups = 0 to switch it off again
+extern "C" int lpx_dbg_group_stats(lpx_ctx *ctx, uint32_t n_groups, uint32_t *out)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    static Buf buf;
+    if (out && ctx->dbg_buf)
+    {
+        LPX_HIP(ctx, hipMemcpy(out, ctx->dbg_buf, 32 * (size_t)n_groups, hipMemcpyDeviceToHost));
+        return LPX_OK;
+    }
+    if (n_groups == 0)
+    {
+        ctx->dbg_buf = nullptr;
+        return LPX_OK;
+    }
+    int rc = lpx_ensure(ctx, buf, 32 * (size_t)n_groups);
+    if (rc)
+        return rc;
+    LPX_HIP(ctx, hipMemset(buf.p, 0, 32 * (size_t)n_groups));
+    ctx->dbg_buf = buf.p;
+    return LPX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -637,32 +661,51 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
         {
             if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, fs.nb_total + 1024)))
                 return rc;
-            const uint32_t zero = 0;
-            LPX_HIP(ctx, hipMemcpyAsync(&((FrameState *)ctx->frame.p)->status, &zero, 4, hipMemcpyHostToDevice,
-                                        ctx->stream));
+            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->status, 0, 4, ctx->stream));
+            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->nb_total, 0, 8, ctx->stream));
             continue;
         }
         break;
     }
     if ((rc = status_to_rc(ctx, fs.status)))
         return rc;
-    uint32_t *off32 = (uint32_t *)malloc(4 * ((size_t)m + 1));
+    // device lists are grouped by kd bucket; hand them back as a CSR ordered by point index
+    uint32_t *off32 = (uint32_t *)malloc(4 * (size_t)m), *len32 = (uint32_t *)malloc(4 * (size_t)m);
+    uint32_t *didx = (uint32_t *)malloc(4 * (size_t)fs.nb_total + 4);
+    float *ddist = (float *)malloc(4 * (size_t)fs.nb_total + 4);
     LPX_HIP(ctx, hipMemcpyAsync(off32, ctx->nb_off.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint32_t i = 0; i < m; ++i)
-        offsets[i] = off32[i];
-    offsets[m] = fs.nb_total;
-    free(off32);
-    if (fs.nb_total > capacity)
-        return lpx_fail(ctx, LPX_ERR_CAPACITY, "caller buffers hold %llu entries, %llu needed",
-                        (unsigned long long)capacity, (unsigned long long)fs.nb_total);
+    LPX_HIP(ctx, hipMemcpyAsync(len32, ctx->nb_len.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     if (fs.nb_total)
     {
-        LPX_HIP(ctx, hipMemcpyAsync(idx, ctx->nb_idx.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
-        LPX_HIP(ctx, hipMemcpyAsync(dist, ctx->nb_dist.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
+        LPX_HIP(ctx, hipMemcpyAsync(didx, ctx->nb_idx.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
+        LPX_HIP(ctx, hipMemcpyAsync(ddist, ctx->nb_dist.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
     }
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return LPX_OK;
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < m; ++i)
+    {
+        offsets[i] = run;
+        run += len32[i];
+    }
+    offsets[m] = run;
+    rc = LPX_OK;
+    if (run != fs.nb_total)
+        rc = lpx_fail(ctx, LPX_ERR_INTERNAL, "list lengths sum to %llu, allocated %llu", (unsigned long long)run,
+                      (unsigned long long)fs.nb_total);
+    else if (run > capacity)
+        rc = lpx_fail(ctx, LPX_ERR_CAPACITY, "caller buffers hold %llu entries, %llu needed",
+                      (unsigned long long)capacity, (unsigned long long)run);
+    else
+        for (uint32_t i = 0; i < m; ++i)
+        {
+            memcpy(idx + offsets[i], didx + off32[i], 4 * (size_t)len32[i]);
+            memcpy(dist + offsets[i], ddist + off32[i], 4 * (size_t)len32[i]);
+        }
+    free(off32);
+    free(len32);
+    free(didx);
+    free(ddist);
+    return rc;
 }
 
 __global__ void dbg_roots_kernel(uint32_t *parent, uint32_t m, uint32_t *root)
@@ -694,9 +737,8 @@ extern "C" int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
         {
             if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, fs.nb_total + 1024)))
                 return rc;
-            const uint32_t zero = 0;
-            LPX_HIP(ctx, hipMemcpyAsync(&((FrameState *)ctx->frame.p)->status, &zero, 4, hipMemcpyHostToDevice,
-                                        ctx->stream));
+            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->status, 0, 4, ctx->stream));
+            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->nb_total, 0, 8, ctx->stream));
             continue;
         }
         break;

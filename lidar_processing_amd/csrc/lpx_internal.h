@@ -20,9 +20,9 @@ enum lpx_stage
     ST_PLANE,        // fused inlier test + moment accumulation + 3x3 solve (I launches + seed pass)
     ST_COMPACT,      // final flags -> labels, ground/obstacle lists, obstacle SoA
     ST_KD_BUILD,     // kd-tree layout (libstdc++ introselect order)
-    ST_NB_COUNT,     // radius neighbour count
-    ST_NB_SCAN,      // CSR offsets
-    ST_NB_FILL,      // radius neighbour fill + union-find hooking
+    ST_NB_COUNT,     // pre-order rank layout of the kd nodes
+    ST_NB_SCAN,      // union-find hooking over the neighbour lists
+    ST_NB_FILL,      // radius neighbour lists (count + allocate + fill, one launch)
     ST_CC,           // flatten roots, sort members by (root, index), component ranges
     ST_REPLAY,       // ordered FEC replay, one wavefront per component
     ST_LABELS,       // dense relabel
@@ -88,7 +88,8 @@ struct lpx_ctx
     Buf d_labels, d_gidx, d_oidx, d_planes, d_counts;  // outputs for host API
     // ---- clustering buffers ----
     Buf OX, OY, OZ;            // obstacle SoA (cap_n)
-    Buf nodes;                 // float4 kd nodes
+    Buf nodes;                 // float4 kd nodes, array (in-order) layout
+    Buf nodes_pre;             // the same nodes in pre-order rank layout
     Buf lpos, rpos;            // partition scratch
     Buf nb_len, nb_off;        // u32 len, u32 off (cap_n + 1)
     Buf nb_idx, nb_dist;       // cap_nb
@@ -103,6 +104,8 @@ struct lpx_ctx
     // ---- pinned host staging ----
     void *h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
+
+    void *dbg_buf = nullptr;   // optional per-group statistics of the neighbour kernel (tools only)
 
     // profiling
     bool profiling = false;

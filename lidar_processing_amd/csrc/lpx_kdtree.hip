@@ -585,9 +585,12 @@ __global__ __launch_bounds__(SUB_WAVES *WAVE) void kd_subtree_kernel(Node *nodes
 // ------------------------------------------------------------------------------------------------
 // union-find (roots are the smallest original index of a component = its first FEC seed)
 // ------------------------------------------------------------------------------------------------
+// Cacheable relaxed loads: a stale parent is still an ancestor (parents only ever move towards the
+// root and roots only ever get hooked under smaller roots), and every hook is a CAS that returns the
+// current value, so staleness costs a retry, never a wrong union.  Roots are read back in a later launch.
 __device__ __forceinline__ uint32_t uf_ld(uint32_t *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void uf_st(uint32_t *p, uint32_t v)
 {
@@ -629,98 +632,559 @@ __device__ void uf_unite(uint32_t *parent, uint32_t a, uint32_t b)
 }
 
 // ------------------------------------------------------------------------------------------------
-// radius search of every point, one thread per query (src/kdtree.hpp:292-341): emission order is
-// the tree's pre-order, left before right, pruning on (node[axis]-target[axis])^2 <= r2.
+// pre-order layout.  PR[rank] = node with pre-order rank `rank`; a subtree is a contiguous rank
+// interval [rank(root), rank(root) + size), so "emit in pre-order" becomes "emit in array order".
 // ------------------------------------------------------------------------------------------------
-constexpr int RS_STACK = 48;
-
-template <bool FILL>
-__global__ __launch_bounds__(256) void radius_kernel(const Node *__restrict__ nodes, const float *__restrict__ OX,
-                                                      const float *__restrict__ OY, const float *__restrict__ OZ,
-                                                      const FrameState *__restrict__ frame, float r2,
-                                                      uint32_t *__restrict__ len, const uint32_t *__restrict__ off,
-                                                      uint32_t *__restrict__ nb_idx, float *__restrict__ nb_dist,
-                                                      uint64_t cap, uint32_t *parent, int hook)
+__global__ void kd_preorder_kernel(const Node *__restrict__ nodes, const FrameState *__restrict__ frame,
+                                   Node *__restrict__ PR)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
-    if (i >= M)
+    if (p >= M)
         return;
-    if (FILL && frame->nb_total > cap)
-        return;
-    const float tx = OX[i], ty = OY[i], tz = OZ[i];
-    uint32_t sb[RS_STACK], se[RS_STACK];
-    int sp = 0;
-    sb[0] = 0;
-    se[0] = M;  // axis in bits 30..31
-    sp = 1;
-    uint32_t cnt = 0;
-    const uint32_t base = FILL ? off[i] : 0u;
-    while (sp)
+    uint32_t b = 0, e = M, rank = 0;
+    for (;;)
     {
-        --sp;
-        const uint32_t b = sb[sp];
-        const uint32_t ea = se[sp];
-        const uint32_t e = ea & 0x3fffffffu, axis = ea >> 30;
         const uint32_t mid = b + (e - b) / 2;
-        const Node nd = nodes[mid];
-        const float d0 = tx - nd.x, d1 = ty - nd.y, d2 = tz - nd.z;
-        const float dist = d0 * d0 + (d1 * d1 + (d2 * d2 + 0.0f));  // src/kdtree.hpp:145-157
-        if (dist <= r2)
+        if (p == mid)
+            break;
+        if (p < mid)
         {
-            if (FILL)
-            {
-                const uint32_t k = __float_as_uint(nd.w);
-                nb_idx[base + cnt] = k;
-                nb_dist[base + cnt] = dist;
-                if (hook && k < i)
-                    uf_unite(parent, i, k);
-            }
-            ++cnt;
+            rank += 1;
+            e = mid;
         }
-        const uint32_t next = (axis + 1) % 3;
-        const float delta = (axis == 0 ? nd.x - tx : (axis == 1 ? nd.y - ty : nd.z - tz));
-        const float ads = delta * delta;
-        const bool has_l = mid > b, has_r = mid + 1 < e;
-        if (ads <= r2)
+        else
         {
-            if (has_r)
-            {
-                sb[sp] = mid + 1;
-                se[sp] = e | (next << 30);
-                ++sp;
-            }
-            if (has_l)
-            {
-                sb[sp] = b;
-                se[sp] = mid | (next << 30);
-                ++sp;
-            }
-        }
-        else if (delta > 0.0f)
-        {
-            if (has_l)
-            {
-                sb[sp] = b;
-                se[sp] = mid | (next << 30);
-                ++sp;
-            }
-        }
-        else if (has_r)
-        {
-            sb[sp] = mid + 1;
-            se[sp] = e | (next << 30);
-            ++sp;
+            rank += 1 + (mid - b);
+            b = mid + 1;
         }
     }
-    if (!FILL)
-        len[i] = cnt;
+    PR[rank] = nodes[p];
 }
 
-__global__ void nb_check_kernel(FrameState *frame, uint64_t cap)
+// ------------------------------------------------------------------------------------------------
+// radius-neighbour lists of every point, in the emission order of KDTree::radius_search
+// (src/kdtree.hpp:292-341: pre-order, left before right, inclusive dist <= r2).
+//
+// The reference prunes a child only when no point below it can be in range, so the list of a query
+// is exactly {nodes with dist_sqr <= r2} in pre-order.  One wavefront serves a GROUP of queries:
+// the <= 64 nodes of one bucket subtree (level D, where subtrees hold <= 64 nodes), or one node above
+// that level.  It walks the top D levels once for the group's bounding box (+r), breadth-first but
+// order-preserving (each unexpanded subtree is replaced in place by [node, left?, right?]), which
+// yields the candidate set as a short sequence of rank intervals already in pre-order; candidates are
+// then distance-tested 64 at a time with the reference's float expression, and accepted ones are
+// appended in order -- no sort.  Stopping the expansion early (sequence full) only widens the
+// candidate intervals, it never changes the result.
+// ------------------------------------------------------------------------------------------------
+constexpr int NB_WAVES = 4;
+constexpr int NB_THREADS = NB_WAVES * WAVE;
+constexpr int NB_SEQ = 1024;    // interval items in LDS per block (12 KiB)
+constexpr int NB_NODES = 2048;  // candidate nodes staged in LDS per block (32 KiB)
+constexpr int NB_BUCKET = 64;
+constexpr uint32_t NB_FINAL = 0x80000000u;
+
+struct Item
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && frame->nb_total > cap)
-        frame->status = (uint32_t)(-LPX_ERR_CAPACITY);
+    uint32_t rank, b, e;  // unexpanded subtree: node range [b,e), root at `rank`; final: e == NB_FINAL, b = count
+};
+
+// order-preserving breadth-first walk of the top D levels for the box [blo,bhi] (already widened by
+// the radius); one wavefront.  Leaves the candidate intervals in cur[0..n) and their exclusive size
+// prefix in pre[0..n]; returns n and the total T.
+__device__ uint32_t nb_traverse(const Node *__restrict__ PR, uint32_t M, uint32_t D, const float *blo,
+                                const float *bhi, Item *buf, uint32_t caps, uint32_t *pre, uint32_t lane,
+                                Item **cur_out, uint32_t *T_out)
+{
+    Item *cur = buf, *nxt = buf + caps;
+    uint32_t n_cur = 1;
+    if (lane == 0)
+    {
+        cur[0].rank = 0;
+        cur[0].b = 0;
+        cur[0].e = M;
+    }
+    Coop<WAVE>::sync();
+    for (uint32_t lvl = 0; lvl < D; ++lvl)
+    {
+        const int axis = (int)(lvl % 3);
+        const float lo_a = axis == 0 ? blo[0] : (axis == 1 ? blo[1] : blo[2]);
+        const float hi_a = axis == 0 ? bhi[0] : (axis == 1 ? bhi[1] : bhi[2]);
+        uint32_t out_base = 0;
+        bool overflow = false;
+        for (uint32_t c0 = 0; c0 < n_cur; c0 += WAVE)
+        {
+            const bool valid = c0 + lane < n_cur;
+            Item it;
+            it.rank = it.b = 0;
+            it.e = NB_FINAL;
+            if (valid)
+                it = cur[c0 + lane];
+            const bool fin = it.e == NB_FINAL;
+            uint32_t cnt = 0, mid = 0;
+            bool goL = false, goR = false;
+            if (valid)
+            {
+                if (fin)
+                    cnt = 1;
+                else
+                {
+                    mid = it.b + (it.e - it.b) / 2;
+                    const Node nd = PR[it.rank];
+                    const float s = akey(nd, axis);
+                    goL = (mid > it.b) && (s >= lo_a);
+                    goR = (mid + 1 < it.e) && (s <= hi_a);
+                    cnt = 1u + (goL ? 1u : 0u) + (goR ? 1u : 0u);
+                }
+            }
+            const uint32_t incl = lpx_wave_incl_scan_u32(cnt);
+            const uint32_t tot = __builtin_amdgcn_readfirstlane(__shfl(incl, WAVE - 1, 64));
+            if (out_base + tot > caps)
+            {
+                overflow = true;
+                break;
+            }
+            if (valid)
+            {
+                uint32_t pos = out_base + incl - cnt;
+                if (fin)
+                    nxt[pos] = it;
+                else
+                {
+                    Item o;
+                    o.rank = it.rank;
+                    o.b = 1;
+                    o.e = NB_FINAL;
+                    nxt[pos++] = o;
+                    if (goL)
+                    {
+                        o.rank = it.rank + 1;
+                        o.b = it.b;
+                        o.e = mid;
+                        nxt[pos++] = o;
+                    }
+                    if (goR)
+                    {
+                        o.rank = it.rank + 1 + (mid - it.b);
+                        o.b = mid + 1;
+                        o.e = it.e;
+                        nxt[pos++] = o;
+                    }
+                }
+            }
+            out_base += tot;
+        }
+        if (overflow)
+            break;  // stopping early only widens the candidate intervals
+        Item *t = cur;
+        cur = nxt;
+        nxt = t;
+        n_cur = out_base;
+        Coop<WAVE>::sync();
+    }
+    uint32_t T = 0;
+    for (uint32_t c0 = 0; c0 < n_cur; c0 += WAVE)
+    {
+        const bool valid = c0 + lane < n_cur;
+        uint32_t cnt = 0;
+        if (valid)
+        {
+            const Item it = cur[c0 + lane];
+            cnt = (it.e == NB_FINAL) ? it.b : (it.e - it.b);
+        }
+        const uint32_t incl = lpx_wave_incl_scan_u32(cnt);
+        if (valid)
+            pre[c0 + lane] = T + incl - cnt;
+        T += __builtin_amdgcn_readfirstlane(__shfl(incl, WAVE - 1, 64));
+    }
+    if (lane == 0)
+        pre[n_cur] = T;
+    Coop<WAVE>::sync();
+    *cur_out = cur;
+    *T_out = T;
+    return n_cur;
+}
+
+// BLOCK = true : one workgroup per bucket subtree (<= 64 queries); the four wavefronts share the
+//                candidate tile and split the queries (query j -> wavefront j % 4)
+// BLOCK = false: one wavefront per node above the bucket level (a single query each)
+// Both count, allocate (64-bit atomic bump of frame->nb_total, one block of list storage per group)
+// and fill in the same launch; off[i] / len[i] locate the list of point i.
+template <bool BLOCK>
+__global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__restrict__ PR, FrameState *frame,
+                                                               float r2, float rr, uint32_t *__restrict__ len,
+                                                               uint32_t *__restrict__ off,
+                                                               uint32_t *__restrict__ nb_idx,
+                                                               float *__restrict__ nb_dist, uint64_t cap,
+                                                               uint32_t *__restrict__ parent,
+                                                               uint32_t *__restrict__ dbg)
+{
+    __shared__ Item s_seq[NB_SEQ];
+    __shared__ uint32_t s_pre[NB_SEQ / 2 + 8 * NB_WAVES];
+    __shared__ Node s_tile[NB_NODES];
+    __shared__ float s_cbox[NB_NODES / WAVE][6];
+    __shared__ uint32_t s_q[2][WAVE];  // per-query counts / write cursors (BLOCK mode)
+    __shared__ uint32_t s_n[4];        // n_cur, T, cur offset, abort
+    const uint32_t w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const uint32_t M = frame->n_obstacle;
+    if (M == 0)
+        return;
+    const float r2c = r2 * 1.0001f + 1.0e-6f;  // conservative radius^2 for the chunk cull
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t D = 0;
+    while ((M >> D) > (uint32_t)NB_BUCKET)
+        ++D;
+    const uint32_t nbk = 1u << D;
+    uint32_t level, path, gid;
+    if (BLOCK)
+    {
+        gid = blockIdx.x;
+        if (gid >= nbk)
+            return;
+        level = D;
+        path = gid;
+    }
+    else
+    {
+        const uint32_t u = blockIdx.x * NB_WAVES + w;
+        if (u >= nbk - 1)
+            return;
+        gid = nbk + u;
+        level = 31 - __clz(u + 1);
+        path = u + 1 - (1u << level);
+    }
+    uint32_t gb = 0, ge = M, grank = 0;
+    for (int d = (int)level - 1; d >= 0; --d)
+    {
+        if (gb >= ge)
+            break;
+        const uint32_t mid = gb + (ge - gb) / 2;
+        if ((path >> d) & 1u)
+        {
+            grank += 1 + (mid - gb);
+            gb = mid + 1;
+        }
+        else
+        {
+            grank += 1;
+            ge = mid;
+        }
+    }
+    if (gb >= ge)
+        return;
+    const uint32_t nq = __builtin_amdgcn_readfirstlane(BLOCK ? (ge - gb) : 1u);
+    const bool active = lane < nq;
+    const Node q = PR[grank + (active ? lane : 0u)];
+    const uint32_t qi = __float_as_uint(q.w);
+
+    // LDS partition: BLOCK mode uses everything, wave mode a quarter each
+    const uint32_t caps = BLOCK ? NB_SEQ / 2 : NB_SEQ / 2 / NB_WAVES;
+    const uint32_t tile_cap = BLOCK ? NB_NODES : NB_NODES / NB_WAVES;
+    Item *seqbuf = BLOCK ? s_seq : s_seq + w * (NB_SEQ / NB_WAVES);
+    uint32_t *pre = BLOCK ? s_pre : s_pre + w * (NB_SEQ / 2 / NB_WAVES + 8);
+    Node *tile = BLOCK ? s_tile : s_tile + w * (NB_NODES / NB_WAVES);
+    float(*cbox)[6] = BLOCK ? s_cbox : s_cbox + w * (NB_NODES / WAVE / NB_WAVES);
+    const uint32_t nthr = BLOCK ? NB_THREADS : WAVE;
+    const uint32_t tix = BLOCK ? threadIdx.x : lane;
+    const uint32_t nwav = BLOCK ? NB_WAVES : 1;
+    const uint32_t wix = BLOCK ? w : 0;
+
+    Item *cur = nullptr;
+    uint32_t n_cur = 0, T = 0;
+    if (!BLOCK || w == 0)
+    {
+        // bounding box of the group's queries, widened by a conservative radius
+        float blo[3] = {q.x, q.y, q.z}, bhi[3] = {q.x, q.y, q.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+        {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+            {
+                blo[a] = fminf(blo[a], __shfl_xor(blo[a], o, 64));
+                bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], o, 64));
+            }
+            blo[a] -= rr;
+            bhi[a] += rr;
+        }
+        n_cur = nb_traverse(PR, M, D, blo, bhi, seqbuf, caps, pre, lane, &cur, &T);
+        if (BLOCK && lane == 0)
+        {
+            s_n[0] = n_cur;
+            s_n[1] = T;
+            s_n[2] = (uint32_t)(cur - seqbuf);
+            s_n[3] = 0;
+        }
+    }
+    if (BLOCK)
+    {
+        __syncthreads();
+        n_cur = s_n[0];
+        T = s_n[1];
+        cur = seqbuf + s_n[2];
+    }
+
+    const unsigned long long lt = lpx_lanemask_lt();
+    uint32_t my_cnt = 0;     // lane j (of the wavefront that owns query j): list length of query j
+    uint32_t my_cursor = 0;  // ... and its write position
+    uint32_t my_min = qi;    // ... and the smallest neighbour index (first union-find link)
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        for (uint32_t t0 = 0; t0 < T; t0 += tile_cap)
+        {
+            const uint32_t tn = min(tile_cap, T - t0);
+            for (uint32_t c = tix; c < tn; c += nthr)
+            {
+                const uint32_t ci = t0 + c;
+                uint32_t lo = 0, hi = n_cur - 1;  // last interval with pre <= ci
+                while (lo < hi)
+                {
+                    const uint32_t m2 = (lo + hi + 1) / 2;
+                    if (pre[m2] <= ci)
+                        lo = m2;
+                    else
+                        hi = m2 - 1;
+                }
+                tile[c] = PR[cur[lo].rank + (ci - pre[lo])];
+            }
+            if (BLOCK)
+                __syncthreads();
+            else
+                Coop<WAVE>::sync();
+            // bounding box of each chunk of 64 consecutive candidates (rank order keeps them compact)
+            const uint32_t nchunks = (tn + WAVE - 1) / WAVE;
+            for (uint32_t c = wix; c < nchunks; c += nwav)
+            {
+                const bool valid = c * WAVE + lane < tn;
+                const Node nd = tile[valid ? c * WAVE + lane : c * WAVE];
+                float lo0 = nd.x, lo1 = nd.y, lo2 = nd.z, hi0 = nd.x, hi1 = nd.y, hi2 = nd.z;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                {
+                    lo0 = fminf(lo0, __shfl_xor(lo0, o, 64));
+                    lo1 = fminf(lo1, __shfl_xor(lo1, o, 64));
+                    lo2 = fminf(lo2, __shfl_xor(lo2, o, 64));
+                    hi0 = fmaxf(hi0, __shfl_xor(hi0, o, 64));
+                    hi1 = fmaxf(hi1, __shfl_xor(hi1, o, 64));
+                    hi2 = fmaxf(hi2, __shfl_xor(hi2, o, 64));
+                }
+                if (lane == 0)
+                {
+                    cbox[c][0] = lo0;
+                    cbox[c][1] = lo1;
+                    cbox[c][2] = lo2;
+                    cbox[c][3] = hi0;
+                    cbox[c][4] = hi1;
+                    cbox[c][5] = hi2;
+                }
+            }
+            if (BLOCK)
+                __syncthreads();
+            else
+                Coop<WAVE>::sync();
+            for (uint32_t j = wix; j < nq; j += nwav)
+            {
+                const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), j));
+                const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), j));
+                const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), j));
+                // cull: lane c tests chunk c's box against the query sphere (conservatively)
+                bool keep = false;
+                if (lane < nchunks)
+                {
+                    const float ex = fmaxf(fmaxf(cbox[lane][0] - qx, qx - cbox[lane][3]), 0.0f);
+                    const float ey = fmaxf(fmaxf(cbox[lane][1] - qy, qy - cbox[lane][4]), 0.0f);
+                    const float ez = fmaxf(fmaxf(cbox[lane][2] - qz, qz - cbox[lane][5]), 0.0f);
+                    keep = (ex * ex + ey * ey + ez * ez) <= r2c;
+                }
+                unsigned long long km = __ballot(keep);
+                uint32_t run = (pass == 0) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)my_cursor, j);
+                const uint32_t run0 = run;
+                uint32_t mn = 0xffffffffu;
+                while (km)
+                {
+                    // two surviving chunks per step: their LDS reads and compares overlap
+                    const uint32_t c0 = (uint32_t)(__ffsll((long long)km) - 1) * WAVE;
+                    km &= km - 1;
+                    const bool two = km != 0;
+                    const uint32_t c1 = two ? (uint32_t)(__ffsll((long long)km) - 1) * WAVE : c0;
+                    if (two)
+                        km &= km - 1;
+                    const bool v0 = c0 + lane < tn, v1 = two && (c1 + lane < tn);
+                    const Node n0 = tile[v0 ? c0 + lane : 0u];
+                    const Node n1 = tile[v1 ? c1 + lane : 0u];
+                    const float a0 = qx - n0.x, a1 = qy - n0.y, a2 = qz - n0.z;
+                    const float b0 = qx - n1.x, b1 = qy - n1.y, b2 = qz - n1.z;
+                    const float da = a0 * a0 + (a1 * a1 + (a2 * a2 + 0.0f));  // src/kdtree.hpp:145-157
+                    const float db = b0 * b0 + (b1 * b1 + (b2 * b2 + 0.0f));
+                    const bool ia = v0 && da <= r2, ib = v1 && db <= r2;      // :315 inclusive
+                    const unsigned long long ma = __ballot(ia), mb = __ballot(ib);
+                    const uint32_t na = __popcll(ma);
+                    if (pass == 0)
+                    {
+                        if (ia)
+                            mn = min(mn, __float_as_uint(n0.w));
+                        if (ib)
+                            mn = min(mn, __float_as_uint(n1.w));
+                    }
+                    if (pass == 1)
+                    {
+                        if (ia)
+                        {
+                            const uint32_t pos = run + __popcll(ma & lt);
+                            nb_idx[pos] = __float_as_uint(n0.w);
+                            nb_dist[pos] = da;
+                        }
+                        if (ib)
+                        {
+                            const uint32_t pos = run + na + __popcll(mb & lt);
+                            nb_idx[pos] = __float_as_uint(n1.w);
+                            nb_dist[pos] = db;
+                        }
+                    }
+                    run += na + __popcll(mb);
+                }
+                if (pass == 0)
+                {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1)
+                        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+                }
+                if (lane == j)
+                {
+                    if (pass == 0)
+                    {
+                        my_cnt += run;
+                        my_min = min(my_min, mn);
+                    }
+                    else
+                        my_cursor += run - run0;
+                }
+            }
+            if (BLOCK)
+                __syncthreads();
+            else
+                Coop<WAVE>::sync();
+        }
+        if (pass == 0)
+        {
+            // first link of the union-find forest: every point under its smallest neighbour
+            if (parent && active && (!BLOCK || (lane % NB_WAVES) == w))
+                parent[qi] = my_min;
+            if (BLOCK)
+            {
+                // gather the per-query counts (query j lives in lane j of wavefront j % 4)
+                if (active && (lane % NB_WAVES) == w)
+                    s_q[0][lane] = my_cnt;
+                __syncthreads();
+                if (w == 0)
+                {
+                    const uint32_t c = active ? s_q[0][lane] : 0u;
+                    const uint32_t incl = lpx_wave_incl_scan_u32(c);
+                    const uint32_t total = __shfl(incl, WAVE - 1, 64);
+                    unsigned long long base = 0;
+                    if (lane == 0)
+                        base = atomicAdd((unsigned long long *)&frame->nb_total, (unsigned long long)total);
+                    base = __shfl(base, 0, 64);
+                    const bool ok = base + total <= cap;
+                    if (ok && active)
+                    {
+                        const uint32_t o = (uint32_t)base + incl - c;
+                        s_q[1][lane] = o;
+                        off[qi] = o;
+                        len[qi] = c;
+                    }
+                    if (lane == 0)
+                    {
+                        s_n[3] = ok ? 0u : 1u;
+                        if (!ok)
+                            frame->status = (uint32_t)(-LPX_ERR_CAPACITY);
+                        if (dbg)
+                        {
+                            dbg[gid * 8 + 0] = T;
+                            dbg[gid * 8 + 1] = n_cur;
+                            dbg[gid * 8 + 2] = nq;
+                            dbg[gid * 8 + 3] = total;
+                            dbg[gid * 8 + 4] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_n[3])
+                    return;  // nb_total keeps growing to the required size
+                if (active && (lane % NB_WAVES) == w)
+                    my_cursor = s_q[1][lane];
+            }
+            else
+            {
+                const uint32_t total = __builtin_amdgcn_readlane((int)my_cnt, 0);
+                unsigned long long base = 0;
+                if (lane == 0)
+                    base = atomicAdd((unsigned long long *)&frame->nb_total, (unsigned long long)total);
+                base = __shfl(base, 0, 64);
+                if (base + total > cap)
+                {
+                    if (lane == 0)
+                        frame->status = (uint32_t)(-LPX_ERR_CAPACITY);
+                    return;
+                }
+                my_cursor = (uint32_t)base;
+                if (lane == 0)
+                {
+                    off[qi] = my_cursor;
+                    len[qi] = my_cnt;
+                    if (dbg)
+                    {
+                        dbg[gid * 8 + 0] = T;
+                        dbg[gid * 8 + 1] = n_cur;
+                        dbg[gid * 8 + 2] = nq;
+                        dbg[gid * 8 + 3] = total;
+                        dbg[gid * 8 + 4] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+                    }
+                }
+            }
+        }
+    }
+    if (dbg && lane == 0 && (!BLOCK || w == 0))
+        dbg[gid * 8 + 5] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+}
+
+// connected components of the d-graph.  The neighbour kernel has already put every point under its
+// smallest neighbour; cc_flatten_kernel points everybody at the current root, then one wavefront per
+// list checks every edge: equal roots (the common case) cost one cached load, the rest are united.
+__global__ void cc_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *parent)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame->n_obstacle)
+        return;
+    uint32_t x = i, p = uf_ld(parent + x);
+    while (p != x)
+    {
+        x = p;
+        p = uf_ld(parent + x);
+    }
+    uf_st(parent + i, x);
+}
+
+__global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restrict__ frame,
+                                                       const uint32_t *__restrict__ off,
+                                                       const uint32_t *__restrict__ len,
+                                                       const uint32_t *__restrict__ nb_idx, uint32_t *parent,
+                                                       uint64_t cap)
+{
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
+    if (i >= frame->n_obstacle || frame->nb_total > cap)
+        return;
+    const uint32_t o = off[i], n = len[i];
+    uint32_t ri = uf_ld(parent + i);
+    for (uint32_t t = lane; t < n; t += WAVE)
+    {
+        const uint32_t k = nb_idx[o + t];
+        if (k < i && uf_ld(parent + k) != ri)
+        {
+            uf_unite(parent, i, k);
+            ri = uf_find(parent, i);
+        }
+    }
 }
 
 __global__ void layout_idx_kernel(const Node *__restrict__ nodes, uint32_t m, uint32_t *__restrict__ out)
@@ -783,28 +1247,38 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
         return LPX_OK;
     FrameState *frame = (FrameState *)ctx->frame.p;
     const Node *nodes = (const Node *)ctx->nodes.p;
-    const dim3 blk(256), grd((m_max + 255) / 256);
+    Node *PR = (Node *)ctx->nodes_pre.p;
     uint32_t *len = (uint32_t *)ctx->nb_len.p, *off = (uint32_t *)ctx->nb_off.p;
+    // conservative radius for the group traversal (superset of every query's own traversal)
+    const float rr = sqrtf(r2) * 1.0001f + 1.0e-3f;
+    uint32_t dmax = 0;
+    while ((m_max >> dmax) > (uint32_t)NB_BUCKET)
+        ++dmax;
+    const uint32_t groups = 2u << dmax;  // 2^D bucket groups + (2^D - 1) upper nodes
     {
         StageTimer tm(ctx, ST_NB_COUNT);
-        hipLaunchKernelGGL((radius_kernel<false>), grd, blk, 0, ctx->stream, nodes, (const float *)ctx->OX.p,
-                           (const float *)ctx->OY.p, (const float *)ctx->OZ.p, frame, r2, len,
-                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (uint64_t)0,
-                           (uint32_t *)nullptr, 0);
-    }
-    {
-        StageTimer tm(ctx, ST_NB_SCAN);
-        int rc = lpx_exclusive_scan(ctx, len, off, m_max, &frame->n_obstacle, &frame->nb_total);
-        if (rc)
-            return rc;
-        hipLaunchKernelGGL(nb_check_kernel, dim3(1), dim3(64), 0, ctx->stream, frame, ctx->cap_nb);
+        hipLaunchKernelGGL(kd_preorder_kernel, dim3((m_max + 255) / 256), dim3(256), 0, ctx->stream, nodes, frame, PR);
     }
     {
         StageTimer tm(ctx, ST_NB_FILL);
-        hipLaunchKernelGGL((radius_kernel<true>), grd, blk, 0, ctx->stream, nodes, (const float *)ctx->OX.p,
-                           (const float *)ctx->OY.p, (const float *)ctx->OZ.p, frame, r2, len, off,
-                           (uint32_t *)ctx->nb_idx.p, (float *)ctx->nb_dist.p, ctx->cap_nb, (uint32_t *)ctx->parent.p,
-                           hook ? 1 : 0);
+        const uint32_t nbk = groups / 2;
+        hipLaunchKernelGGL((nb_group_kernel<true>), dim3(nbk), dim3(NB_THREADS), 0, ctx->stream, (const Node *)PR, frame,
+                           r2, rr, len, off, (uint32_t *)ctx->nb_idx.p, (float *)ctx->nb_dist.p, ctx->cap_nb,
+                           hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf);
+        if (nbk > 1)
+            hipLaunchKernelGGL((nb_group_kernel<false>), dim3((nbk + NB_WAVES - 1) / NB_WAVES), dim3(NB_THREADS), 0,
+                               ctx->stream, (const Node *)PR, frame, r2, rr, len, off, (uint32_t *)ctx->nb_idx.p,
+                               (float *)ctx->nb_dist.p, ctx->cap_nb,
+                               hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf);
+    }
+    if (hook)
+    {
+        StageTimer tm(ctx, ST_NB_SCAN);
+        hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256), dim3(256), 0, ctx->stream, frame,
+                           (uint32_t *)ctx->parent.p);
+        hipLaunchKernelGGL(cc_hook_kernel, dim3((m_max + 3) / 4), dim3(256), 0, ctx->stream, frame,
+                           (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
+                           (uint32_t *)ctx->parent.p, ctx->cap_nb);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
