@@ -56,6 +56,24 @@ def algorithmic_bytes(stage, N, M, E, I, P):
     }[stage]
 
 
+def frame_ids_for_rank(rank, world, frames_per_step, n_frames):
+    """Frame i of the global stream goes to GPU i mod world (SURVEY 8e): rank r owns i = r, r + world, ...;
+    the stream cycles over the n_frames available frames."""
+    return [(rank + world * j) % n_frames for j in range(frames_per_step)]
+
+
+def aggregate(elapsed_s, points_per_step, device, world):
+    """MAX of the per-rank time and SUM of the per-rank points (the only cross-rank exchange)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    pts = torch.tensor([float(points_per_step)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(pts.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,8 +108,7 @@ def main():
     # ---- inputs: resident in HBM before the timed region (32-byte PointXYZI records) ----
     host_frames = [load_frame(f) for f in FRAMES]
     F = args.frames_per_step
-    # frame i of the global stream goes to GPU i mod world: rank r owns i = r, r+world, ...
-    my_ids = [(rank + world * j) % len(host_frames) for j in range(F)]
+    my_ids = frame_ids_for_rank(rank, world, F, len(host_frames))
     recs = []
     for hf in host_frames:
         rec = np.zeros((hf.shape[0], 8), np.float32)
@@ -145,13 +162,7 @@ def main():
     if any(int(c[3]) != 0 for c in counts):
         raise SystemExit(f"device status != 0: {[int(c[3]) for c in counts]}")
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    pts = torch.tensor([float(points_per_step)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total_points_per_step = float(pts.item())
+    elapsed, total_points_per_step = aggregate(elapsed, points_per_step, dev, world)
 
     # ---- roofline of the dominant stage: same K steps with HIP-event pairs around every stage ----
     roofline = None

@@ -1,0 +1,94 @@
+// clustering.hpp -- drop-in replacement of the reference's src/clustering.hpp.
+//
+// Same names, namespace, defaults, sentinels and call surface as the reference
+// (src/clustering.hpp:40-90), so src/processor.cpp compiles against it unchanged
+// (#include "clustering.hpp", :27; member :132; call :178; sentinels used at :186-190).
+// cluster() works for every PCL point type whose record starts with float x, y, z
+// (the reference instantiates PointXYZ, PointXYZI, PointXYZL, PointXYZRGB, PointXYZRGBL).
+#ifndef LIDAR_PROCESSING__CLUSTERING_HPP
+#define LIDAR_PROCESSING__CLUSTERING_HPP
+
+#include "lpx_context.hpp"
+
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace lidar_processing
+{
+using ClusteringLabel = std::int32_t;
+
+struct ClusteringConfiguration final
+{
+    float distance_squared{0.18F};
+    float cluster_quality{0.5F};
+    std::uint32_t min_cluster_size{4U};
+    std::uint32_t max_cluster_size{std::numeric_limits<std::uint32_t>::max()};
+};
+
+class Clusterer final
+{
+  public:
+    static constexpr ClusteringLabel UNDEFINED{std::numeric_limits<std::int32_t>::lowest()};
+    static constexpr ClusteringLabel INVALID{-1};
+
+    Clusterer() : context_{std::make_shared<detail::LpxContext>()}, configuration_{}
+    {
+        reserve_memory();
+    }
+    explicit Clusterer(std::shared_ptr<detail::LpxContext> context) : context_{std::move(context)}, configuration_{}
+    {
+        reserve_memory();
+    }
+    ~Clusterer() = default;
+
+    void update_configuration(const ClusteringConfiguration &configuration)
+    {
+        configuration_ = configuration;
+    }
+
+    void reserve_memory(std::uint32_t number_of_points = 200'000U)
+    {
+        lpx_reserve(context_->get(), number_of_points, 0U);
+    }
+
+    template <typename PointT>
+    void cluster(const pcl::PointCloud<PointT> &cloud_in, std::vector<ClusteringLabel> &labels)
+    {
+        labels.assign(cloud_in.size(), UNDEFINED);
+        if (cloud_in.empty())
+        {
+            return;
+        }
+
+        lpx_clu_cfg cfg{};
+        cfg.distance_squared = configuration_.distance_squared;
+        cfg.cluster_quality = configuration_.cluster_quality;
+        cfg.min_cluster_size = configuration_.min_cluster_size;
+        cfg.max_cluster_size = configuration_.max_cluster_size;
+
+        std::uint32_t number_of_clusters = 0U;
+        const int rc = lpx_cluster(context_->get(), detail::points_base(cloud_in.points.data()), sizeof(PointT),
+                                   static_cast<std::uint32_t>(cloud_in.size()), &cfg, labels.data(),
+                                   &number_of_clusters);
+        if (rc != LPX_OK)
+        {
+            // The reference's only failure is KDTree::rebuild throwing std::runtime_error
+            // (src/kdtree.hpp:221-224); labels stay UNDEFINED, which the caller treats as fatal
+            // (src/processor.cpp:186-189).
+            throw std::runtime_error(std::string("clustering failed: ") + lpx_last_error(context_->get()));
+        }
+    }
+
+  private:
+    std::shared_ptr<detail::LpxContext> context_;
+    ClusteringConfiguration configuration_;
+};
+
+} // namespace lidar_processing
+
+#endif // LIDAR_PROCESSING__CLUSTERING_HPP

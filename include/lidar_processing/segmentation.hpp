@@ -1,0 +1,145 @@
+// segmentation.hpp -- drop-in replacement of the reference's src/segmentation.hpp.
+//
+// Same names, namespace, defaults and call surface as the reference (src/segmentation.hpp:41-139), so
+// src/processor.cpp compiles against it unchanged (#include "segmentation.hpp", :30; members :129;
+// call :150).  The work is done on the MI355X through the C-ABI of include/lpx.h; this header only
+// gathers the points of the two output clouds on the host, in the reference's order
+// (src/segmentation.cpp:331-343).
+#ifndef LIDAR_PROCESSING__SEGMENTATION_HPP
+#define LIDAR_PROCESSING__SEGMENTATION_HPP
+
+#include "lpx_context.hpp"
+
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace lidar_processing
+{
+enum class SegmentationLabel : std::uint32_t
+{
+    UNKNOWN = 0U,
+    GROUND,
+    OBSTACLE
+};
+
+struct SegmentationConfiguration final
+{
+    float sensor_height_m{1.73F};
+    float orthogonal_distance_threshold{0.3F};
+    float initial_seed_threshold{0.6F};
+    std::uint32_t number_of_iterations{3U};
+    std::uint32_t number_of_planar_partitions{2U};
+    std::uint32_t number_of_lower_point_representatives{5000U};
+};
+
+class Segmenter final
+{
+  public:
+    Segmenter() : context_{std::make_shared<detail::LpxContext>()}, configuration_{}
+    {
+        reserve_memory();
+    }
+    explicit Segmenter(std::shared_ptr<detail::LpxContext> context) : context_{std::move(context)}, configuration_{}
+    {
+        reserve_memory();
+    }
+    ~Segmenter() = default;
+
+    void update_configuration(const SegmentationConfiguration &configuration)
+    {
+        configuration_ = configuration;
+        reserve_memory();
+    }
+
+    void reserve_memory(std::uint32_t number_of_points = 200'000U)
+    {
+        lpx_reserve(context_->get(), number_of_points, 0U);
+        ground_indices_.reserve(number_of_points);
+        obstacle_indices_.reserve(number_of_points);
+    }
+
+    // Plane coefficients a, b, c, d (ax + by + cz = d) of the last plane fitted in every segment; the
+    // reference keeps them private (src/segmentation.cpp:245).
+    const std::vector<float> &planes() const noexcept
+    {
+        return planes_;
+    }
+
+    // shared GPU context, to keep the obstacle cloud on the device for the Clusterer
+    const std::shared_ptr<detail::LpxContext> &context() const noexcept
+    {
+        return context_;
+    }
+
+    template <typename PointT>
+    void segment(const pcl::PointCloud<PointT> &cloud_in, std::vector<SegmentationLabel> &labels,
+                 pcl::PointCloud<PointT> &ground_cloud, pcl::PointCloud<PointT> &obstacle_cloud)
+    {
+        static_assert(sizeof(SegmentationLabel) == sizeof(std::uint32_t), "label layout");
+        labels.resize(cloud_in.size(), SegmentationLabel::UNKNOWN);
+        ground_cloud.clear();
+        obstacle_cloud.clear();
+
+        const std::uint32_t number_of_points = static_cast<std::uint32_t>(cloud_in.points.size());
+        if (number_of_points == 0)
+        {
+            return;
+        }
+
+        ground_indices_.resize(number_of_points);
+        obstacle_indices_.resize(number_of_points);
+        planes_.assign(4U * configuration_.number_of_planar_partitions, 0.0F);
+
+        lpx_seg_cfg cfg{};
+        cfg.sensor_height_m = configuration_.sensor_height_m;
+        cfg.orthogonal_distance_threshold = configuration_.orthogonal_distance_threshold;
+        cfg.initial_seed_threshold = configuration_.initial_seed_threshold;
+        cfg.number_of_iterations = configuration_.number_of_iterations;
+        cfg.number_of_planar_partitions = configuration_.number_of_planar_partitions;
+        cfg.number_of_lower_point_representatives = configuration_.number_of_lower_point_representatives;
+
+        std::uint32_t number_of_ground = 0U;
+        std::uint32_t number_of_obstacle = 0U;
+        const int rc = lpx_segment(context_->get(), detail::points_base(cloud_in.points.data()), sizeof(PointT),
+                                   number_of_points, &cfg, reinterpret_cast<std::uint32_t *>(labels.data()),
+                                   ground_indices_.data(), &number_of_ground, obstacle_indices_.data(),
+                                   &number_of_obstacle, planes_.data());
+        if (rc != LPX_OK)
+        {
+            // the reference never throws from segment(): it reports on std::cerr and degrades to
+            // "everything is an obstacle" (src/segmentation.cpp:251-259)
+            std::cerr << "Failed ground segmentation: " << lpx_last_error(context_->get()) << std::endl;
+            for (std::uint32_t i = 0U; i < number_of_points; ++i)
+            {
+                labels[i] = SegmentationLabel::OBSTACLE;
+                obstacle_cloud.push_back(cloud_in[i]);
+            }
+            return;
+        }
+
+        ground_cloud.reserve(number_of_ground);
+        obstacle_cloud.reserve(number_of_obstacle);
+        for (std::uint32_t i = 0U; i < number_of_ground; ++i)
+        {
+            ground_cloud.push_back(cloud_in[ground_indices_[i]]);
+        }
+        for (std::uint32_t i = 0U; i < number_of_obstacle; ++i)
+        {
+            obstacle_cloud.push_back(cloud_in[obstacle_indices_[i]]);
+        }
+    }
+
+  private:
+    std::shared_ptr<detail::LpxContext> context_;
+    SegmentationConfiguration configuration_;
+    std::vector<std::uint32_t> ground_indices_;
+    std::vector<std::uint32_t> obstacle_indices_;
+    std::vector<float> planes_;
+};
+
+} // namespace lidar_processing
+
+#endif // LIDAR_PROCESSING__SEGMENTATION_HPP
