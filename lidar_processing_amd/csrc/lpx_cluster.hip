@@ -174,6 +174,135 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
     }
 }
 
+// Same replay with the point states in LDS: 2 bits per point over the whole index range (bit 0 queued,
+// bit 1 removed), one wavefront per workgroup.  Removes the global round trip from the dependent chain
+// of every step; list chunks are loaded four at a time; offsets/lengths are fetched with the queue
+// window.  Used when the bitmap fits (M <= 393 216 points), which covers every real frame.
+__global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__restrict__ frame,
+                                                           const uint32_t *__restrict__ cc_lo,
+                                                           const uint32_t *__restrict__ cc_hi,
+                                                           const uint32_t *__restrict__ members,
+                                                           const uint32_t *__restrict__ nb_off,
+                                                           const uint32_t *__restrict__ nb_len,
+                                                           const uint32_t *__restrict__ nb_idx,
+                                                           const float *__restrict__ nb_dist, int32_t *seed_of,
+                                                           uint32_t *queue, uint32_t *valid, ReplayParams prm,
+                                                           uint64_t cap)
+{
+    extern __shared__ uint32_t sbits[];
+    const uint32_t r = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t M = frame->n_obstacle;
+    if (r >= M || frame->nb_total > cap)
+        return;
+    const uint32_t lo = cc_lo[r], hi = cc_hi[r];
+    if (hi <= lo)
+        return;  // r is not a root
+    const uint32_t words = (M + 15) / 16;
+    for (uint32_t i = lane; i < words; i += WAVE)
+        sbits[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+#define ST_GET(k) ((sbits[(k) >> 4] >> (((k) & 15u) * 2u)) & 3u)
+#define ST_OR(k, v) atomicOr(&sbits[(k) >> 4], (uint32_t)(v) << (((k) & 15u) * 2u))
+    const unsigned long long lt = lpx_lanemask_lt();
+    uint32_t *q = queue + lo;
+    uint32_t cursor = lo;
+    for (;;)
+    {
+        uint32_t seed = 0xffffffffu;
+        while (cursor < hi)
+        {
+            const uint32_t p = cursor + lane;
+            const uint32_t cand = (p < hi) ? members[p] : 0u;
+            const bool ok = (p < hi) && !(ST_GET(cand) & 2u);
+            const unsigned long long m = __ballot(ok);
+            if (m)
+            {
+                const int f = __ffsll((long long)m) - 1;
+                seed = __shfl(cand, f, 64);
+                cursor += f + 1;
+                break;
+            }
+            cursor += WAVE;
+        }
+        if (seed == 0xffffffffu)
+            break;
+        uint32_t qh = 0, qt = 1;
+        unsigned long long touches = 0;
+        if (lane == 0)
+        {
+            q[0] = seed;
+            ST_OR(seed, 1u);
+        }
+        uint32_t wb = 0, wn = 0;  // queue window [wb, wb + wn) held in registers
+        uint32_t wcand = 0, woff = 0, wlen = 0;
+        while (qh < qt)
+        {
+            if (qh >= wb + wn)
+            {
+                __threadfence_block();  // queue entries pushed by other lanes
+                wb = qh;
+                wn = min((uint32_t)WAVE, qt - qh);
+                const bool in = lane < wn;
+                wcand = in ? q[wb + lane] : 0u;
+                woff = in ? nb_off[wcand] : 0u;
+                wlen = in ? nb_len[wcand] : 0u;
+            }
+            const bool ok = (lane < wn) && (wb + lane >= qh) && !(ST_GET(wcand) & 2u);
+            const unsigned long long m = __ballot(ok);
+            if (!m)
+            {
+                qh = wb + wn;
+                continue;
+            }
+            const int f = __ffsll((long long)m) - 1;
+            const uint32_t o0 = __shfl(woff, f, 64), cnt = __shfl(wlen, f, 64);
+            qh = wb + f + 1;
+            for (uint32_t base = 0; base < cnt; base += 4 * WAVE)
+            {
+                uint32_t kk[4];
+                float dd[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    const uint32_t t = base + c * WAVE + lane;
+                    const bool in = t < cnt;
+                    kk[c] = in ? nb_idx[o0 + t] : 0xffffffffu;
+                    dd[c] = in ? nb_dist[o0 + t] : 0.0f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    if (base + c * WAVE >= cnt)
+                        break;
+                    const bool in = kk[c] != 0xffffffffu;
+                    const uint32_t k = in ? kk[c] : 0u;
+                    const uint32_t sk = in ? ST_GET(k) : 2u;
+                    const bool vis = in && !(sk & 2u);
+                    touches += __popcll(__ballot(vis));
+                    const bool absorb = vis && ((double)dd[c] <= prm.thr);
+                    const bool push = vis && !absorb && sk == 0u;
+                    const unsigned long long pm = __ballot(push);
+                    if (vis)
+                        seed_of[k] = (int32_t)seed;
+                    if (absorb)
+                        ST_OR(k, 2u);
+                    if (push)
+                    {
+                        q[qt + __popcll(pm & lt)] = k;
+                        ST_OR(k, 1u);
+                    }
+                    qt += __popcll(pm);
+                }
+            }
+        }
+        if (lane == 0)
+            valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;
+    }
+#undef ST_GET
+#undef ST_OR
+}
+
 __global__ void relabel_kernel(const FrameState *__restrict__ frame, const int32_t *__restrict__ seed_of,
                                const uint32_t *__restrict__ valid, const uint32_t *__restrict__ dense,
                                int32_t *__restrict__ labels, uint64_t cap)
@@ -240,10 +369,27 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         prm.thr = (one_minus_q * one_minus_q) * (double)cfg->distance_squared;  // std::pow(x, 2) == x*x exactly
         prm.min_size = cfg->min_cluster_size;
         prm.max_size = cfg->max_cluster_size;
-        hipLaunchKernelGGL(replay_kernel, dim3((m_max + RP_WAVES - 1) / RP_WAVES), dim3(RP_WAVES * WAVE), 0, st, frame,
-                           cc_lo, cc_hi, members, (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,
-                           (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->nb_dist.p, (uint8_t *)ctx->state.p,
-                           (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb);
+        const size_t lds = sizeof(uint32_t) * (((size_t)m_max + 15) / 16);
+        if (lds <= 96 * 1024)
+        {
+            static bool attr_set = false;
+            if (!attr_set)
+            {
+                LPX_HIP(ctx, hipFuncSetAttribute((const void *)replay_lds_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(replay_lds_kernel, dim3(m_max), dim3(WAVE), lds, st, frame, cc_lo, cc_hi, members,
+                               (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,
+                               (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->nb_dist.p,
+                               (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb);
+        }
+        else
+            hipLaunchKernelGGL(replay_kernel, dim3((m_max + RP_WAVES - 1) / RP_WAVES), dim3(RP_WAVES * WAVE), 0, st,
+                               frame, cc_lo, cc_hi, members, (const uint32_t *)ctx->nb_off.p,
+                               (const uint32_t *)ctx->nb_len.p, (const uint32_t *)ctx->nb_idx.p,
+                               (const float *)ctx->nb_dist.p, (uint8_t *)ctx->state.p, (int32_t *)ctx->seed_of.p,
+                               (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb);
     }
     {
         StageTimer tm(ctx, ST_LABELS);
