@@ -25,6 +25,11 @@ import time
 
 import numpy as np
 
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
+# queue serialise.  The bench keeps many frames in flight on separate streams, so ask for 16 queues.
+# Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -79,8 +84,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=24, help="frames in one batch (per GPU)")
-    ap.add_argument("--contexts", type=int, default=8, help="concurrent lpx contexts (HIP streams) per GPU")
+    ap.add_argument("--frames-per-step", type=int, default=64, help="frames in one batch (per GPU)")
+    ap.add_argument("--contexts", type=int, default=32, help="concurrent lpx contexts (HIP streams) per GPU")
+    ap.add_argument("--threads", type=int, default=4, help="host threads that enqueue (ctypes releases the GIL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,12 +135,26 @@ def main():
                          counts=torch.zeros(4, dtype=torch.int32, device=dev)))
     points_per_step = sum(host_frames[i].shape[0] for i in my_ids)
 
-    def step():
+    import concurrent.futures
+    T = max(1, min(args.threads, C))
+    pool = concurrent.futures.ThreadPoolExecutor(T) if T > 1 else None
+
+    def enqueue(tid):
+        # thread tid owns contexts tid, tid + T, ... and therefore frames j with (j % C) % T == tid
+        torch.cuda.set_device(local_rank)
         for j, fid in enumerate(my_ids):
+            if (j % C) % T != tid:
+                continue
             o = outs[j]
             ctxs[j % C].segment_cluster_device(recs[fid].data_ptr(), 32, host_frames[fid].shape[0], scfg, ccfg,
                                                o["labels"].data_ptr(), o["gidx"].data_ptr(), o["oidx"].data_ptr(),
                                                o["planes"].data_ptr(), o["clabels"].data_ptr(), o["counts"].data_ptr())
+
+    def step():
+        if pool is None:
+            enqueue(0)
+        else:
+            list(pool.map(enqueue, range(T)))
 
     def sync():
         for c in ctxs:
@@ -238,7 +258,8 @@ def main():
             "dtype": "f32",
             "data": "real KITTI frames (committed fixture of the reference's data/*.pcd), random-free",
             "config": {"workload": "configs[1]: 120k-pt KITTI frames, 6 segments, 5 iters, FEC d=0.5 m q=0.5",
-                       "frames_per_step_per_gpu": F, "contexts_per_gpu": C,
+                       "frames_per_step_per_gpu": F, "contexts_per_gpu": C, "host_threads_per_gpu": T,
+                       "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "points_per_step": int(total_points_per_step),
                        "frames_per_s": round(F * world * args.steps / elapsed, 2)},
             "roofline": roofline,

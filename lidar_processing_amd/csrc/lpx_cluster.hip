@@ -52,8 +52,9 @@ __global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ 
 }
 
 // sorted by root (stable): members of a component are contiguous, ascending original index
-__global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, const FrameState *__restrict__ frame,
-                                 uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi)
+__global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, FrameState *frame,
+                                 uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi,
+                                 uint32_t *__restrict__ roots)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
@@ -61,7 +62,10 @@ __global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, const Frame
         return;
     const uint32_t r = sroot[p];
     if (p == 0 || sroot[p - 1] != r)
+    {
         cc_lo[r] = p;
+        roots[atomicAdd(&frame->n_roots, 1u)] = r;  // work list of the replay
+    }
     if (p + 1 == M || sroot[p + 1] != r)
         cc_hi[r] = p + 1;
 }
@@ -187,21 +191,33 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                                                            const uint32_t *__restrict__ nb_idx,
                                                            const float *__restrict__ nb_dist, int32_t *seed_of,
                                                            uint32_t *queue, uint32_t *valid, ReplayParams prm,
-                                                           uint64_t cap)
+                                                           uint64_t cap, FrameState *fstate,
+                                                           const uint32_t *__restrict__ roots)
 {
     extern __shared__ uint32_t sbits[];
-    const uint32_t r = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const uint32_t M = frame->n_obstacle;
-    if (r >= M || frame->nb_total > cap)
+    if (frame->nb_total > cap)
         return;
-    const uint32_t lo = cc_lo[r], hi = cc_hi[r];
-    if (hi <= lo)
-        return;  // r is not a root
+    const uint32_t n_roots = frame->n_roots;
+    if (blockIdx.x >= n_roots)
+        return;
+    // the bitmap is zeroed once: components own disjoint points, so the 2-bit states of one component
+    // are never read by another
     const uint32_t words = (M + 15) / 16;
     for (uint32_t i = lane; i < words; i += WAVE)
         sbits[i] = 0;
     __builtin_amdgcn_wave_barrier();
+  for (;;)
+  {
+    uint32_t ticket = 0;
+    if (lane == 0)
+        ticket = atomicAdd(&fstate->root_cursor, 1u);
+    ticket = __shfl(ticket, 0, 64);
+    if (ticket >= n_roots)
+        break;
+    const uint32_t r = roots[ticket];
+    const uint32_t lo = cc_lo[r], hi = cc_hi[r];
 #define ST_GET(k) ((sbits[(k) >> 4] >> (((k) & 15u) * 2u)) & 3u)
 #define ST_OR(k, v) atomicOr(&sbits[(k) >> 4], (uint32_t)(v) << (((k) & 15u) * 2u))
     const unsigned long long lt = lpx_lanemask_lt();
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
         if (lane == 0)
             valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;
     }
+  }
 #undef ST_GET
 #undef ST_OR
 }
@@ -360,7 +377,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                             &frame->n_obstacle, bits_for_count(m_max), &sroot, &members);
         if (rc)
             return rc;
-        hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, sroot, frame, cc_lo, cc_hi);
+        hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, sroot, frame, cc_lo, cc_hi, (uint32_t *)ctx->rpos.p);
     }
     {
         StageTimer tm(ctx, ST_REPLAY);
@@ -379,10 +396,12 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(replay_lds_kernel, dim3(m_max), dim3(WAVE), lds, st, frame, cc_lo, cc_hi, members,
+            const uint32_t rgrid = m_max < 1024u ? m_max : 1024u;  // persistent: blocks pull components from a list
+            hipLaunchKernelGGL(replay_lds_kernel, dim3(rgrid), dim3(WAVE), lds, st, frame, cc_lo, cc_hi, members,
                                (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,
                                (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->nb_dist.p,
-                               (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb);
+                               (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb, frame,
+                               (const uint32_t *)ctx->rpos.p);
         }
         else
             hipLaunchKernelGGL(replay_kernel, dim3((m_max + RP_WAVES - 1) / RP_WAVES), dim3(RP_WAVES * WAVE), 0, st,

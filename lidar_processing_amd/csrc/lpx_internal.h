@@ -39,7 +39,8 @@ struct FrameState
     uint32_t n_clusters;
     uint32_t status;      // 0 ok, else -LPX_ERR_*
     uint64_t nb_total;    // total neighbour entries required
-    uint32_t pad[2];
+    uint32_t n_roots;     // connected components of the d-graph
+    uint32_t root_cursor; // work queue head of the replay
 };
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)

@@ -1170,19 +1170,23 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
                                                        const uint32_t *__restrict__ nb_idx, uint32_t *parent,
                                                        uint64_t cap)
 {
-    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
-    if (i >= frame->n_obstacle || frame->nb_total > cap)
+    const uint32_t M = frame->n_obstacle;
+    if (frame->nb_total > cap)
         return;
-    const uint32_t o = off[i], n = len[i];
-    uint32_t ri = uf_ld(parent + i);
-    for (uint32_t t = lane; t < n; t += WAVE)
+    const uint32_t stride = gridDim.x * (blockDim.x / WAVE);
+    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE; i < M; i += stride)
     {
-        const uint32_t k = nb_idx[o + t];
-        if (k < i && uf_ld(parent + k) != ri)
+        const uint32_t o = off[i], n = len[i];
+        uint32_t ri = uf_ld(parent + i);
+        for (uint32_t t = lane; t < n; t += WAVE)
         {
-            uf_unite(parent, i, k);
-            ri = uf_find(parent, i);
+            const uint32_t k = nb_idx[o + t];
+            if (k < i && uf_ld(parent + k) != ri)
+            {
+                uf_unite(parent, i, k);
+                ri = uf_find(parent, i);
+            }
         }
     }
 }
@@ -1276,7 +1280,8 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
         StageTimer tm(ctx, ST_NB_SCAN);
         hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256), dim3(256), 0, ctx->stream, frame,
                            (uint32_t *)ctx->parent.p);
-        hipLaunchKernelGGL(cc_hook_kernel, dim3((m_max + 3) / 4), dim3(256), 0, ctx->stream, frame,
+        const uint32_t hgrid = (m_max + 3) / 4 < 4096u ? (m_max + 3) / 4 : 4096u;
+        hipLaunchKernelGGL(cc_hook_kernel, dim3(hgrid), dim3(256), 0, ctx->stream, frame,
                            (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
                            (uint32_t *)ctx->parent.p, ctx->cap_nb);
     }
