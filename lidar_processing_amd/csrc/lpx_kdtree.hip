@@ -285,6 +285,13 @@ struct Coop<64>
             v += __shfl_xor(v, o, 64);
         return v;
     }
+    // exclusive scan of two 16-bit counters packed in one word
+    static __device__ __forceinline__ void scan_packed(uint32_t v, uint32_t &excl, uint32_t &total, uint32_t *)
+    {
+        const uint32_t incl = lpx_wave_incl_scan_u32(v);
+        excl = incl - v;
+        total = __shfl(incl, WAVE - 1, 64);
+    }
 };
 
 template <>
@@ -324,6 +331,26 @@ struct Coop<1024>
         t0 = s0;
         t1 = s1;
     }
+    static __device__ __forceinline__ void scan_packed(uint32_t v, uint32_t &excl, uint32_t &total, uint32_t *cs)
+    {
+        const uint32_t incl = lpx_wave_incl_scan_u32(v);
+        const uint32_t w = threadIdx.x / WAVE;
+        if ((threadIdx.x % WAVE) == WAVE - 1)
+            cs[w] = incl;
+        __syncthreads();
+        uint32_t b = 0, s = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+        {
+            const uint32_t c = cs[i];
+            if (i < (int)w)
+                b += c;
+            s += c;
+        }
+        __syncthreads();
+        excl = b + incl - v;
+        total = s;
+    }
     static __device__ __forceinline__ uint32_t sum(uint32_t v, uint32_t *cs)
     {
 #pragma unroll
@@ -351,21 +378,37 @@ __device__ int coop_partition_pivot(const View &v, int first, int last, int axis
     Coop<G>::sync();
     const float pv = nkey(v, first, axis);
     int cntL = 0, cntR = 0;
-    for (int base = first + 1; base < last; base += G)
+    // flag pass, PE consecutive positions per thread: their loads overlap and there is one scan per G*PE keys
+    constexpr int PE = 4;
+    for (int base = first + 1; base < last; base += G * PE)
     {
-        const int p = base + tid;
-        const bool valid = p < last;
-        const float k = valid ? nkey(v, p, axis) : 0.0f;
-        const bool ge = valid && !(k < pv);  // left cursor stops here
-        const bool le = valid && !(pv < k);  // right cursor stops here
-        uint32_t rL, rR, tL, tR;
-        Coop<G>::scan2(ge, le, rL, rR, tL, tR, cs);
-        if (ge)
-            v.lp[first + cntL + (int)rL - v.off] = (uint32_t)p;
-        if (le)
-            v.ra[first + cntR + (int)rR - v.off] = (uint32_t)p;
-        cntL += (int)tL;
-        cntR += (int)tR;
+        const int p0 = base + tid * PE;
+        bool ge[PE], le[PE];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < PE; ++e)
+        {
+            const int p = p0 + e;
+            const bool valid = p < last;
+            const float k = valid ? nkey(v, p, axis) : 0.0f;
+            ge[e] = valid && !(k < pv);  // left cursor stops here
+            le[e] = valid && !(pv < k);  // right cursor stops here
+            packed += (ge[e] ? 1u : 0u) + (le[e] ? 0x10000u : 0u);
+        }
+        uint32_t excl, total;
+        Coop<G>::scan_packed(packed, excl, total, cs);
+        int rL = first + cntL + (int)(excl & 0xffffu) - v.off;
+        int rR = first + cntR + (int)(excl >> 16) - v.off;
+#pragma unroll
+        for (int e = 0; e < PE; ++e)
+        {
+            if (ge[e])
+                v.lp[rL++] = (uint32_t)(p0 + e);
+            if (le[e])
+                v.ra[rR++] = (uint32_t)(p0 + e);
+        }
+        cntL += (int)(total & 0xffffu);
+        cntR += (int)(total >> 16);
     }
     Coop<G>::sync();
     const int kmax = min(cntL, cntR);
@@ -418,6 +461,9 @@ __global__ void kd_init_kernel(const float *__restrict__ OX, const float *__rest
 
 constexpr int BLK_G = 1024;
 constexpr int BLK_CAP = 4096;  // nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch
+constexpr int SUB_CAP = 512;   // nodes per wavefront subtree
+constexpr int SUB_LEAF = 16;   // below this one lane finishes a subtree on its own
+constexpr int SUB_WAVES = 4;
 
 // one workgroup per range of `level`: std::nth_element(b, mid, e) on axis level % 3
 __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
@@ -431,6 +477,8 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
 
     const int tid = threadIdx.x;
     int b = 0, e = (int)frame->n_obstacle;
+    if ((e >> level) <= SUB_CAP)
+        return;  // this level already belongs to the subtree kernel (the host planned with an upper bound)
     descend(b, e, blockIdx.x, level);
     if (e - b < 2)
         return;
@@ -486,10 +534,6 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
             nodes[i] = l_nodes[i - sb];
 }
 
-constexpr int SUB_CAP = 512;   // nodes per wavefront subtree
-constexpr int SUB_LEAF = 16;   // below this one lane finishes a subtree on its own
-constexpr int SUB_WAVES = 4;
-
 // one wavefront per range of `level` (<= SUB_CAP nodes): the whole subtree below it, in LDS
 __global__ __launch_bounds__(SUB_WAVES *WAVE) void kd_subtree_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
                                                                      const FrameState *__restrict__ frame, int level)
@@ -499,9 +543,16 @@ __global__ __launch_bounds__(SUB_WAVES *WAVE) void kd_subtree_kernel(Node *nodes
     __shared__ uint32_t l_ra[SUB_WAVES][SUB_CAP];
     const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     const uint32_t r = blockIdx.x * SUB_WAVES + w;
+    int b = 0, e = (int)frame->n_obstacle;
+    // first level whose ranges fit a wavefront, from the real point count (the host used a bound)
+    {
+        int lv = 0;
+        while ((e >> lv) > SUB_CAP)
+            ++lv;
+        level = lv;
+    }
     if (r >= (1u << level))
         return;
-    int b = 0, e = (int)frame->n_obstacle;
     descend(b, e, r, level);
     const int n = e - b;
     if (n < 2)

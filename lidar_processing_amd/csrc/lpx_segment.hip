@@ -517,16 +517,20 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     if (!s_last)
         return;
     __threadfence();
-    // last block of the segment: solve and publish plane t, reset the accumulators
+    // last block of the segment: solve and publish plane t, reset the accumulators.  The 16 words are
+    // fetched and cleared by 16 lanes at once (a single lane would chain 32 dependent atomics).
+    if (tid < LPX_ACC_WORDS)
+    {
+        red[0][tid] = (long long)atomicExch((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], 0ull);
+        if (tid == 0)
+            atomicExch(&ticket[s], 0u);
+    }
+    __syncthreads();
     if (tid == 0)
     {
         long long m[LPX_ACC_WORDS];
         for (int i = 0; i < LPX_ACC_WORDS; ++i)
-        {
-            m[i] = (long long)atomicAdd((unsigned long long *)&acc[s * LPX_ACC_WORDS + i], 0ull);
-            atomicExch((unsigned long long *)&acc[s * LPX_ACC_WORDS + i], 0ull);
-        }
-        atomicExch(&ticket[s], 0u);
+            m[i] = red[0][i];
         SegState o = sst;
         if (!dead)
         {
