@@ -209,18 +209,19 @@ __device__ __forceinline__ uint32_t lpx_wave_sum_u32(uint32_t v)
     return v;
 }
 
-// inclusive scan inside a wave
+// inclusive scan inside a wave with DPP row shifts / broadcasts (VALU only, no LDS crossbar): the
+// wave64 sequence of GFX9 -- row_shr 1,2,4,8 inside each row of 16, then row_bcast:15 into rows 1 and 3,
+// then row_bcast:31 into rows 2 and 3.
 __device__ __forceinline__ uint32_t lpx_wave_incl_scan_u32(uint32_t v)
 {
-    const unsigned lane = __lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1)
-    {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= (unsigned)o)
-            v += t;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return (uint32_t)x;
 }
 
 #endif  // __HIPCC__

@@ -462,7 +462,7 @@ __global__ void kd_init_kernel(const float *__restrict__ OX, const float *__rest
 constexpr int BLK_G = 1024;
 constexpr int BLK_CAP = 4096;  // nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch
 constexpr int SUB_CAP = 512;   // nodes per wavefront subtree
-constexpr int SUB_LEAF = 16;   // below this one lane finishes a subtree on its own
+constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
 constexpr int SUB_WAVES = 4;
 
 // one workgroup per range of `level`: std::nth_element(b, mid, e) on axis level % 3
@@ -477,8 +477,8 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
 
     const int tid = threadIdx.x;
     int b = 0, e = (int)frame->n_obstacle;
-    if ((e >> level) <= SUB_CAP)
-        return;  // this level already belongs to the subtree kernel (the host planned with an upper bound)
+    if ((e >> level) <= BLK_CAP)
+        return;  // this level already belongs to kd_lds_kernel (the host planned with an upper bound)
     descend(b, e, blockIdx.x, level);
     if (e - b < 2)
         return;
@@ -534,103 +534,244 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
             nodes[i] = l_nodes[i - sb];
 }
 
-// one wavefront per range of `level` (<= SUB_CAP nodes): the whole subtree below it, in LDS
-__global__ __launch_bounds__(SUB_WAVES *WAVE) void kd_subtree_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
-                                                                     const FrameState *__restrict__ frame, int level)
+// ------------------------------------------------------------------------------------------------
+// Whole subtree of a range that fits LDS (<= BLK_CAP nodes), one workgroup.
+//
+// Sub-level s has 2^s independent ranges; they are partitioned SIMULTANEOUSLY by 2^s groups of
+// 1024 >> s consecutive threads (whole wavefronts while the group has >= 64 threads, lane segments of
+// a wavefront below that), so a sub-level costs one nth_element's worth of rounds instead of 2^s.
+// With PE = 4 keys per thread a group always covers its range in a single flag pass
+// (group size * 4 >= range size), so every introselect round has the same fixed shape:
+// median-of-3 (group leader) | flags + segmented scan | stop lists | swaps + count | cut.
+// Below SUB_LEAF nodes one lane finishes a subtree sequentially.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void group_scan_packed(uint32_t v, int gs, int tid, uint32_t *cs, bool blockmode,
+                                                  uint32_t &excl, uint32_t &total)
 {
-    __shared__ Node l_nodes[SUB_WAVES][SUB_CAP];
-    __shared__ uint32_t l_lp[SUB_WAVES][SUB_CAP];
-    __shared__ uint32_t l_ra[SUB_WAVES][SUB_CAP];
-    const int w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    const uint32_t r = blockIdx.x * SUB_WAVES + w;
-    int b = 0, e = (int)frame->n_obstacle;
-    // first level whose ranges fit a wavefront, from the real point count (the host used a bound)
+    const uint32_t incl = lpx_wave_incl_scan_u32(v);
+    if (blockmode)
     {
-        int lv = 0;
-        while ((e >> lv) > SUB_CAP)
-            ++lv;
-        level = lv;
+        const int w = tid / WAVE;
+        if ((tid % WAVE) == WAVE - 1)
+            cs[w] = incl;
+        __syncthreads();
+        const int gwn = gs / WAVE, gw0 = (tid / gs) * gwn;
+        uint32_t bsum = 0, ssum = 0;
+        for (int i = 0; i < gwn; ++i)
+        {
+            const uint32_t c = cs[gw0 + i];
+            if (gw0 + i < w)
+                bsum += c;
+            ssum += c;
+        }
+        __syncthreads();
+        excl = bsum + incl - v;
+        total = ssum;
     }
-    if (r >= (1u << level))
+    else
+    {
+        const int lane = tid % WAVE;
+        const int g0 = lane & ~(gs - 1);
+        const uint32_t before_raw = __shfl(incl, g0 > 0 ? g0 - 1 : 0, 64);
+        const uint32_t before = g0 > 0 ? before_raw : 0u;
+        const uint32_t lastv = __shfl(incl, g0 + gs - 1, 64);
+        excl = incl - v - before;
+        total = lastv - before;
+    }
+}
+
+constexpr int LG = 256;  // threads of kd_lds_kernel: one wavefront per SIMD, little per-round overhead
+
+__global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, const FrameState *__restrict__ frame,
+                                                    uint32_t *__restrict__ dbg)
+{
+    const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t n_rounds = 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Node *l_nodes = (Node *)smem;
+    uint32_t *l_lp = (uint32_t *)(smem + sizeof(Node) * BLK_CAP);
+    uint32_t *l_ra = l_lp + BLK_CAP;
+    uint32_t *cs = l_ra + BLK_CAP;
+    const int tid = threadIdx.x;
+    const int M = (int)frame->n_obstacle;
+    int lv = 0;
+    while ((M >> lv) > BLK_CAP)
+        ++lv;
+    if (blockIdx.x >= (1u << lv))
         return;
-    descend(b, e, r, level);
+    int b = 0, e = M;
+    descend(b, e, blockIdx.x, lv);
     const int n = e - b;
     if (n < 2)
         return;
+    for (int i = tid; i < n; i += LG)
+        l_nodes[i] = nodes[b + i];
     View v;
-    const bool staged = n <= SUB_CAP;
-    if (staged)
-    {
-        for (int i = lane; i < n; i += WAVE)
-            l_nodes[w][i] = nodes[b + i];
-        v.a = l_nodes[w];
-        v.lp = l_lp[w];
-        v.ra = l_ra[w];
-        v.off = b;
-    }
-    else
-    {  // host bound was wrong: stay correct, in global memory
-        v.a = nodes;
-        v.lp = lpos;
-        v.ra = rasc;
-        v.off = 0;
-    }
-    Coop<WAVE>::sync();
+    v.a = l_nodes;
+    v.lp = l_lp;
+    v.ra = l_ra;
+    v.off = b;
+    __syncthreads();
 
-    // cooperative levels while ranges are larger than SUB_LEAF
     int s = 0;
-    for (;; ++s)
+    for (; (n >> s) > SUB_LEAF && (LG >> s) >= 1; ++s)
     {
-        // largest range at sub-level s is ceil-ish n / 2^s
-        if ((n >> s) <= SUB_LEAF)
-            break;
-        const int axis = (level + s) % 3;
-        for (uint32_t j = 0; j < (1u << s); ++j)
+        const int gs = LG >> s;
+        const bool blockmode = gs >= WAVE;
+        const int g = tid / gs, gl = tid % gs;
+        int rb = b, re = e;
+        descend(rb, re, (uint32_t)g, s);
+        const int axis = (lv + s) % 3;
+        int first = rb, last = re;
+        const int nth = rb + (re - rb) / 2;
+        int depth_limit = (re - rb >= 2) ? 2 * floor_log2(re - rb) : 0;
+        bool done = (re - rb) < 2;
+        for (;;)
         {
-            int rb = b, re = e;
-            descend(rb, re, j, s);
-            if (re - rb < 2)
-                continue;
-            const int nth = rb + (re - rb) / 2;
-            int first = rb, last = re;
-            int depth_limit = 2 * floor_log2(re - rb);
-            bool done = false;
-            while (last - first > 3)
+            const bool act = !done && (last - first > 3);
+            bool any;
+            if (blockmode)
+                any = __syncthreads_or(act ? 1 : 0) != 0;
+            else
             {
-                if (depth_limit == 0)
+                Coop<WAVE>::sync();
+                any = __any(act ? 1 : 0) != 0;
+            }
+            if (!any)
+                break;
+            ++n_rounds;
+            const bool part = act && depth_limit > 0;
+            if (act && depth_limit == 0)
+            {
+                if (gl == 0)
                 {
-                    if (lane == 0)
-                    {
-                        seq_heap_select(v, first, nth + 1, last, axis);
-                        nswap(v, first, nth);
-                    }
-                    done = true;
-                    break;
+                    seq_heap_select(v, first, nth + 1, last, axis);
+                    nswap(v, first, nth);
                 }
+                done = true;
+            }
+            if (part)
+            {
                 --depth_limit;
-                const int cut = coop_partition_pivot<WAVE>(v, first, last, axis, lane, nullptr);
+                if (gl == 0)
+                    seq_median_to_first(v, first, last, axis);
+            }
+            if (blockmode)
+                __syncthreads();
+            else
+                Coop<WAVE>::sync();
+            // flag pass: the group's span is cut into gs contiguous runs of `pe` keys (pe <= 16)
+            const float pv = part ? nkey(v, first, axis) : 0.0f;
+            const int span = part ? (last - first - 1) : 0;
+            const int pe = (span + gs - 1) / gs;
+            const int p0 = first + 1 + gl * pe;
+            uint32_t gem = 0, lem = 0;
+            for (int q = 0; q < pe; ++q)
+            {
+                const int p = p0 + q;
+                if (p < last)
+                {
+                    const float k = nkey(v, p, axis);
+                    gem |= (!(k < pv) ? 1u : 0u) << q;
+                    lem |= (!(pv < k) ? 1u : 0u) << q;
+                }
+            }
+            const uint32_t packed = (uint32_t)__popc(gem) + ((uint32_t)__popc(lem) << 16);
+            uint32_t excl, total;
+            group_scan_packed(packed, gs, tid, cs, blockmode, excl, total);
+            const int cntL = (int)(total & 0xffffu), cntR = (int)(total >> 16);
+            {
+                int rL = first + (int)(excl & 0xffffu) - v.off;
+                int rR = first + (int)(excl >> 16) - v.off;
+                uint32_t m = gem;
+                while (m)
+                {
+                    const int q = __ffs(m) - 1;
+                    m &= m - 1;
+                    v.lp[rL++] = (uint32_t)(p0 + q);
+                }
+                m = lem;
+                while (m)
+                {
+                    const int q = __ffs(m) - 1;
+                    m &= m - 1;
+                    v.ra[rR++] = (uint32_t)(p0 + q);
+                }
+            }
+            if (blockmode)
+                __syncthreads();
+            else
+                Coop<WAVE>::sync();
+            const int kmax = part ? min(cntL, cntR) : 0;
+            uint32_t my = 0;
+            for (int k0 = gl; k0 < kmax; k0 += 4 * gs)
+            {
+                // four swaps per trip with batched loads so the LDS latencies overlap
+                int sl[4], sr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                {
+                    const int k = k0 + q * gs;
+                    const bool in = k < kmax;
+                    sl[q] = in ? (int)v.lp[first + k - v.off] : 0;
+                    sr[q] = in ? (int)v.ra[first + cntR - 1 - k - v.off] : -1;
+                }
+                Node nl[4], nr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (sl[q] < sr[q])
+                    {
+                        nl[q] = nget(v, sl[q]);
+                        nr[q] = nget(v, sr[q]);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (sl[q] < sr[q])
+                    {
+                        nset(v, sl[q], nr[q]);
+                        nset(v, sr[q], nl[q]);
+                        ++my;
+                    }
+            }
+            uint32_t e2, ktot;
+            group_scan_packed(my, gs, tid, cs, blockmode, e2, ktot);
+            if (part)
+            {
+                const int K = (int)ktot;
+                const int c1 = (K < cntL) ? (int)v.lp[first + K - v.off] : INT_MAX;
+                const int c2 = (K > 0) ? (int)v.ra[first + cntR - K - v.off] : INT_MAX;
+                const int cut = min(c1, c2);
                 if (cut <= nth)
                     first = cut;
                 else
                     last = cut;
             }
-            if (!done && lane == 0)
-                seq_insertion_sort(v, first, last, axis);
-            Coop<WAVE>::sync();
+        }
+        if (!done && gl == 0)
+            seq_insertion_sort(v, first, last, axis);
+        __syncthreads();
+        if (dbg && tid == 0 && blockIdx.x == 0 && s < 12)
+        {
+            dbg[2 * s] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+            dbg[2 * s + 1] = n_rounds;
         }
     }
-    // leaf phase: lane j finishes sub-range j of sub-level s on its own
-    for (uint32_t j = lane; j < (1u << s); j += WAVE)
+    // leaf phase: one lane per remaining subtree
+    for (uint32_t j = tid; j < (1u << s); j += LG)
     {
         int rb = b, re = e;
         descend(rb, re, j, s);
         if (re - rb >= 2)
-            seq_build_subtree(v, rb, re, level + s);
+            seq_build_subtree(v, rb, re, lv + s);
     }
-    Coop<WAVE>::sync();
-    if (staged)
-        for (int i = lane; i < n; i += WAVE)
-            nodes[b + i] = l_nodes[w][i];
+    __syncthreads();
+    if (dbg && tid == 0 && blockIdx.x == 0)
+    {
+        dbg[30] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+        dbg[31] = (uint32_t)n;
+    }
+    for (int i = tid; i < n; i += LG)
+        nodes[b + i] = l_nodes[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1277,21 +1418,22 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     {
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)blk_lds));
+        LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)blk_lds));
         attr_set = true;
     }
-    // sizes at level d are within one of m_max / 2^d
+    // global-memory levels while a range can exceed the LDS capacity, then the whole rest in one launch
     int level = 0;
     uint32_t size = m_max;
-    while (size > (uint32_t)SUB_CAP)
+    while (size > (uint32_t)BLK_CAP)
     {
         hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level), dim3(BLK_G), blk_lds, ctx->stream, nodes, lpos, rasc,
                            frame, level);
-        size = size / 2;  // larger child holds (size)/2 nodes at most: (n-1) - (n-1)/2 <= n/2
+        size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
-    const uint32_t ranges = 1u << level;
-    hipLaunchKernelGGL(kd_subtree_kernel, dim3((ranges + SUB_WAVES - 1) / SUB_WAVES), dim3(SUB_WAVES * WAVE), 0,
-                       ctx->stream, nodes, lpos, rasc, frame, level);
+    hipLaunchKernelGGL(kd_lds_kernel, dim3(1u << level), dim3(LG), blk_lds, ctx->stream, nodes, frame,
+                       (uint32_t *)ctx->dbg_buf);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
