@@ -18,6 +18,8 @@
 // Labels: dense 0..L-1 in seed order (:120-123) = exclusive scan over the valid-seed flags.
 #include "lpx_internal.h"
 
+#include <math.h>
+
 namespace
 {
 enum : uint8_t
@@ -72,7 +74,8 @@ __global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, FrameState 
 
 struct ReplayParams
 {
-    double thr;  // (1-q)^2 * d^2 in double, src/clustering.cpp:66-67
+    double thr;   // (1-q)^2 * d^2 in double, src/clustering.cpp:66-67
+    float thr_f;  // largest float <= thr: for a float d, (double)d <= thr  <=>  d <= thr_f
     uint32_t min_size, max_size;
 };
 
@@ -249,9 +252,16 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
         {
             q[0] = seed;
             ST_OR(seed, 1u);
+            seed_of[seed] = (int32_t)seed;  // queued before it is ever touched
         }
         uint32_t wb = 0, wn = 0;  // queue window [wb, wb + wn) held in registers
         uint32_t wcand = 0, woff = 0, wlen = 0;
+        // first four list chunks of the NEXT unremoved window candidate, loaded while the current one is
+        // processed (it is the next expansion unless the current one absorbs it)
+        bool pf_valid = false;
+        uint32_t pf_q = 0;
+        uint32_t pk[4] = {0, 0, 0, 0};
+        float pd[4] = {0, 0, 0, 0};
         while (qh < qt)
         {
             if (qh >= wb + wn)
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                 wcand = in ? q[wb + lane] : 0u;
                 woff = in ? nb_off[wcand] : 0u;
                 wlen = in ? nb_len[wcand] : 0u;
+                pf_valid = false;
             }
             const bool ok = (lane < wn) && (wb + lane >= qh) && !(ST_GET(wcand) & 2u);
             const unsigned long long m = __ballot(ok);
@@ -274,17 +285,58 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
             const int f = __ffsll((long long)m) - 1;
             const uint32_t o0 = __shfl(woff, f, 64), cnt = __shfl(wlen, f, 64);
             qh = wb + f + 1;
-            for (uint32_t base = 0; base < cnt; base += 4 * WAVE)
+            uint32_t kk[4];
+            float dd[4];
+            if (pf_valid && pf_q == wb + (uint32_t)f)
             {
-                uint32_t kk[4];
-                float dd[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                 {
-                    const uint32_t t = base + c * WAVE + lane;
+                    kk[c] = pk[c];
+                    dd[c] = pd[c];
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    const uint32_t t = c * WAVE + lane;
                     const bool in = t < cnt;
                     kk[c] = in ? nb_idx[o0 + t] : 0xffffffffu;
                     dd[c] = in ? nb_dist[o0 + t] : 0.0f;
+                }
+            }
+            {
+                const unsigned long long m2 = (f == 63) ? 0ull : (m & ~((2ull << f) - 1ull));
+                pf_valid = m2 != 0;
+                if (pf_valid)
+                {
+                    const int f2 = __ffsll((long long)m2) - 1;
+                    pf_q = wb + (uint32_t)f2;
+                    const uint32_t o2 = __shfl(woff, f2, 64), c2 = __shfl(wlen, f2, 64);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                    {
+                        const uint32_t t = c * WAVE + lane;
+                        const bool in = t < c2;
+                        pk[c] = in ? nb_idx[o2 + t] : 0xffffffffu;
+                        pd[c] = in ? nb_dist[o2 + t] : 0.0f;
+                    }
+                }
+            }
+            for (uint32_t base = 0; base < cnt; base += 4 * WAVE)
+            {
+                if (base)
+                {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                    {
+                        const uint32_t t = base + c * WAVE + lane;
+                        const bool in = t < cnt;
+                        kk[c] = in ? nb_idx[o0 + t] : 0xffffffffu;
+                        dd[c] = in ? nb_dist[o0 + t] : 0.0f;
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -296,11 +348,11 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                     const uint32_t sk = in ? ST_GET(k) : 2u;
                     const bool vis = in && !(sk & 2u);
                     touches += __popcll(__ballot(vis));
-                    const bool absorb = vis && ((double)dd[c] <= prm.thr);
+                    const bool absorb = vis && (dd[c] <= prm.thr_f);
                     const bool push = vis && !absorb && sk == 0u;
                     const unsigned long long pm = __ballot(push);
-                    if (vis)
-                        seed_of[k] = (int32_t)seed;
+                    if (vis && sk == 0u)
+                        seed_of[k] = (int32_t)seed;  // first touch; later touches in this BFS carry the same seed
                     if (absorb)
                         ST_OR(k, 2u);
                     if (push)
@@ -384,6 +436,9 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         ReplayParams prm;
         const double one_minus_q = 1.0 - (double)cfg->cluster_quality;
         prm.thr = (one_minus_q * one_minus_q) * (double)cfg->distance_squared;  // std::pow(x, 2) == x*x exactly
+        prm.thr_f = (float)prm.thr;
+        if ((double)prm.thr_f > prm.thr)
+            prm.thr_f = nextafterf(prm.thr_f, -INFINITY);
         prm.min_size = cfg->min_cluster_size;
         prm.max_size = cfg->max_cluster_size;
         const size_t lds = sizeof(uint32_t) * (((size_t)m_max + 15) / 16);
