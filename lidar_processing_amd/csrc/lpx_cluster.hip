@@ -451,7 +451,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 attr_set = true;
             }
-            const uint32_t rgrid = m_max < 1024u ? m_max : 1024u;  // persistent: blocks pull components from a list
+            const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: blocks pull components from a list
             hipLaunchKernelGGL(replay_lds_kernel, dim3(rgrid), dim3(WAVE), lds, st, frame, cc_lo, cc_hi, members,
                                (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,
                                (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->nb_dist.p,

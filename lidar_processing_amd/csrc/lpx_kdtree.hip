@@ -1001,7 +1001,6 @@ __device__ uint32_t nb_traverse(const Node *__restrict__ PR, uint32_t M, uint32_
 // BLOCK = false: one wavefront per node above the bucket level (a single query each)
 // Both count, allocate (64-bit atomic bump of frame->nb_total, one block of list storage per group)
 // and fill in the same launch; off[i] / len[i] locate the list of point i.
-template <bool BLOCK>
 __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__restrict__ PR, FrameState *frame,
                                                                float r2, float rr, uint32_t *__restrict__ len,
                                                                uint32_t *__restrict__ off,
@@ -1026,18 +1025,18 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
     while ((M >> D) > (uint32_t)NB_BUCKET)
         ++D;
     const uint32_t nbk = 1u << D;
+    // blocks [0, nbk): one bucket group each; blocks [nbk, ...): four single-node groups each
+    const bool BLOCK = blockIdx.x < nbk;
     uint32_t level, path, gid;
     if (BLOCK)
     {
         gid = blockIdx.x;
-        if (gid >= nbk)
-            return;
         level = D;
         path = gid;
     }
     else
     {
-        const uint32_t u = blockIdx.x * NB_WAVES + w;
+        const uint32_t u = (blockIdx.x - nbk) * NB_WAVES + w;
         if (u >= nbk - 1)
             return;
         gid = nbk + u;
@@ -1458,15 +1457,14 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
     }
     {
         StageTimer tm(ctx, ST_NB_FILL);
+        // bucket groups (one workgroup each) and the single-node groups (four per workgroup) in ONE launch.
+        // The device derives the bucket level from the real point count, which may be lower than the
+        // host's bound; surplus blocks return at once.
         const uint32_t nbk = groups / 2;
-        hipLaunchKernelGGL((nb_group_kernel<true>), dim3(nbk), dim3(NB_THREADS), 0, ctx->stream, (const Node *)PR, frame,
-                           r2, rr, len, off, (uint32_t *)ctx->nb_idx.p, (float *)ctx->nb_dist.p, ctx->cap_nb,
+        hipLaunchKernelGGL(nb_group_kernel, dim3(nbk + (nbk + NB_WAVES - 1) / NB_WAVES), dim3(NB_THREADS), 0,
+                           ctx->stream, (const Node *)PR, frame, r2, rr, len, off, (uint32_t *)ctx->nb_idx.p,
+                           (float *)ctx->nb_dist.p, ctx->cap_nb,
                            hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf);
-        if (nbk > 1)
-            hipLaunchKernelGGL((nb_group_kernel<false>), dim3((nbk + NB_WAVES - 1) / NB_WAVES), dim3(NB_THREADS), 0,
-                               ctx->stream, (const Node *)PR, frame, r2, rr, len, off, (uint32_t *)ctx->nb_idx.p,
-                               (float *)ctx->nb_dist.p, ctx->cap_nb,
-                               hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf);
     }
     if (hook)
     {
