@@ -40,9 +40,21 @@ SEG = dict(number_of_planar_partitions=6, number_of_iterations=5)
 CLU = dict(distance_squared=0.25, cluster_quality=0.5)
 
 
-def algorithmic_bytes(stage, N, M, E, I, P):
+# stage -> kernel that dominates it (names as rocprofv3 prints them), for the PMC traffic lookup
+STAGE_KERNEL = {"ingest": "ingest_kernel", "xsort": "radix_scatter_kernel<unsigned int, true>", "gather": "gather_kernel",
+                "zsort": "radix_scatter_kernel<unsigned long, false>", "seeds": "seed_kernel",
+                "plane_passes": "plane_pass_kernel<false>", "compact": "compact_kernel", "kd_build": "kd_block_kernel",
+                "kd_preorder": "kd_preorder_kernel", "cc_hook": "cc_hook_kernel", "neighbours": "nb_group_kernel",
+                "components": "radix_scatter_kernel<unsigned int, true>", "replay": "replay_lds_kernel",
+                "labels": "relabel_kernel"}
+
+
+def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None):
     """Algorithmic HBM bytes of one launch group of `stage` for a frame with N points, M obstacle
-    points, E neighbour-list entries ("Kernels and their algorithmic bytes")."""
+    points, E neighbour-list entries, E_replay entries in the lists of the points the reference would
+    expand (DESIGN.md, "Kernels and their algorithmic bytes")."""
+    if E_replay is None:
+        E_replay = E
     return {
         "ingest": N * (16 + 12 + 8),                 # AoS read, SoA write, (key, index) write
         "xsort": 4 * N * (8 + 8 + 8),                # per pass: histogram read, scatter read + write of 8 B pairs
@@ -56,9 +68,22 @@ def algorithmic_bytes(stage, N, M, E, I, P):
         "cc_hook": E * 4 + M * (8 + 8),              # list indices read, offsets/lengths, parents
         "neighbours": M * 16 + E * 8 + M * 8,        # nodes read once, (index, distance) lists written, off/len
         "components": M * (4 + 4 + 4 + 1 + 4 + 8) + 3 * M * 24,
-        "replay": E * 8 + M * (1 + 4 + 4 + 4),
+        "replay": E_replay * 8 + M * (8 + 1 + 4 + 4 + 4),  # expanded lists, off/len, state, seed, queue, valid
         "labels": M * (4 + 4 + 4 + 4),
     }[stage]
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the stage's dominant kernel from the committed rocprofv3 --pmc summary
+    (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half of a coalesced read on
+    gfx950 (guides/MI355X_MICROARCH.md, HBM).  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")
+    try:
+        d = json.load(open(path))
+        k = next(v for name, v in d.items() if name.startswith(STAGE_KERNEL[stage][:40]))
+        return int((2 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024)
+    except Exception:
+        return None
 
 
 def frame_ids_for_rank(rank, world, frames_per_step, n_frames):
@@ -202,25 +227,18 @@ def main():
         dom = max(stage_ms, key=stage_ms.get)
         n_launch = max(1, launches[dom])
         avg_ms = stage_ms[dom] / n_launch
-        # frame-averaged sizes of this rank's batch
+        # frame-averaged sizes of this rank's batch; list sizes come from the device counters of the last
+        # frame each context processed
         Nn = np.mean([host_frames[i].shape[0] for i in my_ids])
         Mm = np.mean([int(c[1]) for c in counts])
-        # neighbour entries are not exported per frame; estimate from the oracle-free device totals is not
-        # available here, so E is measured once on the host-API path of frame 0 (documented in DESIGN.md)
-        E = 0.0
-        try:
-            probe = Context(local_rank)
-            hf = host_frames[my_ids[0]]
-            r = probe.segment(hf, scfg)
-            off, _, _ = probe.dbg_neighbours(hf[r[2]][:, :3], CLU["distance_squared"])
-            E = float(off[-1]) * Mm / max(1, len(r[2]))
-            probe.close()
-        except Exception:
-            pass
-        algo = algorithmic_bytes(dom, Nn, Mm, E, SEG["number_of_iterations"], SEG["number_of_planar_partitions"])
+        fst = [c.frame_stats() for c in ctxs]
+        E = float(np.mean([f["neighbour_entries"] for f in fst]))
+        E_replay = float(np.mean([f["replay_entries"] for f in fst]))
+        algo = algorithmic_bytes(dom, Nn, Mm, E, SEG["number_of_iterations"], SEG["number_of_planar_partitions"],
+                                 E_replay)
         achieved = algo / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom),
                     "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(algo)}
 
     # ---- CPU baseline: the oracle restatement on this host, bounded sample (rank 0, N = 1 only) ----

@@ -149,6 +149,10 @@ int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uin
                        float *dist, uint64_t capacity);
 /* connected-component root (smallest original index of the component) per point */
 int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint32_t *root);
+/* statistics of the last frame processed by this context (synchronises): out[10] =
+ * {n_ground, n_obstacle, n_clusters, status, neighbour entries lo/hi, components, expansions,
+ *  entries read by the replay lo/hi} */
+int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out10);
 /* plane from points through the device moment/Jacobi path */
 int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane);
 

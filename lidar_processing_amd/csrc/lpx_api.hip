@@ -536,6 +536,28 @@ extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride,
     return cluster_resident(ctx, fs.n_obstacle, clu_cfg, cluster_labels, n_clusters);
 }
 
+// frame statistics of the last call on this context: {n_ground, n_obstacle, n_clusters, status,
+// neighbour entries (lo, hi), components, expansions, entries read by the replay (lo, hi)}
+extern "C" int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out10)
+{
+    if (!ctx || !out10)
+        return LPX_ERR_ARG;
+    FrameState fs;
+    LPX_HIP(ctx, hipMemcpyAsync(&fs, ctx->frame.p, sizeof fs, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out10[0] = fs.n_ground;
+    out10[1] = fs.n_obstacle;
+    out10[2] = fs.n_clusters;
+    out10[3] = fs.status;
+    out10[4] = (uint32_t)fs.nb_total;
+    out10[5] = (uint32_t)(fs.nb_total >> 32);
+    out10[6] = fs.n_roots;
+    out10[7] = fs.n_expansions;
+    out10[8] = (uint32_t)fs.replay_entries;
+    out10[9] = (uint32_t)(fs.replay_entries >> 32);
+    return LPX_OK;
+}
+
 // tools only: per-group statistics of the neighbour kernel ({T, intervals, queries, hits, cycles to
 // allocation, cycles total, -, -} per group); pass n_groups = 0 to switch it off again
 extern "C" int lpx_dbg_group_stats(lpx_ctx *ctx, uint32_t n_groups, uint32_t *out)

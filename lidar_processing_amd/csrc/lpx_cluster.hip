@@ -211,6 +211,8 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
     for (uint32_t i = lane; i < words; i += WAVE)
         sbits[i] = 0;
     __builtin_amdgcn_wave_barrier();
+    unsigned long long st_entries = 0;
+    uint32_t st_exp = 0;
   for (;;)
   {
     uint32_t ticket = 0;
@@ -285,6 +287,8 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
             const int f = __ffsll((long long)m) - 1;
             const uint32_t o0 = __shfl(woff, f, 64), cnt = __shfl(wlen, f, 64);
             qh = wb + f + 1;
+            st_entries += cnt;
+            ++st_exp;
             uint32_t kk[4];
             float dd[4];
             if (pf_valid && pf_q == wb + (uint32_t)f)
@@ -368,6 +372,11 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
             valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;
     }
   }
+    if (lane == 0 && st_exp)
+    {
+        atomicAdd((unsigned long long *)&fstate->replay_entries, st_entries);
+        atomicAdd(&fstate->n_expansions, st_exp);
+    }
 #undef ST_GET
 #undef ST_OR
 }

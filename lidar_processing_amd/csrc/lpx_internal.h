@@ -41,6 +41,9 @@ struct FrameState
     uint64_t nb_total;    // total neighbour entries required
     uint32_t n_roots;     // connected components of the d-graph
     uint32_t root_cursor; // work queue head of the replay
+    uint64_t replay_entries;  // neighbour entries read by the replay (lists of expanded points)
+    uint32_t n_expansions;    // radius_search calls the reference would have made
+    uint32_t pad;
 };
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
