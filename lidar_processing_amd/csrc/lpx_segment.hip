@@ -413,41 +413,61 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
     uint32_t cnt_g = 0, cnt_o = 0;
 
-    for (uint32_t p = lo + tid; p < hi; p += SEG_THREADS)
+    // four points per thread and trip: the twelve loads are issued before any of them is used
+    for (uint32_t p0 = lo + tid; p0 < hi; p0 += 4 * SEG_THREADS)
     {
-        const float x = XS[p], y = YS[p], z = ZS[p];
-        bool member;
-        if (use_seed)
-            member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
-        else
+        float xs[4], ys[4], zs[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
         {
-            const float dist = ((x * pa + y * pb) + z * pc) - pd;
-            member = dist < thr;
+            const uint32_t p = p0 + u * SEG_THREADS;
+            in[u] = p < hi;
+            xs[u] = in[u] ? XS[p] : 0.0f;
+            ys[u] = in[u] ? YS[p] : 0.0f;
+            zs[u] = in[u] ? ZS[p] : 0.0f;
         }
-        member = member && !dead;
-        if (FINAL)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
         {
-            // number_of_iterations == 0: seeds are ground, the rest stays UNKNOWN (:243-247)
-            const uint8_t f = skip ? 0 : (member ? 1 : ((prm.I == 0 && !dead) ? 0 : 2));
-            flags[p] = f;
-            cnt_g += (f == 1);
-            cnt_o += (f == 2);
-        }
-        else if (member)
-        {
-            const int qx = __float2int_rn(x * FIX_SCALE);
-            const int qy = __float2int_rn(y * FIX_SCALE);
-            const int qz = __float2int_rn(z * FIX_SCALE);
-            a_n += 1;
-            a_x += qx;
-            a_y += qy;
-            a_z += qz;
-            a_xx += (long long)qx * qx;
-            a_xy += (long long)qx * qy;
-            a_xz += (long long)qx * qz;
-            a_yy += (long long)qy * qy;
-            a_yz += (long long)qy * qz;
-            a_zz += (long long)qz * qz;
+            const uint32_t p = p0 + u * SEG_THREADS;
+            const float x = xs[u], y = ys[u], z = zs[u];
+            bool member;
+            if (use_seed)
+                member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
+            else
+            {
+                const float dist = ((x * pa + y * pb) + z * pc) - pd;
+                member = dist < thr;
+            }
+            member = member && !dead && in[u];
+            if (FINAL)
+            {
+                if (in[u])
+                {
+                    // number_of_iterations == 0: seeds are ground, the rest stays UNKNOWN (:243-247)
+                    const uint8_t f = skip ? 0 : (member ? 1 : ((prm.I == 0 && !dead) ? 0 : 2));
+                    flags[p] = f;
+                    cnt_g += (f == 1);
+                    cnt_o += (f == 2);
+                }
+            }
+            else if (member)
+            {
+                const int qx = __float2int_rn(x * FIX_SCALE);
+                const int qy = __float2int_rn(y * FIX_SCALE);
+                const int qz = __float2int_rn(z * FIX_SCALE);
+                a_n += 1;
+                a_x += qx;
+                a_y += qy;
+                a_z += qz;
+                a_xx += (long long)qx * qx;
+                a_xy += (long long)qx * qy;
+                a_xz += (long long)qx * qz;
+                a_yy += (long long)qy * qy;
+                a_yz += (long long)qy * qz;
+                a_zz += (long long)qz * qz;
+            }
         }
     }
 
@@ -505,8 +525,11 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
             tot += red[i][tid];
         if (tot != 0)
             atomicAdd((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], (unsigned long long)tot);
+        // All cross-block traffic of this kernel is device-scope atomics (performed at the coherence
+        // point, nothing cached dirty), so ordering is all that is needed: wait until this lane's adds
+        // have been performed before the barrier that precedes the ticket.  No L2 write-back fence.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __threadfence();
     __syncthreads();
     if (tid == 0)
     {
@@ -516,7 +539,6 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     __syncthreads();
     if (!s_last)
         return;
-    __threadfence();
     // last block of the segment: solve and publish plane t, reset the accumulators.  The 16 words are
     // fetched and cleared by 16 lanes at once (a single lane would chain 32 dependent atomics).
     if (tid < LPX_ACC_WORDS)
