@@ -300,3 +300,38 @@ def test_cxx_dropin_headers_run_like_processor(ctx, tmp_path):
     wl, wn = oracle.cluster(pts[want["obstacle_idx"]])
     assert np.array_equal(clu_labels, wl)
     assert nc == wn  # every valid label owns at least one point, so no empty cluster is erased
+
+
+def test_full_size_properties_5m(ctx):
+    """BASELINE config 5 (5M points, 24 segments, d = 0.2 m): size-independent properties"""
+    pts = synthetic_scene(2_000_000, 3000, 1000, 20240602, extent=100.0)
+    scfg = SegmentationConfiguration(number_of_planar_partitions=24, number_of_iterations=3)
+    out = ctx.segment_cluster(pts, scfg, ClusteringConfiguration(0.04, 0.5))
+    n = pts.shape[0]
+    labels, gi, oi = out["labels"], out["ground_idx"], out["obstacle_idx"]
+    assert len(gi) + len(oi) + int((labels == 0).sum()) == n and (labels == 0).sum() == n % 24
+    assert (labels[gi] == 1).all() and (labels[oi] == 2).all()
+    # output order: x ascending inside the concatenation of segments (Q7)
+    assert (np.diff(pts[oi, 0]) >= 0).all() and (np.diff(pts[gi, 0]) >= 0).all()
+    # the plane of every segment separates the masks with the signed test (Q1)
+    n_per = n // 24
+    order = np.lexsort((np.arange(n), pts[:, 0]))
+    for s in (0, 11, 23):
+        seg = order[s * n_per:(s + 1) * n_per]
+        a, b, c, d = out["planes"][s]
+        dist = ((pts[seg, 0] * a + pts[seg, 1] * b) + pts[seg, 2] * c) - d
+        thr = np.float32(0.3) * np.sqrt((a * a + b * b) + c * c)
+        assert np.array_equal(dist < thr, labels[seg] == 1)
+    cl = out["cluster_labels"]
+    assert (cl >= -1).all()
+    valid = cl[cl >= 0]
+    assert np.array_equal(np.unique(valid), np.arange(out["n_clusters"]))
+    first = np.full(out["n_clusters"], cl.size, np.int64)
+    np.minimum.at(first, valid, np.nonzero(cl >= 0)[0])
+    assert (np.diff(first) > 0).all()  # dense labels in seed order
+    # a cluster never spans two connected components: members of one label are chained within d
+    big = np.bincount(valid).argmax()
+    mem = pts[oi[cl == big], :3].astype(np.float64)
+    from scipy.spatial import cKDTree
+    t = cKDTree(mem)
+    assert len(t.query_pairs(0.2001)) >= len(mem) - 1
