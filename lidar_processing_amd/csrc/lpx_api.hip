@@ -236,7 +236,7 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
                   &ctx->d_oidx, &ctx->d_planes, &ctx->d_counts, &ctx->OX,     &ctx->OY,      &ctx->OZ,     &ctx->nodes, &ctx->nodes_pre,
                   &ctx->lpos,   &ctx->rpos,     &ctx->nb_len,   &ctx->nb_off, &ctx->nb_idx,  &ctx->nb_dist, &ctx->parent,
                   &ctx->cc_lo,  &ctx->cc_hi,    &ctx->state,    &ctx->seed_of, &ctx->queue,  &ctx->valid,  &ctx->d_clabels,
-                  &ctx->frame};
+                  &ctx->frame, &ctx->dbg_store};
     for (Buf *b : all)
         if (b->p)
             hipFree(b->p);
@@ -564,7 +564,7 @@ extern "C" int lpx_dbg_group_stats(lpx_ctx *ctx, uint32_t n_groups, uint32_t *ou
 {
     if (!ctx)
         return LPX_ERR_ARG;
-    static Buf buf;
+    Buf &buf = ctx->dbg_store;
     if (out && ctx->dbg_buf)
     {
         LPX_HIP(ctx, hipMemcpy(out, ctx->dbg_buf, 32 * (size_t)n_groups, hipMemcpyDeviceToHost));

@@ -285,7 +285,8 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                 continue;
             }
             const int f = __ffsll((long long)m) - 1;
-            const uint32_t o0 = __shfl(woff, f, 64), cnt = __shfl(wlen, f, 64);
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)woff, f);
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)wlen, f);
             qh = wb + f + 1;
             st_entries += cnt;
             ++st_exp;
@@ -318,7 +319,8 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                 {
                     const int f2 = __ffsll((long long)m2) - 1;
                     pf_q = wb + (uint32_t)f2;
-                    const uint32_t o2 = __shfl(woff, f2, 64), c2 = __shfl(wlen, f2, 64);
+                    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)woff, f2);
+                    const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)wlen, f2);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                     {
@@ -453,12 +455,11 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         const size_t lds = sizeof(uint32_t) * (((size_t)m_max + 15) / 16);
         if (lds <= 96 * 1024)
         {
-            static bool attr_set = false;
-            if (!attr_set)
+            if (!ctx->attr_replay)
             {
                 LPX_HIP(ctx, hipFuncSetAttribute((const void *)replay_lds_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                attr_set = true;
+                ctx->attr_replay = true;
             }
             const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: blocks pull components from a list
             hipLaunchKernelGGL(replay_lds_kernel, dim3(rgrid), dim3(WAVE), lds, st, frame, cc_lo, cc_hi, members,

@@ -110,6 +110,8 @@ struct lpx_ctx
     size_t h_pinned_bytes = 0;
 
     void *dbg_buf = nullptr;   // optional per-group statistics of the neighbour kernel (tools only)
+    Buf dbg_store;
+    bool attr_kd = false, attr_replay = false;  // hipFuncSetAttribute done for this context's device
 
     // profiling
     bool profiling = false;

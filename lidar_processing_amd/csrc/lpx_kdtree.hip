@@ -383,29 +383,37 @@ __device__ int coop_partition_pivot(const View &v, int first, int last, int axis
     for (int base = first + 1; base < last; base += G * PE)
     {
         const int p0 = base + tid * PE;
-        bool ge[PE], le[PE];
-        uint32_t packed = 0;
-#pragma unroll
-        for (int e = 0; e < PE; ++e)
+        uint32_t gem = 0, lem = 0;
+        if (p0 < last)
         {
-            const int p = p0 + e;
-            const bool valid = p < last;
-            const float k = valid ? nkey(v, p, axis) : 0.0f;
-            ge[e] = valid && !(k < pv);  // left cursor stops here
-            le[e] = valid && !(pv < k);  // right cursor stops here
-            packed += (ge[e] ? 1u : 0u) + (le[e] ? 0x10000u : 0u);
+            float kk[PE];
+#pragma unroll
+            for (int e = 0; e < PE; ++e)
+                kk[e] = (p0 + e < last) ? nkey(v, p0 + e, axis) : pv;
+#pragma unroll
+            for (int e = 0; e < PE; ++e)
+            {
+                const bool valid = p0 + e < last;
+                gem |= ((valid && !(kk[e] < pv)) ? 1u : 0u) << e;  // left cursor stops here
+                lem |= ((valid && !(pv < kk[e])) ? 1u : 0u) << e;  // right cursor stops here
+            }
         }
+        const uint32_t packed = (uint32_t)__popc(gem) + ((uint32_t)__popc(lem) << 16);
         uint32_t excl, total;
         Coop<G>::scan_packed(packed, excl, total, cs);
         int rL = first + cntL + (int)(excl & 0xffffu) - v.off;
         int rR = first + cntR + (int)(excl >> 16) - v.off;
-#pragma unroll
-        for (int e = 0; e < PE; ++e)
+        while (gem)
         {
-            if (ge[e])
-                v.lp[rL++] = (uint32_t)(p0 + e);
-            if (le[e])
-                v.ra[rR++] = (uint32_t)(p0 + e);
+            const int e = __ffs(gem) - 1;
+            gem &= gem - 1;
+            v.lp[rL++] = (uint32_t)(p0 + e);
+        }
+        while (lem)
+        {
+            const int e = __ffs(lem) - 1;
+            lem &= lem - 1;
+            v.ra[rR++] = (uint32_t)(p0 + e);
         }
         cntL += (int)(total & 0xffffu);
         cntR += (int)(total >> 16);
@@ -413,15 +421,34 @@ __device__ int coop_partition_pivot(const View &v, int first, int last, int axis
     Coop<G>::sync();
     const int kmax = min(cntL, cntR);
     uint32_t my = 0;
-    for (int k = tid; k < kmax; k += G)
+    for (int k0 = tid; k0 < kmax; k0 += 4 * G)
     {
-        const int l = (int)v.lp[first + k - v.off];
-        const int r = (int)v.ra[first + cntR - 1 - k - v.off];
-        if (l < r)
+        // four swaps per trip with batched loads so the memory latencies overlap
+        int sl[4], sr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
         {
-            nswap(v, l, r);
-            ++my;
+            const int k = k0 + q * G;
+            const bool in = k < kmax;
+            sl[q] = in ? (int)v.lp[first + k - v.off] : 0;
+            sr[q] = in ? (int)v.ra[first + cntR - 1 - k - v.off] : -1;
         }
+        Node nl[4], nr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (sl[q] < sr[q])
+            {
+                nl[q] = nget(v, sl[q]);
+                nr[q] = nget(v, sr[q]);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (sl[q] < sr[q])
+            {
+                nset(v, sl[q], nr[q]);
+                nset(v, sr[q], nl[q]);
+                ++my;
+            }
     }
     const int K = (int)Coop<G>::sum(my, cs);
     const int c1 = (K < cntL) ? (int)v.lp[first + K - v.off] : INT_MAX;
@@ -1412,14 +1439,13 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     hipLaunchKernelGGL(kd_init_kernel, dim3((m_max + 255) / 256), dim3(256), 0, ctx->stream, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, frame, nodes, (uint32_t *)ctx->parent.p);
     const size_t blk_lds = sizeof(Node) * BLK_CAP + 2 * sizeof(uint32_t) * BLK_CAP + 64 * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set)
+    if (!ctx->attr_kd)
     {
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)blk_lds));
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)blk_lds));
-        attr_set = true;
+        ctx->attr_kd = true;
     }
     // global-memory levels while a range can exceed the LDS capacity, then the whole rest in one launch
     int level = 0;

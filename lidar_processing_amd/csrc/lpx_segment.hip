@@ -95,7 +95,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
                                                             SegState *__restrict__ st, long long *__restrict__ acc,
                                                             uint32_t *__restrict__ ticket)
 {
-    __shared__ float zbuf[SEED_LDS];
+    __shared__ __attribute__((aligned(16))) float zbuf[SEED_LDS];
     __shared__ float s_sum;
     __shared__ uint32_t s_cut;
     const uint32_t s = blockIdx.x;
@@ -137,8 +137,32 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
         __syncthreads();
         if (tid == 0)
         {
+            // strictly sequential adds (bit-exact with the reference's loop); the LDS reads are hoisted
+            // sixteen at a time so that only the 4-cycle add chain is serial
             float sum = s_sum;
-            for (uint32_t i = 0; i < cnt; ++i)
+            uint32_t i = 0;
+            for (; i + 16 <= cnt; i += 16)
+            {
+                const float4 a = *(const float4 *)&zbuf[i], b = *(const float4 *)&zbuf[i + 4];
+                const float4 c = *(const float4 *)&zbuf[i + 8], d = *(const float4 *)&zbuf[i + 12];
+                sum += a.x;
+                sum += a.y;
+                sum += a.z;
+                sum += a.w;
+                sum += b.x;
+                sum += b.y;
+                sum += b.z;
+                sum += b.w;
+                sum += c.x;
+                sum += c.y;
+                sum += c.z;
+                sum += c.w;
+                sum += d.x;
+                sum += d.y;
+                sum += d.z;
+                sum += d.w;
+            }
+            for (; i < cnt; ++i)
                 sum += zbuf[i];
             s_sum = sum;
         }
