@@ -210,6 +210,7 @@ static int create_common(int device, hipStream_t stream, bool own, lpx_ctx **out
         return rc;
     }
     hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream);
+    hipMemsetAsync(ctx->hist.p, 0, 64, ctx->stream);
     *out = ctx;
     return LPX_OK;
 }

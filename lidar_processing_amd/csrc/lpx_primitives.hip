@@ -17,25 +17,104 @@ constexpr int SORT_ITEMS = 8;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 constexpr int RADIX = 256;
 
+// Histogram of one digit per tile.  With `ticket` set, the last block to finish also turns the whole
+// [256][nblocks] table into exclusive offsets (thread d owns the contiguous row of digit d), which
+// saves the separate single-block scan launch of every pass for frame-sized inputs.
 template <typename KeyT>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__restrict__ keys, uint32_t n_max,
                                                                    const uint32_t *__restrict__ d_n, uint32_t shift,
-                                                                   uint32_t *__restrict__ hist, uint32_t nblocks)
+                                                                   uint32_t *hist, uint32_t nblocks, uint32_t *ticket)
 {
     __shared__ uint32_t h[RADIX];
+    __shared__ uint32_t s_last;
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
-    h[threadIdx.x] = 0;
+    const uint32_t tid = threadIdx.x;
+    h[tid] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * SORT_TILE;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r)
     {
-        const uint32_t e = base + r * SORT_THREADS + threadIdx.x;
+        const uint32_t e = base + r * SORT_THREADS + tid;
         if (e < n)
             atomicAdd(&h[(uint32_t)(keys[e] >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (!ticket)
+    {
+        hist[tid * nblocks + blockIdx.x] = h[tid];
+        return;
+    }
+    // hand-off without L2 write-back / invalidate fences: the column is stored write-through (agent-scope
+    // atomic store), drained, and the last block reads every column with agent-scope atomic loads
+    __hip_atomic_store(&hist[tid * nblocks + blockIdx.x], h[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last)
+        return;
+    // in-place exclusive scan of the flat [256 * nblocks] table: 4 groups x 256 threads x 4 entries per trip,
+    // coalesced, one barrier per trip
+    {
+        const uint32_t total_n = RADIX * nblocks;
+        const uint32_t lane = tid % WAVE, w = tid / WAVE;
+        uint32_t carry = 0, it = 0;
+        for (uint32_t base0 = 0; base0 < total_n; base0 += 4 * SORT_THREADS * 4, ++it)
+        {
+            uint32_t a[4][4], tsum[4], incl[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+            {
+                const uint32_t e = base0 + g * (SORT_THREADS * 4) + tid * 4;
+                tsum[g] = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                {
+                    a[g][i] = (e + i < total_n)
+                                  ? __hip_atomic_load(&hist[e + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                  : 0u;
+                    tsum[g] += a[g][i];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+            {
+                incl[g] = lpx_wave_incl_scan_u32(tsum[g]);
+                if (lane == WAVE - 1)
+                    h[(it & 1) * 16 + g * SORT_WAVES + w] = incl[g];  // h[] is free again: reuse as scratch
+            }
+            __syncthreads();
+            uint32_t gbase = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+            {
+                uint32_t wbase = 0, tot = 0;
+#pragma unroll
+                for (int i = 0; i < SORT_WAVES; ++i)
+                {
+                    const uint32_t sv = h[(it & 1) * 16 + g * SORT_WAVES + i];
+                    if (i < (int)w)
+                        wbase += sv;
+                    tot += sv;
+                }
+                const uint32_t e = base0 + g * (SORT_THREADS * 4) + tid * 4;
+                uint32_t run = carry + gbase + wbase + (incl[g] - tsum[g]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                {
+                    if (e + i < total_n)
+                        hist[e + i] = run;
+                    run += a[g][i];
+                }
+                gbase += tot;
+            }
+            carry += gbase;
+        }
+    }
+    if (tid == 0)
+        *ticket = 0;  // self-resetting for the next pass
 }
 
 template <typename KeyT, bool HAS_VALS>
@@ -199,9 +278,19 @@ static inline uint32_t sort_blocks(uint32_t n)
     return n == 0 ? 1u : (n + SORT_TILE - 1) / SORT_TILE;
 }
 
+constexpr uint32_t FUSED_SCAN_MAX_BLOCKS = 128;
+
+// hist buffer: bytes [0,8) scan-total scratch, [32,36) the ticket of the fused scan, [64,...) the table
 static int ensure_hist(lpx_ctx *ctx, uint32_t nblocks)
 {
-    return lpx_ensure(ctx, ctx->hist, (size_t)RADIX * nblocks * sizeof(uint32_t) + 64);
+    const size_t need = 64 + (size_t)RADIX * nblocks * sizeof(uint32_t) + 64;
+    if (ctx->hist.bytes >= need && ctx->hist.p)
+        return LPX_OK;
+    int rc = lpx_ensure(ctx, ctx->hist, need);
+    if (rc)
+        return rc;
+    LPX_HIP(ctx, hipMemsetAsync(ctx->hist.p, 0, 64, ctx->stream));  // the ticket starts at zero
+    return LPX_OK;
 }
 
 int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n,
@@ -219,14 +308,16 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     int rc = ensure_hist(ctx, nblocks);
     if (rc)
         return rc;
-    uint32_t *hist = (uint32_t *)ctx->hist.p;
+    uint32_t *hist = (uint32_t *)((char *)ctx->hist.p + 64);
+    uint32_t *ticket = (nblocks <= FUSED_SCAN_MAX_BLOCKS) ? (uint32_t *)((char *)ctx->hist.p + 32) : nullptr;
     uint32_t *ka = keys_a, *kb = keys_b, *va = vals_a, *vb = vals_b;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
         hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
-                           d_n, shift, hist, nblocks);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist, RADIX * nblocks,
-                           (const uint32_t *)nullptr, (uint64_t *)nullptr);
+                           d_n, shift, hist, nblocks, ticket);
+        if (!ticket)
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist, RADIX * nblocks,
+                               (const uint32_t *)nullptr, (uint64_t *)nullptr);
         hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream,
                            ka, kb, va, vb, n, d_n, shift, hist, nblocks);
         uint32_t *t = ka;
@@ -248,14 +339,16 @@ int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n
     int rc = ensure_hist(ctx, nblocks);
     if (rc)
         return rc;
-    uint32_t *hist = (uint32_t *)ctx->hist.p;
+    uint32_t *hist = (uint32_t *)((char *)ctx->hist.p + 64);
+    uint32_t *ticket = (nblocks <= FUSED_SCAN_MAX_BLOCKS) ? (uint32_t *)((char *)ctx->hist.p + 32) : nullptr;
     uint64_t *ka = keys_a, *kb = keys_b;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
         hipLaunchKernelGGL((radix_hist_kernel<uint64_t>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
-                           (const uint32_t *)nullptr, shift, hist, nblocks);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist, RADIX * nblocks,
-                           (const uint32_t *)nullptr, (uint64_t *)nullptr);
+                           (const uint32_t *)nullptr, shift, hist, nblocks, ticket);
+        if (!ticket)
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist, RADIX * nblocks,
+                               (const uint32_t *)nullptr, (uint64_t *)nullptr);
         hipLaunchKernelGGL((radix_scatter_kernel<uint64_t, false>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream,
                            ka, kb, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, (const uint32_t *)nullptr, shift,
                            hist, nblocks);
