@@ -76,10 +76,13 @@ struct ReplayParams
 {
     double thr;   // (1-q)^2 * d^2 in double, src/clustering.cpp:66-67
     float thr_f;  // largest float <= thr: for a float d, (double)d <= thr  <=>  d <= thr_f
+    float r2;     // distance_squared (list membership)
     uint32_t min_size, max_size;
 };
 
 constexpr int RP_WAVES = 4;
+constexpr int RP_DEPTH = 4;    // neighbour lists kept in flight ahead of the expansion being processed
+constexpr int RP_RING = 4096;  // queue entries mirrored in LDS by replay_lds_kernel
 
 // one wavefront per component (root r == smallest member == first seed)
 __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState *__restrict__ frame,
@@ -192,10 +195,13 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                                                            const uint32_t *__restrict__ nb_off,
                                                            const uint32_t *__restrict__ nb_len,
                                                            const uint32_t *__restrict__ nb_idx,
-                                                           const float *__restrict__ nb_dist, int32_t *seed_of,
+                                                           const float *__restrict__ nb_dist,
+                                                           const float *__restrict__ OX, const float *__restrict__ OY,
+                                                           const float *__restrict__ OZ, int32_t *seed_of,
                                                            uint32_t *queue, uint32_t *valid, ReplayParams prm,
                                                            uint64_t cap, FrameState *fstate,
-                                                           const uint32_t *__restrict__ roots)
+                                                           const uint32_t *__restrict__ roots,
+                                                           uint32_t *__restrict__ dbg)
 {
     extern __shared__ uint32_t sbits[];
     const uint32_t lane = threadIdx.x;
@@ -210,6 +216,9 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
     const uint32_t words = (M + 15) / 16;
     for (uint32_t i = lane; i < words; i += WAVE)
         sbits[i] = 0;
+    // the most recent RP_RING queue entries are mirrored in LDS: a window of pops is then read without
+    // waiting for the global queue stores (the global queue remains the fallback for long queues)
+    uint32_t *ring = sbits + ((words + 3) & ~3u);
     __builtin_amdgcn_wave_barrier();
     unsigned long long st_entries = 0;
     uint32_t st_exp = 0;
@@ -223,6 +232,10 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
         break;
     const uint32_t r = roots[ticket];
     const uint32_t lo = cc_lo[r], hi = cc_hi[r];
+    const unsigned long long cc_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long cc_e0 = st_entries;
+    const uint32_t cc_x0 = st_exp;
+    uint32_t cc_windows = 0, cc_seeds = 0;
 #define ST_GET(k) ((sbits[(k) >> 4] >> (((k) & 15u) * 2u)) & 3u)
 #define ST_OR(k, v) atomicOr(&sbits[(k) >> 4], (uint32_t)(v) << (((k) & 15u) * 2u))
     const unsigned long long lt = lpx_lanemask_lt();
@@ -253,125 +266,168 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
         if (lane == 0)
         {
             q[0] = seed;
+            ring[0] = seed;
             ST_OR(seed, 1u);
             seed_of[seed] = (int32_t)seed;  // queued before it is ever touched
         }
-        uint32_t wb = 0, wn = 0;  // queue window [wb, wb + wn) held in registers
-        uint32_t wcand = 0, woff = 0, wlen = 0;
-        // first four list chunks of the NEXT unremoved window candidate, loaded while the current one is
-        // processed (it is the next expansion unless the current one absorbs it)
-        bool pf_valid = false;
-        uint32_t pf_q = 0;
-        uint32_t pk[4] = {0, 0, 0, 0};
-        float pd[4] = {0, 0, 0, 0};
+        // The queue is consumed in windows of up to 64 pops.  Which of a window's candidates the reference
+        // expands is decided inside the window: candidate c is skipped iff it is already removed, or an
+        // EXPANDED earlier candidate h of the window holds it within the absorb radius (c is then in h's
+        // list with dist <= thr and gets removed before its turn).  That is a greedy pass over at most 64
+        // points in registers, after which the exact sequence of expansions of the window is known and
+        // the next list is always in flight while the current one is processed.
         while (qh < qt)
         {
-            if (qh >= wb + wn)
-            {
-                __threadfence_block();  // queue entries pushed by other lanes
-                wb = qh;
-                wn = min((uint32_t)WAVE, qt - qh);
-                const bool in = lane < wn;
-                wcand = in ? q[wb + lane] : 0u;
-                woff = in ? nb_off[wcand] : 0u;
-                wlen = in ? nb_len[wcand] : 0u;
-                pf_valid = false;
-            }
-            const bool ok = (lane < wn) && (wb + lane >= qh) && !(ST_GET(wcand) & 2u);
-            const unsigned long long m = __ballot(ok);
-            if (!m)
-            {
-                qh = wb + wn;
-                continue;
-            }
-            const int f = __ffsll((long long)m) - 1;
-            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)woff, f);
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)wlen, f);
-            qh = wb + f + 1;
-            st_entries += cnt;
-            ++st_exp;
-            uint32_t kk[4];
-            float dd[4];
-            if (pf_valid && pf_q == wb + (uint32_t)f)
-            {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                {
-                    kk[c] = pk[c];
-                    dd[c] = pd[c];
-                }
-            }
+            const uint32_t wb = qh;
+            const uint32_t wn = min((uint32_t)WAVE, qt - qh);
+            const bool inw = lane < wn;
+            uint32_t wcand;
+            if (qt - qh <= (uint32_t)RP_RING)
+                wcand = inw ? ring[(wb + lane) % RP_RING] : 0u;  // LDS: in order with the pushes of this wave
             else
             {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                {
-                    const uint32_t t = c * WAVE + lane;
-                    const bool in = t < cnt;
-                    kk[c] = in ? nb_idx[o0 + t] : 0xffffffffu;
-                    dd[c] = in ? nb_dist[o0 + t] : 0.0f;
-                }
+                __threadfence_block();  // queue entries pushed by other lanes
+                wcand = inw ? q[wb + lane] : 0u;
             }
+            const bool alive = inw && !(ST_GET(wcand) & 2u);
+            const uint32_t woff = alive ? nb_off[wcand] : 0u;
+            const uint32_t wlen = alive ? nb_len[wcand] : 0u;
+            const float wx = alive ? OX[wcand] : 0.0f, wy = alive ? OY[wcand] : 0.0f, wz = alive ? OZ[wcand] : 0.0f;
+            ++cc_windows;
+            unsigned long long am = __ballot(alive), em = 0;
+            while (am)
             {
-                const unsigned long long m2 = (f == 63) ? 0ull : (m & ~((2ull << f) - 1ull));
-                pf_valid = m2 != 0;
-                if (pf_valid)
+                const int h = __ffsll((long long)am) - 1;
+                em |= 1ull << h;
+                const float hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), h));
+                const float hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), h));
+                const float hz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), h));
+                const float d0 = hx - wx, d1 = hy - wy, d2 = hz - wz;
+                const float dist = d0 * d0 + (d1 * d1 + (d2 * d2 + 0.0f));  // dist_sqr(points_[h], node)
+                const bool conflict = alive && dist <= prm.r2 && dist <= prm.thr_f;
+                am &= ~__ballot(conflict);
+                am &= ~(1ull << h);
+            }
+            qh = wb + wn;
+            if (!em)
+                continue;
+            // software pipeline, RP_DEPTH lists in flight: slot s holds the first four chunks of the
+            // expansion that will be processed RP_DEPTH steps after the one that last used the slot
+            uint32_t K4[RP_DEPTH][4];
+            float D4[RP_DEPTH][4];
+            unsigned long long lm = em;  // expansions whose list still has to be requested
+#pragma unroll
+            for (int sl = 0; sl < RP_DEPTH; ++sl)
+            {
+                if (lm)
                 {
-                    const int f2 = __ffsll((long long)m2) - 1;
-                    pf_q = wb + (uint32_t)f2;
-                    const uint32_t o2 = (uint32_t)__builtin_amdgcn_readlane((int)woff, f2);
-                    const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)wlen, f2);
+                    const int g = __ffsll((long long)lm) - 1;
+                    lm &= lm - 1;
+                    const uint32_t og = (uint32_t)__builtin_amdgcn_readlane((int)woff, g);
+                    const uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)wlen, g);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                     {
                         const uint32_t t = c * WAVE + lane;
-                        const bool in = t < c2;
-                        pk[c] = in ? nb_idx[o2 + t] : 0xffffffffu;
-                        pd[c] = in ? nb_dist[o2 + t] : 0.0f;
+                        const bool in = t < cg;
+                        K4[sl][c] = in ? nb_idx[og + t] : 0xffffffffu;
+                        D4[sl][c] = in ? nb_dist[og + t] : 0.0f;
                     }
                 }
             }
-            for (uint32_t base = 0; base < cnt; base += 4 * WAVE)
+            while (em)
             {
-                if (base)
+#pragma unroll
+                for (int sl = 0; sl < RP_DEPTH; ++sl)
                 {
+                    if (!em)
+                        break;
+                    const int f = __ffsll((long long)em) - 1;
+                    em &= em - 1;
+                    const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)woff, f);
+                    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)wlen, f);
+                    st_entries += cnt;
+                    ++st_exp;
+                    uint32_t kk[4];
+                    float dd[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                     {
-                        const uint32_t t = base + c * WAVE + lane;
-                        const bool in = t < cnt;
-                        kk[c] = in ? nb_idx[o0 + t] : 0xffffffffu;
-                        dd[c] = in ? nb_dist[o0 + t] : 0.0f;
+                        kk[c] = K4[sl][c];
+                        dd[c] = D4[sl][c];
                     }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                {
-                    if (base + c * WAVE >= cnt)
-                        break;
-                    const bool in = kk[c] != 0xffffffffu;
-                    const uint32_t k = in ? kk[c] : 0u;
-                    const uint32_t sk = in ? ST_GET(k) : 2u;
-                    const bool vis = in && !(sk & 2u);
-                    touches += __popcll(__ballot(vis));
-                    const bool absorb = vis && (dd[c] <= prm.thr_f);
-                    const bool push = vis && !absorb && sk == 0u;
-                    const unsigned long long pm = __ballot(push);
-                    if (vis && sk == 0u)
-                        seed_of[k] = (int32_t)seed;  // first touch; later touches in this BFS carry the same seed
-                    if (absorb)
-                        ST_OR(k, 2u);
-                    if (push)
+                    if (lm)
                     {
-                        q[qt + __popcll(pm & lt)] = k;
-                        ST_OR(k, 1u);
+                        // refill the slot with the list of the expansion RP_DEPTH steps ahead
+                        const int g = __ffsll((long long)lm) - 1;
+                        lm &= lm - 1;
+                        const uint32_t og = (uint32_t)__builtin_amdgcn_readlane((int)woff, g);
+                        const uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)wlen, g);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                        {
+                            const uint32_t t = c * WAVE + lane;
+                            const bool in = t < cg;
+                            K4[sl][c] = in ? nb_idx[og + t] : 0xffffffffu;
+                            D4[sl][c] = in ? nb_dist[og + t] : 0.0f;
+                        }
                     }
-                    qt += __popcll(pm);
+                    for (uint32_t base = 0; base < cnt; base += 4 * WAVE)
+                    {
+                        if (base)
+                        {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                            {
+                                const uint32_t t = base + c * WAVE + lane;
+                                const bool in = t < cnt;
+                                kk[c] = in ? nb_idx[o0 + t] : 0xffffffffu;
+                                dd[c] = in ? nb_dist[o0 + t] : 0.0f;
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                        {
+                            if (base + c * WAVE >= cnt)
+                                break;
+                            const bool in = kk[c] != 0xffffffffu;
+                            const uint32_t k = in ? kk[c] : 0u;
+                            const uint32_t sk = in ? ST_GET(k) : 2u;
+                            const bool vis = in && !(sk & 2u);
+                            touches += __popcll(__ballot(vis));
+                            const bool absorb = vis && (dd[c] <= prm.thr_f);
+                            const bool push = vis && !absorb && sk == 0u;
+                            const unsigned long long pm = __ballot(push);
+                            if (vis && sk == 0u)
+                                seed_of[k] = (int32_t)seed;  // first touch; later touches carry the same seed
+                            if (absorb)
+                                ST_OR(k, 2u);
+                            if (push)
+                            {
+                                const uint32_t qi = qt + __popcll(pm & lt);
+                                q[qi] = k;
+                                ring[qi % RP_RING] = k;
+                                ST_OR(k, 1u);
+                            }
+                            qt += __popcll(pm);
+                        }
+                    }
                 }
             }
         }
         if (lane == 0)
             valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;
+        ++cc_seeds;
+    }
+    if (dbg && lane == 0 && ticket < 4096)
+    {
+        dbg[ticket * 8 + 0] = hi - lo;
+        dbg[ticket * 8 + 1] = st_exp - cc_x0;
+        dbg[ticket * 8 + 2] = (uint32_t)(st_entries - cc_e0);
+        dbg[ticket * 8 + 3] = cc_windows;
+        dbg[ticket * 8 + 4] = cc_seeds;
+        dbg[ticket * 8 + 5] = (uint32_t)(__builtin_amdgcn_s_memtime() - cc_t0);
+        dbg[ticket * 8 + 6] = 0;
     }
   }
     if (lane == 0 && st_exp)
@@ -450,23 +506,25 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         prm.thr_f = (float)prm.thr;
         if ((double)prm.thr_f > prm.thr)
             prm.thr_f = nextafterf(prm.thr_f, -INFINITY);
+        prm.r2 = cfg->distance_squared;
         prm.min_size = cfg->min_cluster_size;
         prm.max_size = cfg->max_cluster_size;
-        const size_t lds = sizeof(uint32_t) * (((size_t)m_max + 15) / 16);
-        if (lds <= 96 * 1024)
+        const size_t lds = sizeof(uint32_t) * (((((size_t)m_max + 15) / 16 + 3) & ~(size_t)3) + RP_RING);
+        if (lds <= 112 * 1024)
         {
             if (!ctx->attr_replay)
             {
                 LPX_HIP(ctx, hipFuncSetAttribute((const void *)replay_lds_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
                 ctx->attr_replay = true;
             }
             const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: blocks pull components from a list
             hipLaunchKernelGGL(replay_lds_kernel, dim3(rgrid), dim3(WAVE), lds, st, frame, cc_lo, cc_hi, members,
                                (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,
                                (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->nb_dist.p,
+                               (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p,
                                (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb, frame,
-                               (const uint32_t *)ctx->rpos.p);
+                               (const uint32_t *)ctx->rpos.p, (uint32_t *)ctx->dbg_buf);
         }
         else
             hipLaunchKernelGGL(replay_kernel, dim3((m_max + RP_WAVES - 1) / RP_WAVES), dim3(RP_WAVES * WAVE), 0, st,
