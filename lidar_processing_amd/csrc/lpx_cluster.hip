@@ -290,9 +290,11 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                 wcand = inw ? q[wb + lane] : 0u;
             }
             const bool alive = inw && !(ST_GET(wcand) & 2u);
-            const uint32_t woff = alive ? nb_off[wcand] : 0u;
-            const uint32_t wlen = alive ? nb_len[wcand] : 0u;
-            const float wx = alive ? OX[wcand] : 0.0f, wy = alive ? OY[wcand] : 0.0f, wz = alive ? OZ[wcand] : 0.0f;
+            // unconditional loads (index 0 for idle lanes): the five gathers are issued back to back
+            const uint32_t ci = alive ? wcand : 0u;
+            const uint32_t woff = nb_off[ci];
+            const uint32_t wlen = alive ? nb_len[ci] : 0u;
+            const float wx = OX[ci], wy = OY[ci], wz = OZ[ci];
             ++cc_windows;
             unsigned long long am = __ballot(alive), em = 0;
             while (am)
