@@ -82,11 +82,51 @@ class Clusterer final
             // (src/processor.cpp:186-189).
             throw std::runtime_error(std::string("clustering failed: ") + lpx_last_error(context_->get()));
         }
+        last_size_ = static_cast<std::uint32_t>(cloud_in.size());
+        last_clusters_ = number_of_clusters;
+    }
+
+    // Optional fast path for the regrouping the reference's caller does right after cluster()
+    // (src/processor.cpp:180-200): one cloud per valid cluster, clusters in label order, points in
+    // index order, INVALID dropped.  The grouping is computed on the device from the labels of the last
+    // cluster() call; only the points are gathered here.  `cloud_in` must be the cloud just clustered.
+    template <typename PointT, typename PointOutT>
+    void regroup(const pcl::PointCloud<PointT> &cloud_in, std::vector<pcl::PointCloud<PointOutT>> &clustered_cloud)
+    {
+        clustered_cloud.clear();
+        if (last_clusters_ == 0U || cloud_in.size() != last_size_)
+        {
+            return;
+        }
+        group_offsets_.resize(last_clusters_ + 1U);
+        group_indices_.resize(last_size_);
+        std::uint32_t number_of_valid = 0U;
+        const int rc = lpx_cluster_groups(context_->get(), last_size_, last_clusters_, group_offsets_.data(),
+                                          group_indices_.data(), &number_of_valid);
+        if (rc != LPX_OK)
+        {
+            throw std::runtime_error(std::string("cluster regrouping failed: ") + lpx_last_error(context_->get()));
+        }
+        clustered_cloud.resize(last_clusters_);
+        for (std::uint32_t c = 0U; c < last_clusters_; ++c)
+        {
+            auto &cloud = clustered_cloud[c];
+            cloud.reserve(group_offsets_[c + 1U] - group_offsets_[c]);
+            for (std::uint32_t p = group_offsets_[c]; p < group_offsets_[c + 1U]; ++p)
+            {
+                const auto &point = cloud_in.points[group_indices_[p]];
+                cloud.emplace_back(point.x, point.y, point.z);
+            }
+        }
     }
 
   private:
     std::shared_ptr<detail::LpxContext> context_;
     ClusteringConfiguration configuration_;
+    std::uint32_t last_size_{0U};
+    std::uint32_t last_clusters_{0U};
+    std::vector<std::uint32_t> group_offsets_;
+    std::vector<std::uint32_t> group_indices_;
 };
 
 } // namespace lidar_processing

@@ -105,6 +105,14 @@ int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint
                         uint32_t *obstacle_idx, uint32_t *n_obstacle, float *planes, int32_t *cluster_labels,
                         uint32_t *n_clusters);
 
+/* Cluster regrouping done by the caller right after cluster() (reference src/processor.cpp:180-200):
+ * the points of every valid cluster, clusters in label order, points in ascending index order,
+ * INVALID dropped.  Works on the labels of the LAST lpx_cluster / lpx_segment_cluster call of this
+ * context (still resident on the device): offsets[n_clusters + 1], indices[n_valid] (indices into the
+ * clustered cloud), *n_valid = offsets[n_clusters]. */
+int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t *offsets, uint32_t *indices,
+                       uint32_t *n_valid);
+
 /* ---- device-resident entry points (asynchronous on the context stream) ---------------------- */
 
 /* Same as lpx_segment_cluster with every pointer a DEVICE pointer; counts[4] receives
@@ -119,6 +127,10 @@ int lpx_segment_device(lpx_ctx *ctx, const void *d_pts, size_t stride_bytes, uin
                        uint32_t *d_counts);
 int lpx_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride_bytes, uint32_t m, const lpx_clu_cfg *cfg,
                        int32_t *d_labels, uint32_t *d_counts);
+
+/* device form of lpx_cluster_groups: d_offsets needs n_clusters + 1 (at most m + 1) entries, d_indices m */
+int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets,
+                              uint32_t *d_indices);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 

@@ -163,6 +163,17 @@ class Context:
         return dict(labels=labels, ground_idx=gi[:ng.value].copy(), obstacle_idx=oi[:no.value].copy(),
                     planes=planes[:P], cluster_labels=cl[:no.value].copy(), n_clusters=nc.value)
 
+    def cluster_groups(self, m, n_clusters):
+        """offsets[n_clusters + 1], indices: the regrouping of reference src/processor.cpp:180-200 for the
+        labels of the last cluster call of this context"""
+        off = np.zeros(n_clusters + 1, np.uint32)
+        idx = np.zeros(max(m, 1), np.uint32)
+        nv = C.c_uint32(0)
+        self._L.lpx_cluster_groups.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_uint32)]
+        self.check(self._L.lpx_cluster_groups(self._h, int(m), int(n_clusters), _vp(off), _vp(idx), C.byref(nv)))
+        return off, idx[:nv.value].copy()
+
     # ---- device-resident entry point (asynchronous on the context stream) ----
     def segment_cluster_device(self, d_pts, stride_bytes, n, seg_cfg, clu_cfg, d_labels, d_ground_idx, d_obstacle_idx,
                                d_planes, d_cluster_labels, d_counts):
@@ -291,5 +302,13 @@ class Clusterer:
         a = np.asarray(cloud_in)
         if a.shape[0] == 0:
             return np.zeros(0, np.int32)
-        labels, _ = self._ctx.cluster(a, self.configuration)
+        labels, self._n_clusters = self._ctx.cluster(a, self.configuration)
+        self._m = a.shape[0]
         return labels
+
+    def grouped(self, cloud_in):
+        """The regrouping the reference's caller does right after cluster() (src/processor.cpp:180-200):
+        list of (k, 3) xyz arrays, one per valid cluster in label order, points in index order."""
+        a = np.asarray(cloud_in)
+        off, idx = self._ctx.cluster_groups(self._m, self._n_clusters)
+        return [np.ascontiguousarray(a[idx[off[c]:off[c + 1]], :3]) for c in range(self._n_clusters)]

@@ -88,7 +88,8 @@ static int ensure_for(lpx_ctx *ctx, uint32_t n)
 // profiling
 // ------------------------------------------------------------------------------------------------
 static const char *k_stage_names[ST_COUNT] = {"ingest",   "xsort",   "gather",  "zsort", "seeds",  "plane_passes", "compact",
-                                              "kd_build", "kd_preorder", "cc_hook", "neighbours", "components", "replay", "labels"};
+                                              "kd_build", "kd_preorder", "cc_hook", "neighbours", "components", "replay", "labels",
+                                              "groups"};
 
 StageTimer::StageTimer(lpx_ctx *c, int s) : ctx(c), stage(s)
 {
@@ -535,6 +536,52 @@ extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride,
     if (fs.n_obstacle == 0)
         return LPX_OK;
     return cluster_resident(ctx, fs.n_obstacle, clu_cfg, cluster_labels, n_clusters);
+}
+
+// Cluster regrouping (reference src/processor.cpp:180-200) of the labels of the LAST clustering call on
+// this context, which are still resident on the device.
+extern "C" int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t *offsets, uint32_t *indices,
+                                  uint32_t *n_valid)
+{
+    if (!ctx || !offsets)
+        return LPX_ERR_ARG;
+    if (n_valid)
+        *n_valid = 0;
+    offsets[0] = 0;
+    if (m == 0 || n_clusters == 0)
+    {
+        for (uint32_t c = 0; c <= n_clusters; ++c)
+            offsets[c] = 0;
+        return LPX_OK;
+    }
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, (uint32_t *)ctx->d_gidx.p,
+                            (uint32_t *)ctx->d_oidx.p);
+    if (rc)
+        return rc;
+    LPX_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_gidx.p, sizeof(uint32_t) * ((size_t)n_clusters + 1),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t nv = offsets[n_clusters];
+    if (nv > m)
+        return lpx_fail(ctx, LPX_ERR_INTERNAL, "group offsets out of range");
+    if (indices && nv)
+        LPX_HIP(ctx, hipMemcpy(indices, ctx->d_oidx.p, sizeof(uint32_t) * nv, hipMemcpyDeviceToHost));
+    if (n_valid)
+        *n_valid = nv;
+    return LPX_OK;
+}
+
+extern "C" int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets,
+                                         uint32_t *d_indices)
+{
+    if (!ctx || !d_labels || !d_offsets || !d_indices)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_for(ctx, m);
+    if (rc)
+        return rc;
+    return lpx_run_groups(ctx, d_labels, m, d_offsets, d_indices);
 }
 
 // frame statistics of the last call on this context: {n_ground, n_obstacle, n_clusters, status,

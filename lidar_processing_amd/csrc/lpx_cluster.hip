@@ -464,6 +464,43 @@ __global__ void set_clusters_kernel(FrameState *frame, const uint64_t *total)
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// cluster regrouping (what Processor::process does on the host at reference src/processor.cpp:180-200):
+// points of every valid cluster, clusters in label order, points in ascending index order, INVALID dropped.
+// A stable radix sort of (label, index) with INVALID mapped behind every label gives the order; the
+// cluster boundaries are where the sorted key changes.
+// ------------------------------------------------------------------------------------------------
+__global__ void group_keys_kernel(const int32_t *__restrict__ labels, uint32_t m, uint32_t *__restrict__ key,
+                                  uint32_t *__restrict__ val)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m)
+        return;
+    const int32_t l = labels[i];
+    key[i] = l < 0 ? m : (uint32_t)l;  // labels are < m; INVALID (and UNDEFINED) sort last
+    val[i] = i;
+}
+
+__global__ void group_offsets_kernel(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval, uint32_t m,
+                                     uint32_t *__restrict__ offsets, uint32_t *__restrict__ indices)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m)
+        return;
+    const uint32_t k = skey[p];
+    const uint32_t prev = p ? skey[p - 1] : 0xffffffffu;
+    if (k < m)
+    {
+        indices[p] = sval[p];
+        if (p == 0 || prev != k)
+            offsets[k] = p;
+        if (p == m - 1)
+            offsets[k + 1] = m;  // no rejected point: the last cluster ends the array
+    }
+    else if (p == 0 || prev != k)
+        offsets[p ? prev + 1 : 0] = p;  // first rejected point: end of the last valid cluster
+}
+
 static uint32_t bits_for_count(uint32_t n)  // bits to hold values 0..n-1
 {
     uint32_t b = 1;
@@ -546,6 +583,28 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         hipLaunchKernelGGL(relabel_kernel, grd, blk, 0, st, frame, (const int32_t *)ctx->seed_of.p, valid, dense,
                            d_labels, ctx->cap_nb);
     }
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+int lpx_run_groups(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets, uint32_t *d_indices)
+{
+    if (m == 0)
+    {
+        LPX_HIP(ctx, hipMemsetAsync(d_offsets, 0, sizeof(uint32_t), ctx->stream));
+        return LPX_OK;
+    }
+    StageTimer tm(ctx, ST_GROUPS);
+    const dim3 blk(256), grd((m + 255) / 256);
+    hipLaunchKernelGGL(group_keys_kernel, grd, blk, 0, ctx->stream, d_labels, m, (uint32_t *)ctx->key_a.p,
+                       (uint32_t *)ctx->val_a.p);
+    uint32_t *skey = nullptr, *sval = nullptr;
+    int rc = lpx_sort_pairs(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_b.p, (uint32_t *)ctx->val_a.p,
+                            (uint32_t *)ctx->val_b.p, m, nullptr, bits_for_count(m + 1), &skey, &sval);
+    if (rc)
+        return rc;
+    LPX_HIP(ctx, hipMemsetAsync(d_offsets, 0, sizeof(uint32_t), ctx->stream));  // no valid cluster: offsets[0] = 0
+    hipLaunchKernelGGL(group_offsets_kernel, grd, blk, 0, ctx->stream, skey, sval, m, d_offsets, d_indices);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

@@ -26,6 +26,7 @@ enum lpx_stage
     ST_CC,           // flatten roots, sort members by (root, index), component ranges
     ST_REPLAY,       // ordered FEC replay, one wavefront per component
     ST_LABELS,       // dense relabel
+    ST_GROUPS,       // cluster regrouping (CSR by label), reference src/processor.cpp:180-200
     ST_COUNT
 };
 
@@ -168,6 +169,9 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
 int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels);
 // AoS (device) -> ctx->OX/OY/OZ, sets frame->n_obstacle = m
 int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m);
+
+// CSR of the valid clusters from d_labels (m entries): d_offsets[n_clusters + 1], d_indices[n_valid]
+int lpx_run_groups(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets, uint32_t *d_indices);
 
 int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max);
 int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook);

@@ -70,6 +70,29 @@ int main(int argc, char **argv)
         }
     }
 
+    // optional device-side regrouping must equal the caller's own loop above
+    std::vector<pcl::PointCloud<pcl::PointXYZ>> regrouped;
+    clusterer_.regroup(*obstacle_cloud, regrouped);
+    if (regrouped.size() != clustered_obstacle_cloud.size())
+    {
+        throw std::runtime_error("regroup: cluster count differs");
+    }
+    for (std::size_t c = 0; c < regrouped.size(); ++c)
+    {
+        if (regrouped[c].size() != clustered_obstacle_cloud[c].size())
+        {
+            throw std::runtime_error("regroup: cluster size differs");
+        }
+        for (std::size_t p = 0; p < regrouped[c].size(); ++p)
+        {
+            if (regrouped[c][p].x != clustered_obstacle_cloud[c][p].x || regrouped[c][p].y != clustered_obstacle_cloud[c][p].y ||
+                regrouped[c][p].z != clustered_obstacle_cloud[c][p].z)
+            {
+                throw std::runtime_error("regroup: point differs");
+            }
+        }
+    }
+
     std::FILE *o = std::fopen(argv[2], "wb");
     const std::uint32_t n = static_cast<std::uint32_t>(cloud_in_.size());
     const std::uint32_t ng = static_cast<std::uint32_t>(ground_points_.size());

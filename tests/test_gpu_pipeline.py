@@ -335,3 +335,42 @@ def test_full_size_properties_5m(ctx):
     from scipy.spatial import cKDTree
     t = cKDTree(mem)
     assert len(t.query_pairs(0.2001)) >= len(mem) - 1
+
+
+def _regroup_like_processor(labels):
+    """reference src/processor.cpp:180-200 restated: clusters in label order, points in index order"""
+    groups = [[] for _ in range(int(labels.max()) + 1)] if labels.size and labels.max() >= 0 else []
+    for i, l in enumerate(labels.tolist()):
+        assert l != UNDEFINED
+        if l != INVALID:
+            groups[l].append(i)
+    return [g for g in groups if g]
+
+
+@pytest.mark.parametrize("frame,q", [("0000000000", 0.5), ("0000000153", 0.5), ("0000000077", 0.0)])
+def test_cluster_groups_like_processor(ctx, frame, q):
+    pts = load_frame(frame)
+    obs = pts[oracle.segment(pts)["obstacle_idx"]]
+    lab, nc = ctx.cluster(obs, ClusteringConfiguration(0.18, q))
+    off, idx = ctx.cluster_groups(obs.shape[0], nc)
+    want = _regroup_like_processor(oracle.cluster(obs, oracle.CluCfg(0.18, q))[0])
+    assert len(want) == nc and off[0] == 0 and off[-1] == len(idx) == int((lab >= 0).sum())
+    for c in (list(range(min(nc, 40))) + [nc - 1]):
+        assert idx[off[c]:off[c + 1]].tolist() == want[c]
+    assert np.array_equal(lab[idx], np.repeat(np.arange(nc), np.diff(off)))
+
+
+def test_cluster_groups_edge_cases(ctx):
+    one = np.zeros((3, 4), np.float32)
+    one[:, 0] = [0, 10, 20]
+    lab, nc = ctx.cluster(one, ClusteringConfiguration(0.18, 0.5, 1))  # three singleton clusters, none rejected
+    off, idx = ctx.cluster_groups(3, nc)
+    assert nc == 3 and off.tolist() == [0, 1, 2, 3] and idx.tolist() == [0, 1, 2]
+    lab, nc = ctx.cluster(one, ClusteringConfiguration(0.18, 0.5, 4))  # everything rejected
+    off, idx = ctx.cluster_groups(3, nc)
+    assert nc == 0 and off.tolist() == [0] and idx.size == 0
+    clu = Clusterer(context=ctx)
+    clu.update_configuration(ClusteringConfiguration(0.18, 0.5, 1))
+    clu.cluster(one)
+    g = clu.grouped(one)
+    assert len(g) == 3 and np.array_equal(g[1], one[1:2, :3])
