@@ -441,11 +441,13 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
 #undef ST_OR
 }
 
-__global__ void relabel_kernel(const FrameState *__restrict__ frame, const int32_t *__restrict__ seed_of,
+__global__ void relabel_kernel(FrameState *frame, const int32_t *__restrict__ seed_of,
                                const uint32_t *__restrict__ valid, const uint32_t *__restrict__ dense,
-                               int32_t *__restrict__ labels, uint64_t cap)
+                               int32_t *__restrict__ labels, uint64_t cap, const uint64_t *__restrict__ total)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0)
+        frame->n_clusters = (uint32_t)*total;  // number of valid seeds = number of clusters
     if (i >= frame->n_obstacle)
         return;
     if (frame->nb_total > cap)
@@ -457,11 +459,6 @@ __global__ void relabel_kernel(const FrameState *__restrict__ frame, const int32
     labels[i] = valid[s] ? (int32_t)dense[s] : LPX_CLUSTER_INVALID;
 }
 
-__global__ void set_clusters_kernel(FrameState *frame, const uint64_t *total)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        frame->n_clusters = (uint32_t)*total;
-}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -579,9 +576,8 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         rc = lpx_exclusive_scan(ctx, valid, dense, m_max, &frame->n_obstacle, total);
         if (rc)
             return rc;
-        hipLaunchKernelGGL(set_clusters_kernel, dim3(1), dim3(64), 0, st, frame, total);
         hipLaunchKernelGGL(relabel_kernel, grd, blk, 0, st, frame, (const int32_t *)ctx->seed_of.p, valid, dense,
-                           d_labels, ctx->cap_nb);
+                           d_labels, ctx->cap_nb, (const uint64_t *)total);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;

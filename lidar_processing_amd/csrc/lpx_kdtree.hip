@@ -475,22 +475,9 @@ __device__ __forceinline__ void descend(int &b, int &e, uint32_t r, int level)
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void kd_init_kernel(const float *__restrict__ OX, const float *__restrict__ OY,
-                               const float *__restrict__ OZ, const FrameState *__restrict__ frame,
-                               Node *__restrict__ nodes, uint32_t *__restrict__ parent)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= frame->n_obstacle)
-        return;
-    nodes[i] = make_float4(OX[i], OY[i], OZ[i], __uint_as_float(i));
-    parent[i] = i;
-}
-
 constexpr int BLK_G = 1024;
 constexpr int BLK_CAP = 4096;  // nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch
-constexpr int SUB_CAP = 512;   // nodes per wavefront subtree
 constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
-constexpr int SUB_WAVES = 4;
 
 // one workgroup per range of `level`: std::nth_element(b, mid, e) on axis level % 3
 __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
@@ -607,9 +594,32 @@ __device__ __forceinline__ void group_scan_packed(uint32_t v, int gs, int tid, u
     }
 }
 
+// pre-order rank of array position p in the implicit median-split tree over [0, M)
+__device__ __forceinline__ uint32_t kd_rank_of(uint32_t p, uint32_t M)
+{
+    uint32_t b = 0, e = M, rank = 0;
+    for (;;)
+    {
+        const uint32_t mid = b + (e - b) / 2;
+        if (p == mid)
+            return rank;
+        if (p < mid)
+        {
+            rank += 1;
+            e = mid;
+        }
+        else
+        {
+            rank += 1 + (mid - b);
+            b = mid + 1;
+        }
+    }
+}
+
 constexpr int LG = 256;  // threads of kd_lds_kernel: one wavefront per SIMD, little per-round overhead
 
-__global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, const FrameState *__restrict__ frame,
+__global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restrict__ PR,
+                                                    const FrameState *__restrict__ frame,
                                                     uint32_t *__restrict__ dbg)
 {
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -629,8 +639,28 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, const FrameStat
     int b = 0, e = M;
     descend(b, e, blockIdx.x, lv);
     const int n = e - b;
-    if (n < 2)
+    // the split nodes above this kernel's level are final already: block 0 copies them to the
+    // pre-order layout (every other node is copied by the block that owns its range)
+    if (blockIdx.x == 0)
+        for (uint32_t h = tid; h + 1 < (1u << lv); h += LG)
+        {
+            const int l = 31 - __clz(h + 1);
+            int tb = 0, te = M;
+            descend(tb, te, h + 1 - (1u << l), l);
+            if (tb < te)
+            {
+                const uint32_t mid = (uint32_t)(tb + (te - tb) / 2);
+                PR[kd_rank_of(mid, (uint32_t)M)] = nodes[mid];
+            }
+        }
+    if (n < 1)
         return;
+    if (n == 1)
+    {
+        if (tid == 0)
+            PR[kd_rank_of((uint32_t)b, (uint32_t)M)] = nodes[b];
+        return;
+    }
     for (int i = tid; i < n; i += LG)
         l_nodes[i] = nodes[b + i];
     View v;
@@ -798,7 +828,11 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, const FrameStat
         dbg[31] = (uint32_t)n;
     }
     for (int i = tid; i < n; i += LG)
-        nodes[b + i] = l_nodes[i];
+    {
+        const Node nd = l_nodes[i];
+        nodes[b + i] = nd;
+        PR[kd_rank_of((uint32_t)(b + i), (uint32_t)M)] = nd;  // pre-order rank layout for the neighbour search
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -854,33 +888,6 @@ __device__ void uf_unite(uint32_t *parent, uint32_t a, uint32_t b)
 // pre-order layout.  PR[rank] = node with pre-order rank `rank`; a subtree is a contiguous rank
 // interval [rank(root), rank(root) + size), so "emit in pre-order" becomes "emit in array order".
 // ------------------------------------------------------------------------------------------------
-__global__ void kd_preorder_kernel(const Node *__restrict__ nodes, const FrameState *__restrict__ frame,
-                                   Node *__restrict__ PR)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t M = frame->n_obstacle;
-    if (p >= M)
-        return;
-    uint32_t b = 0, e = M, rank = 0;
-    for (;;)
-    {
-        const uint32_t mid = b + (e - b) / 2;
-        if (p == mid)
-            break;
-        if (p < mid)
-        {
-            rank += 1;
-            e = mid;
-        }
-        else
-        {
-            rank += 1 + (mid - b);
-            b = mid + 1;
-        }
-    }
-    PR[rank] = nodes[p];
-}
-
 // ------------------------------------------------------------------------------------------------
 // radius-neighbour lists of every point, in the emission order of KDTree::radius_search
 // (src/kdtree.hpp:292-341: pre-order, left before right, inclusive dist <= r2).
@@ -1436,8 +1443,7 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     Node *nodes = (Node *)ctx->nodes.p;
     uint32_t *lpos = (uint32_t *)ctx->lpos.p, *rasc = (uint32_t *)ctx->rpos.p;
     StageTimer tm(ctx, ST_KD_BUILD);
-    hipLaunchKernelGGL(kd_init_kernel, dim3((m_max + 255) / 256), dim3(256), 0, ctx->stream, (const float *)ctx->OX.p,
-                       (const float *)ctx->OY.p, (const float *)ctx->OZ.p, frame, nodes, (uint32_t *)ctx->parent.p);
+    // the node array {x, y, z, index} was written by the producer of the obstacle cloud (compact / ingest)
     const size_t blk_lds = sizeof(Node) * BLK_CAP + 2 * sizeof(uint32_t) * BLK_CAP + 64 * sizeof(uint32_t);
     if (!ctx->attr_kd)
     {
@@ -1457,7 +1463,8 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
-    hipLaunchKernelGGL(kd_lds_kernel, dim3(1u << level), dim3(LG), blk_lds, ctx->stream, nodes, frame,
+    hipLaunchKernelGGL(kd_lds_kernel, dim3(1u << level), dim3(LG), blk_lds, ctx->stream, nodes,
+                       (Node *)ctx->nodes_pre.p, frame,
                        (uint32_t *)ctx->dbg_buf);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
@@ -1468,7 +1475,6 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
     if (m_max == 0)
         return LPX_OK;
     FrameState *frame = (FrameState *)ctx->frame.p;
-    const Node *nodes = (const Node *)ctx->nodes.p;
     Node *PR = (Node *)ctx->nodes_pre.p;
     uint32_t *len = (uint32_t *)ctx->nb_len.p, *off = (uint32_t *)ctx->nb_off.p;
     // conservative radius for the group traversal (superset of every query's own traversal)
@@ -1477,10 +1483,6 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
     while ((m_max >> dmax) > (uint32_t)NB_BUCKET)
         ++dmax;
     const uint32_t groups = 2u << dmax;  // 2^D bucket groups + (2^D - 1) upper nodes
-    {
-        StageTimer tm(ctx, ST_NB_COUNT);
-        hipLaunchKernelGGL(kd_preorder_kernel, dim3((m_max + 255) / 256), dim3(256), 0, ctx->stream, nodes, frame, PR);
-    }
     {
         StageTimer tm(ctx, ST_NB_FILL);
         // bucket groups (one workgroup each) and the single-node groups (four per workgroup) in ONE launch.

@@ -45,7 +45,8 @@ struct SegParams
 // ------------------------------------------------------------------------------------------------
 __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, uint32_t n, float *__restrict__ X,
                               float *__restrict__ Y, float *__restrict__ Z, uint32_t *__restrict__ key,
-                              uint32_t *__restrict__ val, FrameState *__restrict__ frame)
+                              uint32_t *__restrict__ val, FrameState *__restrict__ frame,
+                              float4 *__restrict__ nodes)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -60,6 +61,8 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, uint3
         key[i] = lpx_float_key(x);
         val[i] = i;
     }
+    if (nodes)
+        nodes[i] = make_float4(x, y, z, __uint_as_float(i));
     if (!(fabsf(x) < FIX_LIMIT) || !(fabsf(y) < FIX_LIMIT) || !(fabsf(z) < FIX_LIMIT))
         frame->status = (uint32_t)(-LPX_ERR_RANGE);
 }
@@ -516,6 +519,8 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
             const uint32_t nb = prm.P * prm.bps;
             blk_counts[s * prm.bps + b] = g;
             blk_counts[nb + s * prm.bps + b] = o;
+            if (s == 0 && b == 0)
+                blk_counts[2 * nb] = 0;  // sentinel: the exclusive scan leaves the grand total here
         }
         return;
     }
@@ -611,7 +616,8 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
                                                                uint32_t *__restrict__ labels,
                                                                uint32_t *__restrict__ gidx, uint32_t *__restrict__ oidx,
                                                                float *__restrict__ OX, float *__restrict__ OY,
-                                                               float *__restrict__ OZ, const SegState *__restrict__ st,
+                                                               float *__restrict__ OZ, float4 *__restrict__ nodes,
+                                                               const SegState *__restrict__ st,
                                                                float *__restrict__ planes, FrameState *frame)
 {
     __shared__ uint32_t wg[SEG_WAVES], wo[SEG_WAVES];
@@ -666,9 +672,11 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
             {
                 const uint32_t d = opos + __popcll(mo & lt);
                 oidx[d] = i;
-                OX[d] = XS[p];
-                OY[d] = YS[p];
-                OZ[d] = ZS[p];
+                const float ox = XS[p], oy = YS[p], oz = ZS[p];
+                OX[d] = ox;
+                OY[d] = oy;
+                OZ[d] = oz;
+                nodes[d] = make_float4(ox, oy, oz, __uint_as_float(d));  // kd-tree input, KDTree::rebuild :185-189
             }
         }
         gpos += __popcll(mg);
@@ -760,7 +768,7 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
     LPX_HIP(ctx, hipMemsetAsync(frame, 0, sizeof(FrameState), ctx->stream));
     if (n)
         hipLaunchKernelGGL(ingest_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const char *)d_pts,
-                           (size_t)12, n, XS, YS, ZS, (uint32_t *)nullptr, (uint32_t *)nullptr, frame);
+                           (size_t)12, n, XS, YS, ZS, (uint32_t *)nullptr, (uint32_t *)nullptr, frame, (float4 *)nullptr);
     hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, acc, ticket);
     hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
                        0u, sst, acc, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr);
@@ -776,7 +784,7 @@ int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_
     {
         hipLaunchKernelGGL(ingest_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (const char *)d_pts,
                            stride, m, (float *)ctx->OX.p, (float *)ctx->OY.p, (float *)ctx->OZ.p,
-                           (uint32_t *)nullptr, (uint32_t *)nullptr, frame);
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, frame, (float4 *)ctx->nodes.p);
     }
     LPX_HIP(ctx, hipMemcpyAsync(&frame->n_obstacle, &m, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     LPX_HIP(ctx, hipGetLastError());
@@ -794,7 +802,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
                         LPX_MAX_ITERATIONS);
     hipStream_t st = ctx->stream;
     LPX_HIP(ctx, hipMemsetAsync(frame, 0, sizeof(FrameState), st));
-    if (d_planes)
+    if (d_planes && n / P == 0)  // no segment gets a point: nothing else writes the planes
         LPX_HIP(ctx, hipMemsetAsync(d_planes, 0, sizeof(float) * 4 * P, st));
     if (n == 0)
         return LPX_OK;
@@ -818,7 +826,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
     {
         StageTimer tm(ctx, ST_INGEST);
         hipLaunchKernelGGL(ingest_kernel, grd, blk, 0, st, (const char *)d_pts, stride, n, X, Y, Z,
-                           (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->val_a.p, frame);
+                           (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->val_a.p, frame, (float4 *)nullptr);
     }
     uint32_t *skeys = nullptr, *sidx = nullptr;
     {
@@ -871,13 +879,12 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
     {
         StageTimer tm(ctx, ST_COMPACT);
         // one exclusive scan over [ground counts | obstacle counts | sentinel]
-        hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, blk_counts + 2 * nb, 0u, 1u);
         rc = lpx_exclusive_scan(ctx, blk_counts, blk_counts, 2 * nb + 1, nullptr, nullptr);
         if (rc)
             return rc;
         hipLaunchKernelGGL(compact_kernel, dim3(prm.bps, P), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p,
                            sidx, XS, YS, ZS, prm, blk_counts, d_labels, d_gidx, d_oidx, (float *)ctx->OX.p,
-                           (float *)ctx->OY.p, (float *)ctx->OZ.p, sst, d_planes, frame);
+                           (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p, sst, d_planes, frame);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
