@@ -203,7 +203,7 @@ static int create_common(int device, hipStream_t stream, bool own, lpx_ctx **out
     int rc;
     if ((rc = lpx_ensure(ctx, ctx->frame, sizeof(FrameState))) ||
         (rc = lpx_ensure(ctx, ctx->seg_state, sizeof(SegState) * LPX_MAX_PARTITIONS)) ||
-        (rc = lpx_ensure(ctx, ctx->seg_acc, (sizeof(long long) * LPX_ACC_WORDS + sizeof(uint32_t)) * LPX_MAX_PARTITIONS)) ||
+        (rc = lpx_ensure(ctx, ctx->seg_acc, (sizeof(long long) * LPX_ACC_WORDS + 2 * sizeof(uint32_t)) * LPX_MAX_PARTITIONS)) ||
         (rc = lpx_ensure(ctx, ctx->d_planes, sizeof(float) * 4 * LPX_MAX_PARTITIONS)) ||
         (rc = lpx_ensure(ctx, ctx->d_counts, 64)) || (rc = lpx_ensure(ctx, ctx->hist, 1 << 16)))
     {

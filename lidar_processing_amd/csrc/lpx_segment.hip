@@ -96,7 +96,7 @@ constexpr int SEED_LDS = 4096;
 
 __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__restrict__ zsorted, SegParams prm,
                                                             SegState *__restrict__ st, long long *__restrict__ acc,
-                                                            uint32_t *__restrict__ ticket)
+                                                            uint32_t *__restrict__ ticket, uint32_t *__restrict__ gen)
 {
     __shared__ __attribute__((aligned(16))) float zbuf[SEED_LDS];
     __shared__ float s_sum;
@@ -109,7 +109,10 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
     if (tid < LPX_ACC_WORDS)
         acc[s * LPX_ACC_WORDS + tid] = 0;
     if (tid == 0)
+    {
         ticket[s] = 0;
+        gen[s] = 0;
+    }
 
     // first index with z > z_floor (sorted ascending): upper bound
     if (tid == 0)
@@ -604,6 +607,226 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
 }
 
 // ------------------------------------------------------------------------------------------------
+// All I+1 passes in ONE launch.  The blocks of a segment keep their points in registers (16 per thread,
+// read from HBM once), and between two passes they meet at a per-segment barrier: the last block to
+// arrive (ticket) solves plane t, publishes it write-through and bumps the segment's generation word;
+// the others poll that word.  Every exchanged word is an agent-scope atomic, so no L2 fence is needed.
+// Used when the whole grid is certainly co-resident (P * bps <= FUSED_MAX_BLOCKS); larger clouds take
+// the launch-per-pass path above.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t FUSED_MAX_BLOCKS = 512;
+constexpr int PTS_PER_THREAD = SEG_CHUNK / SEG_THREADS;  // 16
+
+__global__ __launch_bounds__(SEG_THREADS) void plane_fused_kernel(const float *__restrict__ XS,
+                                                                   const float *__restrict__ YS,
+                                                                   const float *__restrict__ ZS, SegParams prm,
+                                                                   SegState *st, long long *acc, uint32_t *ticket,
+                                                                   uint32_t *gen, uint8_t *__restrict__ flags,
+                                                                   uint32_t *__restrict__ blk_counts)
+{
+    __shared__ long long red[SEG_WAVES][LPX_ACC_WORDS];
+    __shared__ uint32_t s_last;
+    __shared__ float s_plane[6];  // a, b, c, d, thr, failed
+    const uint32_t s = blockIdx.y, b = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
+    const uint32_t seg_lo = s * prm.n_per;
+    const uint32_t lo = seg_lo + b * prm.chunk;
+    const uint32_t hi = min(lo + prm.chunk, seg_lo + prm.n_per);
+
+    const SegState sst = st[s];  // written by seed_kernel in the previous launch
+    const bool skip = sst.failed == 2;
+    const bool seeds_ok = sst.has_seeds != 0;
+    bool dead = sst.failed != 0;
+    float pa = 0.0f, pb = 0.0f, pc = 0.0f, pd = 0.0f, thr = 0.0f;
+
+    float xs[PTS_PER_THREAD], ys[PTS_PER_THREAD], zs[PTS_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < PTS_PER_THREAD; ++u)
+    {
+        const uint32_t p = lo + tid + u * SEG_THREADS;
+        const bool in = p < hi;
+        xs[u] = in ? XS[p] : 0.0f;
+        ys[u] = in ? YS[p] : 0.0f;
+        zs[u] = in ? ZS[p] : 0.0f;
+    }
+
+    for (uint32_t t = 0;; ++t)
+    {
+        const bool final_pass = (t == prm.I);
+        long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
+        uint32_t cnt_g = 0, cnt_o = 0;
+#pragma unroll
+        for (int u = 0; u < PTS_PER_THREAD; ++u)
+        {
+            const uint32_t p = lo + tid + u * SEG_THREADS;
+            const bool in = p < hi;
+            const float x = xs[u], y = ys[u], z = zs[u];
+            bool member;
+            if (t == 0)
+                member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
+            else
+            {
+                const float dist = ((x * pa + y * pb) + z * pc) - pd;
+                member = dist < thr;
+            }
+            member = member && !dead && in;
+            if (final_pass)
+            {
+                if (in)
+                {
+                    const uint8_t f = skip ? 0 : (member ? 1 : ((prm.I == 0 && !dead) ? 0 : 2));
+                    flags[p] = f;
+                    cnt_g += (f == 1);
+                    cnt_o += (f == 2);
+                }
+            }
+            else if (member)
+            {
+                const int qx = __float2int_rn(x * FIX_SCALE);
+                const int qy = __float2int_rn(y * FIX_SCALE);
+                const int qz = __float2int_rn(z * FIX_SCALE);
+                a_n += 1;
+                a_x += qx;
+                a_y += qy;
+                a_z += qz;
+                a_xx += (long long)qx * qx;
+                a_xy += (long long)qx * qy;
+                a_xz += (long long)qx * qz;
+                a_yy += (long long)qy * qy;
+                a_yz += (long long)qy * qz;
+                a_zz += (long long)qz * qz;
+            }
+        }
+        if (final_pass)
+        {
+            cnt_g = lpx_wave_sum_u32(cnt_g);
+            cnt_o = lpx_wave_sum_u32(cnt_o);
+            if (lane == 0)
+            {
+                red[w][0] = cnt_g;
+                red[w][1] = cnt_o;
+            }
+            __syncthreads();
+            if (tid == 0)
+            {
+                uint32_t g = 0, o = 0;
+                for (int i = 0; i < SEG_WAVES; ++i)
+                {
+                    g += (uint32_t)red[i][0];
+                    o += (uint32_t)red[i][1];
+                }
+                const uint32_t nb = prm.P * prm.bps;
+                blk_counts[s * prm.bps + b] = g;
+                blk_counts[nb + s * prm.bps + b] = o;
+                if (s == 0 && b == 0)
+                    blk_counts[2 * nb] = 0;
+            }
+            return;
+        }
+
+        long long v[LPX_ACC_WORDS];
+        v[0] = a_n;
+        v[1] = a_x;
+        v[2] = a_y;
+        v[3] = a_z;
+        const long long sm[6] = {a_xx, a_xy, a_xz, a_yy, a_yz, a_zz};
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+        {
+            v[4 + 2 * i] = sm[i] >> 32;
+            v[5 + 2 * i] = sm[i] & 0xffffffffLL;
+        }
+#pragma unroll
+        for (int i = 0; i < LPX_ACC_WORDS; ++i)
+        {
+            v[i] = lpx_wave_sum_i64(v[i]);
+            if (lane == 0)
+                red[w][i] = v[i];
+        }
+        __syncthreads();
+        if (tid < LPX_ACC_WORDS)
+        {
+            long long tot = 0;
+#pragma unroll
+            for (int i = 0; i < SEG_WAVES; ++i)
+                tot += red[i][tid];
+            if (tot != 0)
+                atomicAdd((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], (unsigned long long)tot);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // adds performed before the ticket (see plane_pass_kernel)
+        }
+        __syncthreads();
+        if (tid == 0)
+            s_last = (atomicAdd(&ticket[s], 1u) == prm.bps - 1) ? 1u : 0u;
+        __syncthreads();
+        if (s_last)
+        {
+            if (tid < LPX_ACC_WORDS)
+            {
+                red[0][tid] = (long long)atomicExch((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], 0ull);
+                if (tid == 0)
+                    atomicExch(&ticket[s], 0u);
+            }
+            __syncthreads();
+            if (tid == 0)
+            {
+                long long m[LPX_ACC_WORDS];
+                for (int i = 0; i < LPX_ACC_WORDS; ++i)
+                    m[i] = red[0][i];
+                float plane[4] = {pa, pb, pc, pd};
+                float nthr = thr;
+                uint32_t failed = dead ? (skip ? 2u : 1u) : 0u;
+                uint32_t fitted = 0;
+                if (!dead)
+                {
+                    if (!plane_from_moments(m, plane))
+                        failed = 1;
+                    else
+                    {
+                        nthr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
+                        fitted = 1;
+                    }
+                }
+                // publish write-through, then release the generation word
+                SegState *o = st + s;
+                if (fitted)
+                {
+                    __hip_atomic_store(&o->plane[0], plane[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&o->plane[1], plane[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&o->plane[2], plane[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&o->plane[3], plane[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&o->thr, nthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&o->fitted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(&o->failed, failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&gen[s], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // per-segment barrier: wait for plane t
+        if (tid == 0)
+        {
+            while (__hip_atomic_load(&gen[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1)
+                __builtin_amdgcn_s_sleep(2);
+            const SegState *o = st + s;
+            s_plane[0] = __hip_atomic_load(&o->plane[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_plane[1] = __hip_atomic_load(&o->plane[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_plane[2] = __hip_atomic_load(&o->plane[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_plane[3] = __hip_atomic_load(&o->plane[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_plane[4] = __hip_atomic_load(&o->thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_plane[5] = __uint_as_float(__hip_atomic_load(&o->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        __syncthreads();
+        pa = s_plane[0];
+        pb = s_plane[1];
+        pc = s_plane[2];
+        pd = s_plane[3];
+        thr = s_plane[4];
+        dead = __float_as_uint(s_plane[5]) != 0;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // compaction: flags -> labels (original order), ground / obstacle index lists in output-cloud
 // order (:331-343, Q7) and the obstacle SoA handed to clustering.
 // ------------------------------------------------------------------------------------------------
@@ -858,9 +1081,10 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
     SegState *sst = (SegState *)ctx->seg_state.p;
     long long *acc = (long long *)ctx->seg_acc.p;
     uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
+    uint32_t *gen = ticket + LPX_MAX_PARTITIONS;
     {
         StageTimer tm(ctx, ST_SEEDS);
-        hipLaunchKernelGGL(seed_kernel, dim3(P), dim3(SEG_THREADS), 0, st, zsorted, prm, sst, acc, ticket);
+        hipLaunchKernelGGL(seed_kernel, dim3(P), dim3(SEG_THREADS), 0, st, zsorted, prm, sst, acc, ticket, gen);
     }
     const uint32_t nb = P * prm.bps;
     int rc = lpx_ensure(ctx, ctx->blk_counts, sizeof(uint32_t) * (2 * (size_t)nb + 2));
@@ -870,11 +1094,16 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
     {
         StageTimer tm(ctx, ST_PLANE);
         const dim3 g2(prm.bps, P);
+        if (P * prm.bps <= FUSED_MAX_BLOCKS)
+            hipLaunchKernelGGL(plane_fused_kernel, g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, sst, acc, ticket, gen,
+                               (uint8_t *)ctx->flags.p, blk_counts);
+        else
         for (uint32_t t = 0; t < I; ++t)
             hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, t, sst, acc,
                                ticket, (uint8_t *)ctx->flags.p, blk_counts);
-        hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, I, sst, acc,
-                           ticket, (uint8_t *)ctx->flags.p, blk_counts);
+        if (P * prm.bps > FUSED_MAX_BLOCKS)
+            hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, I, sst, acc,
+                               ticket, (uint8_t *)ctx->flags.p, blk_counts);
     }
     {
         StageTimer tm(ctx, ST_COMPACT);
