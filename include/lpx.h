@@ -63,6 +63,7 @@ typedef struct
 #define LPX_ERR_NO_DEVICE (-5)
 #define LPX_ERR_INTERNAL (-6)
 
+#define LPX_MAX_BATCH 64u
 #define LPX_MAX_PARTITIONS 256u
 #define LPX_MAX_ITERATIONS 64u
 
@@ -71,6 +72,9 @@ typedef struct
 /* Creates a context on HIP device `device` with its own stream.  Fails loudly (LPX_ERR_NO_DEVICE)
  * when no GPU is present: there is no CPU fallback. */
 int lpx_create(int device, lpx_ctx **out);
+/* A context with max_frames (1..LPX_MAX_BATCH) frame slots for lpx_segment_cluster_batch_device; every
+ * other entry point uses slot 0.  Device scratch is max_frames times that of lpx_create. */
+int lpx_create_batch(int device, uint32_t max_frames, lpx_ctx **out);
 /* As lpx_create but enqueues on an existing hipStream_t (passed as void*; NULL = default stream). */
 int lpx_create_on_stream(int device, void *hip_stream, lpx_ctx **out);
 void lpx_destroy(lpx_ctx *ctx);
@@ -122,6 +126,19 @@ int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride_by
                                const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, uint32_t *d_labels,
                                uint32_t *d_ground_idx, uint32_t *d_obstacle_idx, float *d_planes,
                                int32_t *d_cluster_labels, uint32_t *d_counts);
+/* n_frames clouds in ONE launch chain (a sensor rig's clouds of one tick, or a backlog of frames): every
+ * kernel covers all frames, so the ~50 dependent launches of the chain are paid once per batch and each
+ * launch has n_frames times the workgroups.  Per frame the results are identical to
+ * lpx_segment_cluster_device.  Layout: frame b's records start at d_pts + b * frame_pitch * stride_bytes
+ * and hold n_points[b] <= frame_pitch points (n_points is a HOST array); d_labels, d_ground_idx,
+ * d_obstacle_idx and d_cluster_labels are pitched by frame_pitch elements, d_planes (may be NULL) by
+ * 4 * number_of_planar_partitions floats, d_counts by 4 words.  Needs a context from lpx_create_batch with
+ * max_frames >= n_frames. */
+int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames, const void *d_pts, size_t stride_bytes,
+                                     uint32_t frame_pitch, const uint32_t *n_points, const lpx_seg_cfg *seg_cfg,
+                                     const lpx_clu_cfg *clu_cfg, uint32_t *d_labels, uint32_t *d_ground_idx,
+                                     uint32_t *d_obstacle_idx, float *d_planes, int32_t *d_cluster_labels,
+                                     uint32_t *d_counts);
 int lpx_segment_device(lpx_ctx *ctx, const void *d_pts, size_t stride_bytes, uint32_t n, const lpx_seg_cfg *cfg,
                        uint32_t *d_labels, uint32_t *d_ground_idx, uint32_t *d_obstacle_idx, float *d_planes,
                        uint32_t *d_counts);

@@ -61,6 +61,9 @@ def lib():
                                       vp, vp, pu32]
     L.lpx_segment_cluster_device.argtypes = [vp, vp, sz, u32, C.POINTER(SegCfg), C.POINTER(CluCfg), vp, vp, vp, vp,
                                              vp, vp]
+    L.lpx_create_batch.argtypes = [C.c_int, u32, C.POINTER(vp)]
+    L.lpx_segment_cluster_batch_device.argtypes = [vp, u32, vp, sz, u32, vp, C.POINTER(SegCfg), C.POINTER(CluCfg), vp,
+                                                   vp, vp, vp, vp, vp]
     L.lpx_segment_device.argtypes = [vp, vp, sz, u32, C.POINTER(SegCfg), vp, vp, vp, vp, vp]
     L.lpx_cluster_device.argtypes = [vp, vp, sz, u32, C.POINTER(CluCfg), vp, vp]
     L.lpx_profile_enable.argtypes = [vp, C.c_int]

@@ -77,10 +77,13 @@ def _vp(a):
 class Context:
     """One HIP device + stream + scratch (lpx_ctx).  Not thread-safe, like the reference objects."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, batch=1):
         self._L = _lib.lib()
         h = C.c_void_p()
-        if stream is None:
+        self.batch = int(batch)
+        if self.batch != 1:
+            rc = self._L.lpx_create_batch(int(device), self.batch, C.byref(h))
+        elif stream is None:
             rc = self._L.lpx_create(int(device), C.byref(h))
         else:
             rc = self._L.lpx_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h))
@@ -182,6 +185,16 @@ class Context:
         self.check(self._L.lpx_segment_cluster_device(self._h, d_pts, stride_bytes, n, C.byref(sc), C.byref(cc),
                                                       d_labels, d_ground_idx, d_obstacle_idx, d_planes,
                                                       d_cluster_labels, d_counts))
+
+    def segment_cluster_batch_device(self, n_points, d_pts, stride_bytes, frame_pitch, seg_cfg, clu_cfg, d_labels,
+                                     d_ground_idx, d_obstacle_idx, d_planes, d_cluster_labels, d_counts):
+        """lpx_segment_cluster_batch_device: len(n_points) frames per launch chain; frame b of every array
+        starts b * frame_pitch elements (records for d_pts) behind frame 0; nothing synchronises."""
+        sc, cc = seg_cfg._c(), clu_cfg._c()
+        n = np.ascontiguousarray(n_points, dtype=np.uint32)
+        self.check(self._L.lpx_segment_cluster_batch_device(self._h, n.shape[0], d_pts, stride_bytes, frame_pitch,
+                                                            _vp(n), C.byref(sc), C.byref(cc), d_labels, d_ground_idx,
+                                                            d_obstacle_idx, d_planes, d_cluster_labels, d_counts))
 
     def frame_stats(self):
         """counters of the last frame of this context (synchronises)"""

@@ -46,33 +46,101 @@ int lpx_ensure(lpx_ctx *ctx, Buf &b, size_t bytes)
     return LPX_OK;
 }
 
+static inline size_t align256(size_t v)
+{
+    return (v + 255) & ~(size_t)255;
+}
+
+// One arena per frame slot: every internal buffer is a fixed sub-range of it, so slot b of any buffer is
+// b * fstride bytes behind slot 0 (what the kernels add for blockIdx.z).  Growing reallocates the arena
+// and drops its contents, which only happens before a call enqueues work.  The neighbour lists have their
+// own arena so that the capacity retry of the host entry points keeps the frame data.
 int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
 {
-    int rc = LPX_OK;
-    if (n > ctx->cap_n)
+    if (n > ctx->cap_n || !ctx->arena)
     {
+        if (n < ctx->cap_n)
+            n = ctx->cap_n;
         const size_t n4 = sizeof(uint32_t) * ((size_t)n + 16);
-        Buf *four[] = {&ctx->X,      &ctx->Y,      &ctx->Z,       &ctx->XS,     &ctx->YS,    &ctx->ZS,
-                       &ctx->OX,     &ctx->OY,     &ctx->OZ,      &ctx->key_a,  &ctx->key_b, &ctx->val_a,
-                       &ctx->val_b,  &ctx->lpos,   &ctx->rpos,    &ctx->nb_len, &ctx->nb_off, &ctx->parent,
-                       &ctx->cc_lo,  &ctx->cc_hi,  &ctx->seed_of, &ctx->queue,  &ctx->valid, &ctx->d_labels,
-                       &ctx->d_gidx, &ctx->d_oidx, &ctx->d_clabels};
-        for (Buf *b : four)
-            if ((rc = lpx_ensure(ctx, *b, n4)))
-                return rc;
-        if ((rc = lpx_ensure(ctx, ctx->key64_a, 2 * n4)) || (rc = lpx_ensure(ctx, ctx->key64_b, 2 * n4)) ||
-            (rc = lpx_ensure(ctx, ctx->nodes, 4 * n4)) || (rc = lpx_ensure(ctx, ctx->nodes_pre, 4 * n4)) || (rc = lpx_ensure(ctx, ctx->flags, (size_t)n + 64)) ||
-            (rc = lpx_ensure(ctx, ctx->state, (size_t)n + 64)))
-            return rc;
+        const size_t sort_blocks = ((size_t)n + LPX_SORT_TILE - 1) / LPX_SORT_TILE + 1;
+        size_t hist_bytes = 64 + 256 * sizeof(uint32_t) * sort_blocks + 64;
+        if (hist_bytes < (1u << 16))
+            hist_bytes = 1u << 16;
+        const size_t blk_bytes = sizeof(uint32_t) * (2 * ((size_t)n / 4096 + LPX_MAX_PARTITIONS + 2) + 2);
+        struct Item
+        {
+            Buf *b;
+            size_t bytes;
+        };
+        const Item items[] = {
+            {&ctx->frame, sizeof(FrameState)},
+            {&ctx->seg_state, sizeof(SegState) * LPX_MAX_PARTITIONS},
+            {&ctx->seg_acc, (sizeof(long long) * LPX_ACC_WORDS + 2 * sizeof(uint32_t)) * LPX_MAX_PARTITIONS},
+            {&ctx->d_planes, sizeof(float) * 4 * LPX_MAX_PARTITIONS},
+            {&ctx->d_counts, 64},
+            {&ctx->hist, hist_bytes},
+            {&ctx->blk_counts, blk_bytes},
+            {&ctx->X, n4},        {&ctx->Y, n4},        {&ctx->Z, n4},       {&ctx->XS, n4},      {&ctx->YS, n4},
+            {&ctx->ZS, n4},       {&ctx->OX, n4},       {&ctx->OY, n4},      {&ctx->OZ, n4},      {&ctx->key_a, n4},
+            {&ctx->key_b, n4},    {&ctx->val_a, n4},    {&ctx->val_b, n4},   {&ctx->lpos, n4},    {&ctx->rpos, n4},
+            {&ctx->nb_len, n4},   {&ctx->nb_off, n4},   {&ctx->parent, n4},  {&ctx->cc_lo, n4},   {&ctx->cc_hi, n4},
+            {&ctx->seed_of, n4},  {&ctx->queue, n4},    {&ctx->valid, n4},   {&ctx->d_labels, n4}, {&ctx->d_gidx, n4},
+            {&ctx->d_oidx, n4},   {&ctx->d_clabels, n4}, {&ctx->key64_a, 2 * n4}, {&ctx->key64_b, 2 * n4},
+            {&ctx->nodes, 4 * n4}, {&ctx->nodes_pre, 4 * n4}, {&ctx->flags, (size_t)n + 64}, {&ctx->state, (size_t)n + 64},
+        };
+        size_t total = 0;
+        for (const Item &it : items)
+            total += align256(it.bytes);
+        if (ctx->arena)
+        {
+            LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            LPX_HIP(ctx, hipFree(ctx->arena));
+            ctx->arena = nullptr;
+            ctx->cap_n = 0;
+        }
+        LPX_HIP(ctx, hipMalloc(&ctx->arena, total * ctx->batch));
+        // zero once: frame states, and the ticket words at the head of every slot's histogram buffer
+        LPX_HIP(ctx, hipMemsetAsync(ctx->arena, 0, total * ctx->batch, ctx->stream));
+        size_t off = 0;
+        for (const Item &it : items)
+        {
+            it.b->p = (char *)ctx->arena + off;
+            it.b->bytes = it.bytes;
+            off += align256(it.bytes);
+        }
+        ctx->fstride = total;
         ctx->cap_n = n;
     }
-    if (nb > ctx->cap_nb)
+    if (nb > ctx->cap_nb || !ctx->nb_arena)
     {
-        if ((rc = lpx_ensure(ctx, ctx->nb_idx, sizeof(uint32_t) * (nb + 64))) ||
-            (rc = lpx_ensure(ctx, ctx->nb_dist, sizeof(float) * (nb + 64))))
-            return rc;
+        if (nb < ctx->cap_nb)
+            nb = ctx->cap_nb;
+        const size_t one = align256(sizeof(uint32_t) * (nb + 64));
+        if (ctx->nb_arena)
+        {
+            LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            LPX_HIP(ctx, hipFree(ctx->nb_arena));
+            ctx->nb_arena = nullptr;
+            ctx->cap_nb = 0;
+        }
+        LPX_HIP(ctx, hipMalloc(&ctx->nb_arena, 2 * one * ctx->batch));
+        ctx->nb_idx.p = ctx->nb_arena;
+        ctx->nb_idx.bytes = one;
+        ctx->nb_dist.p = (char *)ctx->nb_arena + one;
+        ctx->nb_dist.bytes = one;
+        ctx->nb_fstride = 2 * one;
         ctx->cap_nb = nb;
     }
+    return LPX_OK;
+}
+
+// every entry point states how many frame slots its launches cover and the pitch of the caller arrays
+static int begin_call(lpx_ctx *ctx, uint32_t frames, uint32_t upitch)
+{
+    if (frames == 0 || frames > ctx->batch)
+        return lpx_fail(ctx, LPX_ERR_ARG, "%u frames in a call, the context has %u frame slots", frames, ctx->batch);
+    ctx->cur_b = frames;
+    ctx->upitch = upitch;
     return LPX_OK;
 }
 
@@ -170,11 +238,13 @@ extern "C" int lpx_profile_read(lpx_ctx *ctx, float *ms, uint32_t *launches, int
 // ------------------------------------------------------------------------------------------------
 // lifetime
 // ------------------------------------------------------------------------------------------------
-static int create_common(int device, hipStream_t stream, bool own, lpx_ctx **out)
+static int create_common(int device, hipStream_t stream, bool own, uint32_t batch, lpx_ctx **out)
 {
     if (!out)
         return LPX_ERR_ARG;
     *out = nullptr;
+    if (batch == 0 || batch > LPX_MAX_BATCH)
+        return LPX_ERR_ARG;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return LPX_ERR_NO_DEVICE;  // no CPU fallback: fail loudly
@@ -200,30 +270,30 @@ static int create_common(int device, hipStream_t stream, bool own, lpx_ctx **out
     }
     else
         ctx->stream = stream;
+    ctx->batch = batch;
     int rc;
-    if ((rc = lpx_ensure(ctx, ctx->frame, sizeof(FrameState))) ||
-        (rc = lpx_ensure(ctx, ctx->seg_state, sizeof(SegState) * LPX_MAX_PARTITIONS)) ||
-        (rc = lpx_ensure(ctx, ctx->seg_acc, (sizeof(long long) * LPX_ACC_WORDS + 2 * sizeof(uint32_t)) * LPX_MAX_PARTITIONS)) ||
-        (rc = lpx_ensure(ctx, ctx->d_planes, sizeof(float) * 4 * LPX_MAX_PARTITIONS)) ||
-        (rc = lpx_ensure(ctx, ctx->d_counts, 64)) || (rc = lpx_ensure(ctx, ctx->hist, 1 << 16)))
+    if ((rc = lpx_ensure_capacity(ctx, 1024, 1024)))
     {
         lpx_destroy(ctx);
         return rc;
     }
-    hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream);
-    hipMemsetAsync(ctx->hist.p, 0, 64, ctx->stream);
     *out = ctx;
     return LPX_OK;
 }
 
 extern "C" int lpx_create(int device, lpx_ctx **out)
 {
-    return create_common(device, nullptr, true, out);
+    return create_common(device, nullptr, true, 1, out);
+}
+
+extern "C" int lpx_create_batch(int device, uint32_t max_frames, lpx_ctx **out)
+{
+    return create_common(device, nullptr, true, max_frames, out);
 }
 
 extern "C" int lpx_create_on_stream(int device, void *hip_stream, lpx_ctx **out)
 {
-    return create_common(device, (hipStream_t)hip_stream, false, out);
+    return create_common(device, (hipStream_t)hip_stream, false, 1, out);
 }
 
 extern "C" void lpx_destroy(lpx_ctx *ctx)
@@ -232,16 +302,14 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
         return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    Buf *all[] = {&ctx->in_aos, &ctx->X,        &ctx->Y,        &ctx->Z,      &ctx->key_a,   &ctx->key_b,  &ctx->val_a,
-                  &ctx->val_b,  &ctx->key64_a,  &ctx->key64_b,  &ctx->XS,     &ctx->YS,      &ctx->ZS,     &ctx->flags,
-                  &ctx->hist,   &ctx->seg_state, &ctx->seg_acc, &ctx->blk_counts, &ctx->d_labels, &ctx->d_gidx,
-                  &ctx->d_oidx, &ctx->d_planes, &ctx->d_counts, &ctx->OX,     &ctx->OY,      &ctx->OZ,     &ctx->nodes, &ctx->nodes_pre,
-                  &ctx->lpos,   &ctx->rpos,     &ctx->nb_len,   &ctx->nb_off, &ctx->nb_idx,  &ctx->nb_dist, &ctx->parent,
-                  &ctx->cc_lo,  &ctx->cc_hi,    &ctx->state,    &ctx->seed_of, &ctx->queue,  &ctx->valid,  &ctx->d_clabels,
-                  &ctx->frame, &ctx->dbg_store};
-    for (Buf *b : all)
-        if (b->p)
-            hipFree(b->p);
+    if (ctx->arena)
+        hipFree(ctx->arena);
+    if (ctx->nb_arena)
+        hipFree(ctx->nb_arena);
+    if (ctx->in_aos.p)
+        hipFree(ctx->in_aos.p);
+    if (ctx->dbg_store.p)
+        hipFree(ctx->dbg_store.p);
     for (int i = 0; i < ctx->n_pending; ++i)
     {
         hipEventDestroy(ctx->pending[i].a);
@@ -319,13 +387,11 @@ extern "C" int lpx_segment_device(lpx_ctx *ctx, const void *d_pts, size_t stride
     if (rc)
         return rc;
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, n)))
+    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)))
         return rc;
-    if ((rc = lpx_run_segment(ctx, d_pts, stride, n, cfg, d_labels, d_gidx, d_oidx, d_planes)))
+    if ((rc = lpx_run_segment(ctx, d_pts, stride, &n, cfg, d_labels, d_gidx, d_oidx, d_planes)))
         return rc;
-    if (d_counts)
-        LPX_HIP(ctx, hipMemcpyAsync(d_counts, ctx->frame.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
-    return LPX_OK;
+    return d_counts ? lpx_write_counts(ctx, d_counts) : LPX_OK;
 }
 
 extern "C" int lpx_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m, const lpx_clu_cfg *cfg,
@@ -337,16 +403,11 @@ extern "C" int lpx_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride
     if (rc)
         return rc;
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, m)))
+    if ((rc = ensure_for(ctx, m)) || (rc = begin_call(ctx, 1, 0)))
         return rc;
-    LPX_HIP(ctx, hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream));
     if ((rc = lpx_ingest_obstacles(ctx, d_pts, stride, m)))
         return rc;
-    if ((rc = lpx_run_cluster(ctx, m, cfg, d_labels)))
-        return rc;
-    if (d_counts)
-        LPX_HIP(ctx, hipMemcpyAsync(d_counts, ctx->frame.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
-    return LPX_OK;
+    return lpx_run_cluster(ctx, m, cfg, d_labels, d_counts);
 }
 
 extern "C" int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n,
@@ -360,17 +421,47 @@ extern "C" int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_
     if (rc || (rc = check_clu(ctx, clu_cfg, stride)))
         return rc;
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, n)))
+    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)))
         return rc;
-    if ((rc = lpx_run_segment(ctx, d_pts, stride, n, seg_cfg, d_labels, d_gidx, d_oidx, d_planes)))
+    if ((rc = lpx_run_segment(ctx, d_pts, stride, &n, seg_cfg, d_labels, d_gidx, d_oidx, d_planes)))
         return rc;
     if (!d_clabels)
         d_clabels = (int32_t *)ctx->d_clabels.p;
-    if ((rc = lpx_run_cluster(ctx, n, clu_cfg, d_clabels)))  // n bounds the obstacle count
+    return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts);  // n bounds the obstacle count
+}
+
+// B frames per launch chain: every kernel covers all frames (gridDim.z), so the launch count of the chain
+// is paid once per batch and each launch has B times the workgroups of a single frame.
+extern "C" int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames, const void *d_pts, size_t stride,
+                                                uint32_t frame_pitch, const uint32_t *n_points,
+                                                const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
+                                                uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes,
+                                                int32_t *d_clabels, uint32_t *d_counts)
+{
+    if (!ctx || !n_points)
+        return LPX_ERR_ARG;
+    int rc = check_seg(ctx, seg_cfg, stride);
+    if (rc || (rc = check_clu(ctx, clu_cfg, stride)))
         return rc;
-    if (d_counts)
-        LPX_HIP(ctx, hipMemcpyAsync(d_counts, ctx->frame.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
-    return LPX_OK;
+    if (!d_labels || !d_gidx || !d_oidx || !d_clabels || !d_counts)
+        return lpx_fail(ctx, LPX_ERR_ARG, "the batch entry point needs every output array except planes");
+    if ((rc = begin_call(ctx, n_frames, frame_pitch)))
+        return rc;
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < n_frames; ++b)
+    {
+        if (n_points[b] > frame_pitch)
+            return lpx_fail(ctx, LPX_ERR_ARG, "frame %u holds %u points, the pitch is %u", b, n_points[b], frame_pitch);
+        n = n_points[b] > n ? n_points[b] : n;
+    }
+    if (n && !d_pts)
+        return lpx_fail(ctx, LPX_ERR_ARG, "null points");
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_for(ctx, n)))
+        return rc;
+    if ((rc = lpx_run_segment(ctx, d_pts, stride, n_points, seg_cfg, d_labels, d_gidx, d_oidx, d_planes)))
+        return rc;
+    return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,9 +526,9 @@ extern "C" int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
     if (n && !pts)
         return lpx_fail(ctx, LPX_ERR_ARG, "null points");
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, n)) || (rc = upload(ctx, pts, stride, n)))
+    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)) || (rc = upload(ctx, pts, stride, n)))
         return rc;
-    if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, n, cfg, (uint32_t *)ctx->d_labels.p,
+    if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, &n, cfg, (uint32_t *)ctx->d_labels.p,
                               (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
         return rc;
     FrameState fs;
@@ -452,7 +543,7 @@ static int cluster_resident(lpx_ctx *ctx, uint32_t m, const lpx_clu_cfg *cfg, in
     FrameState fs;
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        if ((rc = lpx_run_cluster(ctx, m, cfg, (int32_t *)ctx->d_clabels.p)))
+        if ((rc = lpx_run_cluster(ctx, m, cfg, (int32_t *)ctx->d_clabels.p, nullptr)))
             return rc;
         if ((rc = read_frame(ctx, &fs)))
             return rc;
@@ -497,9 +588,8 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
     if (!pts)
         return lpx_fail(ctx, LPX_ERR_ARG, "null points");
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, m)) || (rc = upload(ctx, pts, stride, m)))
+    if ((rc = ensure_for(ctx, m)) || (rc = begin_call(ctx, 1, 0)) || (rc = upload(ctx, pts, stride, m)))
         return rc;
-    LPX_HIP(ctx, hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream));
     if ((rc = lpx_ingest_obstacles(ctx, ctx->in_aos.p, stride, m)))
         return rc;
     return cluster_resident(ctx, m, cfg, labels, n_clusters);
@@ -524,9 +614,9 @@ extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride,
     if (n && !pts)
         return lpx_fail(ctx, LPX_ERR_ARG, "null points");
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, n)) || (rc = upload(ctx, pts, stride, n)))
+    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)) || (rc = upload(ctx, pts, stride, n)))
         return rc;
-    if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, n, seg_cfg, (uint32_t *)ctx->d_labels.p,
+    if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, &n, seg_cfg, (uint32_t *)ctx->d_labels.p,
                               (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
         return rc;
     FrameState fs;
@@ -555,9 +645,9 @@ extern "C" int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters,
         return LPX_OK;
     }
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, (uint32_t *)ctx->d_gidx.p,
-                            (uint32_t *)ctx->d_oidx.p);
-    if (rc)
+    int rc = begin_call(ctx, 1, 0);
+    if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, (uint32_t *)ctx->d_gidx.p,
+                                   (uint32_t *)ctx->d_oidx.p)))
         return rc;
     LPX_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_gidx.p, sizeof(uint32_t) * ((size_t)n_clusters + 1),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -579,7 +669,7 @@ extern "C" int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, 
         return LPX_ERR_ARG;
     LPX_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_for(ctx, m);
-    if (rc)
+    if (rc || (rc = begin_call(ctx, 1, 0)))
         return rc;
     return lpx_run_groups(ctx, d_labels, m, d_offsets, d_indices);
 }
@@ -639,7 +729,7 @@ extern "C" int lpx_dbg_sort_pairs(lpx_ctx *ctx, uint32_t *keys, uint32_t *values
     if (!ctx)
         return LPX_ERR_ARG;
     int rc = ensure_for(ctx, n);
-    if (rc || n == 0)
+    if (rc || n == 0 || (rc = begin_call(ctx, 1, 0)))
         return rc;
     LPX_HIP(ctx, hipMemcpyAsync(ctx->key_a.p, keys, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     LPX_HIP(ctx, hipMemcpyAsync(ctx->val_a.p, values, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -658,11 +748,11 @@ extern "C" int lpx_dbg_sort_keys64(lpx_ctx *ctx, uint64_t *keys, uint32_t n, uin
     if (!ctx)
         return LPX_ERR_ARG;
     int rc = ensure_for(ctx, n);
-    if (rc || n == 0)
+    if (rc || n == 0 || (rc = begin_call(ctx, 1, 0)))
         return rc;
     LPX_HIP(ctx, hipMemcpyAsync(ctx->key64_a.p, keys, 8 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     uint64_t *ko;
-    if ((rc = lpx_sort_keys64(ctx, (uint64_t *)ctx->key64_a.p, (uint64_t *)ctx->key64_b.p, n, bits, &ko)))
+    if ((rc = lpx_sort_keys64(ctx, (uint64_t *)ctx->key64_a.p, (uint64_t *)ctx->key64_b.p, n, nullptr, bits, &ko)))
         return rc;
     LPX_HIP(ctx, hipMemcpyAsync(keys, ko, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -674,7 +764,7 @@ extern "C" int lpx_dbg_scan(lpx_ctx *ctx, uint32_t *data, uint32_t n, uint64_t *
     if (!ctx)
         return LPX_ERR_ARG;
     int rc = ensure_for(ctx, n);
-    if (rc)
+    if (rc || (rc = begin_call(ctx, 1, 0)))
         return rc;
     if (n)
         LPX_HIP(ctx, hipMemcpyAsync(ctx->key_a.p, data, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
@@ -691,9 +781,8 @@ extern "C" int lpx_dbg_scan(lpx_ctx *ctx, uint32_t *data, uint32_t n, uint64_t *
 static int upload_xyz_as_obstacles(lpx_ctx *ctx, const float *xyz, uint32_t m)
 {
     int rc = ensure_for(ctx, m);
-    if (rc || (rc = upload(ctx, xyz, 12, m)))
+    if (rc || (rc = begin_call(ctx, 1, 0)) || (rc = upload(ctx, xyz, 12, m)))
         return rc;
-    LPX_HIP(ctx, hipMemsetAsync(ctx->frame.p, 0, sizeof(FrameState), ctx->stream));
     return lpx_ingest_obstacles(ctx, ctx->in_aos.p, 12, m);
 }
 
@@ -830,7 +919,7 @@ extern "C" int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *
     if (!ctx)
         return LPX_ERR_ARG;
     int rc = ensure_for(ctx, n);
-    if (rc || (rc = upload(ctx, xyz, 12, n)))
+    if (rc || (rc = begin_call(ctx, 1, 0)) || (rc = upload(ctx, xyz, 12, n)))
         return rc;
     if ((rc = lpx_dbg_plane_run(ctx, ctx->in_aos.p, n, (float *)ctx->d_planes.p)))
         return rc;

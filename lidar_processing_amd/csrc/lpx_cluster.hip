@@ -32,8 +32,16 @@ enum : uint8_t
 __global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ frame, uint32_t *__restrict__ root,
                                uint32_t *__restrict__ iota, uint8_t *__restrict__ state,
                                uint32_t *__restrict__ valid, uint32_t *__restrict__ cc_lo,
-                               uint32_t *__restrict__ cc_hi)
+                               uint32_t *__restrict__ cc_hi, size_t fs)
 {
+    parent = lpx_slot(parent, fs);
+    frame = lpx_slot(frame, fs);
+    root = lpx_slot(root, fs);
+    iota = lpx_slot(iota, fs);
+    state = lpx_slot(state, fs);
+    valid = lpx_slot(valid, fs);
+    cc_lo = lpx_slot(cc_lo, fs);
+    cc_hi = lpx_slot(cc_hi, fs);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= frame->n_obstacle)
         return;
@@ -56,8 +64,13 @@ __global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ 
 // sorted by root (stable): members of a component are contiguous, ascending original index
 __global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, FrameState *frame,
                                  uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi,
-                                 uint32_t *__restrict__ roots)
+                                 uint32_t *__restrict__ roots, size_t fs)
 {
+    sroot = lpx_slot(sroot, fs);
+    frame = lpx_slot(frame, fs);
+    cc_lo = lpx_slot(cc_lo, fs);
+    cc_hi = lpx_slot(cc_hi, fs);
+    roots = lpx_slot(roots, fs);
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
     if (p >= M)
@@ -94,8 +107,20 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
                                                                  const uint32_t *__restrict__ nb_idx,
                                                                  const float *__restrict__ nb_dist, uint8_t *state,
                                                                  int32_t *seed_of, uint32_t *queue, uint32_t *valid,
-                                                                 ReplayParams prm, uint64_t cap)
+                                                                 ReplayParams prm, uint64_t cap, FV fv)
 {
+    frame = lpx_slot(frame, fv.fs);
+    cc_lo = lpx_slot(cc_lo, fv.fs);
+    cc_hi = lpx_slot(cc_hi, fv.fs);
+    members = lpx_slot(members, fv.fs);
+    nb_off = lpx_slot(nb_off, fv.fs);
+    nb_len = lpx_slot(nb_len, fv.fs);
+    nb_idx = lpx_slot(nb_idx, fv.fs_nb);
+    nb_dist = lpx_slot(nb_dist, fv.fs_nb);
+    state = lpx_slot(state, fv.fs);
+    seed_of = lpx_slot(seed_of, fv.fs);
+    queue = lpx_slot(queue, fv.fs);
+    valid = lpx_slot(valid, fv.fs);
     const uint32_t r = blockIdx.x * RP_WAVES + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     const uint32_t M = frame->n_obstacle;
@@ -201,9 +226,25 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                                                            uint32_t *queue, uint32_t *valid, ReplayParams prm,
                                                            uint64_t cap, FrameState *fstate,
                                                            const uint32_t *__restrict__ roots,
-                                                           uint32_t *__restrict__ dbg)
+                                                           uint32_t *__restrict__ dbg, FV fv)
 {
     extern __shared__ uint32_t sbits[];
+    frame = lpx_slot(frame, fv.fs);
+    fstate = lpx_slot(fstate, fv.fs);
+    cc_lo = lpx_slot(cc_lo, fv.fs);
+    cc_hi = lpx_slot(cc_hi, fv.fs);
+    members = lpx_slot(members, fv.fs);
+    nb_off = lpx_slot(nb_off, fv.fs);
+    nb_len = lpx_slot(nb_len, fv.fs);
+    nb_idx = lpx_slot(nb_idx, fv.fs_nb);
+    nb_dist = lpx_slot(nb_dist, fv.fs_nb);
+    OX = lpx_slot(OX, fv.fs);
+    OY = lpx_slot(OY, fv.fs);
+    OZ = lpx_slot(OZ, fv.fs);
+    seed_of = lpx_slot(seed_of, fv.fs);
+    queue = lpx_slot(queue, fv.fs);
+    valid = lpx_slot(valid, fv.fs);
+    roots = lpx_slot(roots, fv.fs);
     const uint32_t lane = threadIdx.x;
     const uint32_t M = frame->n_obstacle;
     if (frame->nb_total > cap)
@@ -443,11 +484,29 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
 
 __global__ void relabel_kernel(FrameState *frame, const int32_t *__restrict__ seed_of,
                                const uint32_t *__restrict__ valid, const uint32_t *__restrict__ dense,
-                               int32_t *__restrict__ labels, uint64_t cap, const uint64_t *__restrict__ total)
+                               int32_t *__restrict__ labels, uint64_t cap, const uint64_t *__restrict__ total,
+                               uint32_t *__restrict__ counts, FV fv)
 {
+    frame = lpx_slot(frame, fv.fs);
+    seed_of = lpx_slot(seed_of, fv.fs);
+    valid = lpx_slot(valid, fv.fs);
+    dense = lpx_slot(dense, fv.fs);
+    total = lpx_slot(total, fv.fs);
+    labels = lpx_user(labels, fv.upitch);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0)
-        frame->n_clusters = (uint32_t)*total;  // number of valid seeds = number of clusters
+    {
+        const uint32_t nc = (uint32_t)*total;  // number of valid seeds = number of clusters
+        frame->n_clusters = nc;
+        if (counts)  // last kernel of the call: hand the frame counts to the caller
+        {
+            counts += 4 * (size_t)blockIdx.z;
+            counts[0] = frame->n_ground;
+            counts[1] = frame->n_obstacle;
+            counts[2] = nc;
+            counts[3] = frame->status;
+        }
+    }
     if (i >= frame->n_obstacle)
         return;
     if (frame->nb_total > cap)
@@ -506,12 +565,13 @@ static uint32_t bits_for_count(uint32_t n)  // bits to hold values 0..n-1
     return b;
 }
 
-int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels)
+int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels, uint32_t *d_counts)
 {
     FrameState *frame = (FrameState *)ctx->frame.p;
     hipStream_t st = ctx->stream;
+    const FV fv = lpx_fv(ctx);
     if (m_max == 0)
-        return LPX_OK;
+        return d_counts ? lpx_write_counts(ctx, d_counts) : LPX_OK;
     int rc = lpx_kd_build(ctx, m_max);
     if (rc)
         return rc;
@@ -519,7 +579,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     if (rc)
         return rc;
 
-    const dim3 blk(256), grd((m_max + 255) / 256);
+    const dim3 blk(256), grd((m_max + 255) / 256, 1, ctx->cur_b);
     uint32_t *root = (uint32_t *)ctx->key_a.p, *iota = (uint32_t *)ctx->val_a.p;
     uint32_t *sroot = nullptr, *members = nullptr;
     uint32_t *cc_lo = (uint32_t *)ctx->cc_lo.p, *cc_hi = (uint32_t *)ctx->cc_hi.p;
@@ -527,12 +587,13 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     {
         StageTimer tm(ctx, ST_CC);
         hipLaunchKernelGGL(flatten_kernel, grd, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
-                           (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi);
+                           (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, fv.fs);
         rc = lpx_sort_pairs(ctx, root, (uint32_t *)ctx->key_b.p, iota, (uint32_t *)ctx->val_b.p, m_max,
                             &frame->n_obstacle, bits_for_count(m_max), &sroot, &members);
         if (rc)
             return rc;
-        hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, sroot, frame, cc_lo, cc_hi, (uint32_t *)ctx->rpos.p);
+        hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, sroot, frame, cc_lo, cc_hi, (uint32_t *)ctx->rpos.p,
+                           fv.fs);
     }
     {
         StageTimer tm(ctx, ST_REPLAY);
@@ -555,19 +616,21 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                 ctx->attr_replay = true;
             }
             const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: blocks pull components from a list
-            hipLaunchKernelGGL(replay_lds_kernel, dim3(rgrid), dim3(WAVE), lds, st, frame, cc_lo, cc_hi, members,
+            hipLaunchKernelGGL(replay_lds_kernel, dim3(rgrid, 1, ctx->cur_b), dim3(WAVE), lds, st, frame, cc_lo, cc_hi,
+                               members,
                                (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,
                                (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->nb_dist.p,
                                (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p,
                                (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb, frame,
-                               (const uint32_t *)ctx->rpos.p, (uint32_t *)ctx->dbg_buf);
+                               (const uint32_t *)ctx->rpos.p, (uint32_t *)ctx->dbg_buf, fv);
         }
         else
-            hipLaunchKernelGGL(replay_kernel, dim3((m_max + RP_WAVES - 1) / RP_WAVES), dim3(RP_WAVES * WAVE), 0, st,
+            hipLaunchKernelGGL(replay_kernel, dim3((m_max + RP_WAVES - 1) / RP_WAVES, 1, ctx->cur_b),
+                               dim3(RP_WAVES * WAVE), 0, st,
                                frame, cc_lo, cc_hi, members, (const uint32_t *)ctx->nb_off.p,
                                (const uint32_t *)ctx->nb_len.p, (const uint32_t *)ctx->nb_idx.p,
                                (const float *)ctx->nb_dist.p, (uint8_t *)ctx->state.p, (int32_t *)ctx->seed_of.p,
-                               (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb);
+                               (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb, fv);
     }
     {
         StageTimer tm(ctx, ST_LABELS);
@@ -577,7 +640,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         if (rc)
             return rc;
         hipLaunchKernelGGL(relabel_kernel, grd, blk, 0, st, frame, (const int32_t *)ctx->seed_of.p, valid, dense,
-                           d_labels, ctx->cap_nb, (const uint64_t *)total);
+                           d_labels, ctx->cap_nb, (const uint64_t *)total, d_counts, fv);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;

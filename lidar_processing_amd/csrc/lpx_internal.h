@@ -44,7 +44,7 @@ struct FrameState
     uint32_t root_cursor; // work queue head of the replay
     uint64_t replay_entries;  // neighbour entries read by the replay (lists of expanded points)
     uint32_t n_expansions;    // radius_search calls the reference would have made
-    uint32_t pad;
+    uint32_t n_in;            // points of the input cloud of this frame slot
 };
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
@@ -67,6 +67,28 @@ struct Buf
     size_t bytes = 0;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Frame batching.  A context owns `batch` identical frame slots.  Every internal buffer is a
+// sub-range of ONE arena per slot, so slot b of any buffer is at (char *)buf.p + b * fstride (the
+// neighbour lists live in a second arena with stride nb_fstride so they can grow on their own).
+// A launch covers the slots of a call with gridDim.z; caller-provided arrays are pitched by
+// `upitch` elements per frame.  With one frame everything is offset 0.
+// ------------------------------------------------------------------------------------------------
+#define LPX_SORT_TILE 2048u  // keys per radix-sort block (lpx_primitives.hip)
+
+struct FV
+{
+    size_t fs;        // bytes between the slots of the frame arena
+    size_t fs_nb;     // bytes between the slots of the neighbour arena
+    uint32_t upitch;  // elements between the frames of caller arrays
+    uint32_t pad;
+};
+
+struct NArr
+{
+    uint32_t v[LPX_MAX_BATCH];
+};
+
 struct lpx_ctx
 {
     int device = 0;
@@ -74,9 +96,14 @@ struct lpx_ctx
     bool own_stream = false;
     char err[512] = {0};
 
-    uint32_t cap_n = 0;        // points
-    uint64_t cap_nb = 0;       // neighbour entries
+    uint32_t cap_n = 0;        // points per frame slot
+    uint64_t cap_nb = 0;       // neighbour entries per frame slot
     uint32_t nb_per_point = 256;
+    uint32_t batch = 1;        // frame slots
+    uint32_t cur_b = 1;        // frames of the call being enqueued (gridDim.z)
+    uint32_t upitch = 0;       // pitch of the caller arrays of that call
+    void *arena = nullptr, *nb_arena = nullptr;
+    size_t fstride = 0, nb_fstride = 0;
 
     // ---- segmentation buffers (cap_n) ----
     Buf in_aos;                // staging for host input
@@ -126,6 +153,16 @@ struct lpx_ctx
     int n_pending = 0, cap_pending = 0;
 };
 
+static inline FV lpx_fv(const lpx_ctx *ctx)
+{
+    FV fv;
+    fv.fs = ctx->fstride;
+    fv.fs_nb = ctx->nb_fstride;
+    fv.upitch = ctx->upitch;
+    fv.pad = 0;
+    return fv;
+}
+
 int lpx_fail(lpx_ctx *ctx, int code, const char *fmt, ...);
 int lpx_ensure(lpx_ctx *ctx, Buf &b, size_t bytes);
 int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb);
@@ -155,7 +192,8 @@ struct StageTimer
 // (function copies if the pass count is odd).  n is a host upper bound; d_n (optional) the device count.
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
                    const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out);
-int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, uint32_t bits, uint64_t **keys_out);
+int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, const uint32_t *d_n, uint32_t bits,
+                    uint64_t **keys_out);
 // exclusive scan (u32 in, u32 out, in place allowed); total (u64) written to *d_total if not null.
 int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n,
                        uint64_t *d_total);
@@ -163,12 +201,17 @@ int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t
 // ------------------------------------------------------------------------------------------------
 // pipeline stages
 // ------------------------------------------------------------------------------------------------
-int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
+int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32_t *n_points, const lpx_seg_cfg *cfg,
                     uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes);
-// clustering of the obstacle SoA already in ctx->OX/OY/OZ, count in frame->n_obstacle (bound m_max)
-int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels);
+// clustering of the obstacle SoA already in ctx->OX/OY/OZ, count in frame->n_obstacle (bound m_max);
+// d_counts (optional) receives {n_ground, n_obstacle, n_clusters, status} from the last kernel
+int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels, uint32_t *d_counts);
 // AoS (device) -> ctx->OX/OY/OZ, sets frame->n_obstacle = m
 int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m);
+// resets the FrameState of every slot of the call and stores the per-frame input sizes
+int lpx_frame_init(lpx_ctx *ctx, const uint32_t *n_points, bool as_obstacles);
+// {n_ground, n_obstacle, n_clusters, status} of every slot -> caller array (4 words per frame)
+int lpx_write_counts(lpx_ctx *ctx, uint32_t *d_counts);
 
 // CSR of the valid clusters from d_labels (m entries): d_offsets[n_clusters + 1], d_indices[n_valid]
 int lpx_run_groups(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets, uint32_t *d_indices);
@@ -182,6 +225,19 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook);
 #ifdef __HIPCC__
 
 #define WAVE 64
+
+// slot `blockIdx.z` of an arena buffer (null stays null)
+template <class T>
+__device__ __forceinline__ T *lpx_slot(T *p, size_t stride_bytes)
+{
+    return p ? (T *)((char *)p + (size_t)blockIdx.z * stride_bytes) : p;
+}
+// frame `blockIdx.z` of a caller array pitched by `pitch` elements
+template <class T>
+__device__ __forceinline__ T *lpx_user(T *p, uint32_t pitch)
+{
+    return p ? p + (size_t)blockIdx.z * pitch : p;
+}
 
 // order-preserving key of a float under operator< with -0 == +0 (ties are broken by index later)
 __device__ __forceinline__ uint32_t lpx_float_key(float f)

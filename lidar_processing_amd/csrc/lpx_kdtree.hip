@@ -481,9 +481,14 @@ constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree o
 
 // one workgroup per range of `level`: std::nth_element(b, mid, e) on axis level % 3
 __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
-                                                          const FrameState *__restrict__ frame, int level)
+                                                          const FrameState *__restrict__ frame, int level,
+                                                          size_t fs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    nodes = lpx_slot(nodes, fs);
+    lpos = lpx_slot(lpos, fs);
+    rasc = lpx_slot(rasc, fs);
+    frame = lpx_slot(frame, fs);
     Node *l_nodes = (Node *)smem;
     uint32_t *l_lp = (uint32_t *)(smem + sizeof(Node) * BLK_CAP);
     uint32_t *l_ra = l_lp + BLK_CAP;
@@ -620,8 +625,11 @@ constexpr int LG = 256;  // threads of kd_lds_kernel: one wavefront per SIMD, li
 
 __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restrict__ PR,
                                                     const FrameState *__restrict__ frame,
-                                                    uint32_t *__restrict__ dbg)
+                                                    uint32_t *__restrict__ dbg, size_t fs)
 {
+    nodes = lpx_slot(nodes, fs);
+    PR = lpx_slot(PR, fs);
+    frame = lpx_slot(frame, fs);
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t n_rounds = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1041,9 +1049,16 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                                                                uint32_t *__restrict__ nb_idx,
                                                                float *__restrict__ nb_dist, uint64_t cap,
                                                                uint32_t *__restrict__ parent,
-                                                               uint32_t *__restrict__ dbg)
+                                                               uint32_t *__restrict__ dbg, FV fv)
 {
     __shared__ Item s_seq[NB_SEQ];
+    PR = lpx_slot(PR, fv.fs);
+    frame = lpx_slot(frame, fv.fs);
+    len = lpx_slot(len, fv.fs);
+    off = lpx_slot(off, fv.fs);
+    parent = lpx_slot(parent, fv.fs);
+    nb_idx = lpx_slot(nb_idx, fv.fs_nb);
+    nb_dist = lpx_slot(nb_dist, fv.fs_nb);
     __shared__ uint32_t s_pre[NB_SEQ / 2 + 8 * NB_WAVES];
     __shared__ Node s_tile[NB_NODES];
     __shared__ float s_cbox[NB_NODES / WAVE][6];
@@ -1375,8 +1390,10 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
 // connected components of the d-graph.  The neighbour kernel has already put every point under its
 // smallest neighbour; cc_flatten_kernel points everybody at the current root, then one wavefront per
 // list checks every edge: equal roots (the common case) cost one cached load, the rest are united.
-__global__ void cc_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *parent)
+__global__ void cc_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *parent, size_t fs)
 {
+    frame = lpx_slot(frame, fs);
+    parent = lpx_slot(parent, fs);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= frame->n_obstacle)
         return;
@@ -1393,8 +1410,13 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
                                                        const uint32_t *__restrict__ off,
                                                        const uint32_t *__restrict__ len,
                                                        const uint32_t *__restrict__ nb_idx, uint32_t *parent,
-                                                       uint64_t cap)
+                                                       uint64_t cap, FV fv)
 {
+    frame = lpx_slot(frame, fv.fs);
+    off = lpx_slot(off, fv.fs);
+    len = lpx_slot(len, fv.fs);
+    parent = lpx_slot(parent, fv.fs);
+    nb_idx = lpx_slot(nb_idx, fv.fs_nb);
     const uint32_t lane = threadIdx.x % WAVE;
     const uint32_t M = frame->n_obstacle;
     if (frame->nb_total > cap)
@@ -1458,14 +1480,13 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     uint32_t size = m_max;
     while (size > (uint32_t)BLK_CAP)
     {
-        hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level), dim3(BLK_G), blk_lds, ctx->stream, nodes, lpos, rasc,
-                           frame, level);
+        hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G), blk_lds, ctx->stream, nodes,
+                           lpos, rasc, frame, level, ctx->fstride);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
-    hipLaunchKernelGGL(kd_lds_kernel, dim3(1u << level), dim3(LG), blk_lds, ctx->stream, nodes,
-                       (Node *)ctx->nodes_pre.p, frame,
-                       (uint32_t *)ctx->dbg_buf);
+    hipLaunchKernelGGL(kd_lds_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(LG), blk_lds, ctx->stream, nodes,
+                       (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, ctx->fstride);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
@@ -1489,20 +1510,21 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
         // The device derives the bucket level from the real point count, which may be lower than the
         // host's bound; surplus blocks return at once.
         const uint32_t nbk = groups / 2;
-        hipLaunchKernelGGL(nb_group_kernel, dim3(nbk + (nbk + NB_WAVES - 1) / NB_WAVES), dim3(NB_THREADS), 0,
-                           ctx->stream, (const Node *)PR, frame, r2, rr, len, off, (uint32_t *)ctx->nb_idx.p,
-                           (float *)ctx->nb_dist.p, ctx->cap_nb,
-                           hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf);
+        hipLaunchKernelGGL(nb_group_kernel, dim3(nbk + (nbk + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b),
+                           dim3(NB_THREADS), 0, ctx->stream, (const Node *)PR, frame, r2, rr, len, off,
+                           (uint32_t *)ctx->nb_idx.p, (float *)ctx->nb_dist.p, ctx->cap_nb,
+                           hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf,
+                           lpx_fv(ctx));
     }
     if (hook)
     {
         StageTimer tm(ctx, ST_NB_SCAN);
-        hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256), dim3(256), 0, ctx->stream, frame,
-                           (uint32_t *)ctx->parent.p);
+        hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
+                           (uint32_t *)ctx->parent.p, ctx->fstride);
         const uint32_t hgrid = (m_max + 3) / 4 < 4096u ? (m_max + 3) / 4 : 4096u;
-        hipLaunchKernelGGL(cc_hook_kernel, dim3(hgrid), dim3(256), 0, ctx->stream, frame,
+        hipLaunchKernelGGL(cc_hook_kernel, dim3(hgrid, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
                            (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
-                           (uint32_t *)ctx->parent.p, ctx->cap_nb);
+                           (uint32_t *)ctx->parent.p, ctx->cap_nb, lpx_fv(ctx));
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;

@@ -15,6 +15,7 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_WAVES = SORT_THREADS / WAVE;
 constexpr int SORT_ITEMS = 8;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
+static_assert(SORT_TILE == (int)LPX_SORT_TILE, "the arena sizes the histogram table with LPX_SORT_TILE");
 constexpr int RADIX = 256;
 
 // Histogram of one digit per tile.  With `ticket` set, the last block to finish also turns the whole
@@ -23,10 +24,15 @@ constexpr int RADIX = 256;
 template <typename KeyT>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__restrict__ keys, uint32_t n_max,
                                                                    const uint32_t *__restrict__ d_n, uint32_t shift,
-                                                                   uint32_t *hist, uint32_t nblocks, uint32_t *ticket)
+                                                                   uint32_t *hist, uint32_t nblocks, uint32_t *ticket,
+                                                                   size_t fs)
 {
     __shared__ uint32_t h[RADIX];
     __shared__ uint32_t s_last;
+    keys = lpx_slot(keys, fs);
+    d_n = lpx_slot(d_n, fs);
+    hist = lpx_slot(hist, fs);
+    ticket = lpx_slot(ticket, fs);
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     const uint32_t tid = threadIdx.x;
     h[tid] = 0;
@@ -124,9 +130,15 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
                                                                       uint32_t *__restrict__ vals_out, uint32_t n_max,
                                                                       const uint32_t *__restrict__ d_n, uint32_t shift,
                                                                       const uint32_t *__restrict__ offs,
-                                                                      uint32_t nblocks)
+                                                                      uint32_t nblocks, size_t fs)
 {
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
+    keys_in = lpx_slot(keys_in, fs);
+    keys_out = lpx_slot(keys_out, fs);
+    vals_in = lpx_slot(vals_in, fs);
+    vals_out = lpx_slot(vals_out, fs);
+    d_n = lpx_slot(d_n, fs);
+    offs = lpx_slot(offs, fs);
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     const uint32_t tid = threadIdx.x;
     const uint32_t w = tid / WAVE, lane = tid % WAVE;
@@ -205,9 +217,13 @@ constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 
 // in == out is allowed (no __restrict__): every thread reads its inputs before it writes them
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint32_t *in, uint32_t *out, uint32_t n_max,
-                                                             const uint32_t *d_n, uint64_t *d_total)
+                                                             const uint32_t *d_n, uint64_t *d_total, size_t fs)
 {
     __shared__ uint32_t wsum[2][SCAN_GROUPS][SCAN_WAVES];
+    in = lpx_slot(in, fs);
+    out = lpx_slot(out, fs);
+    d_n = lpx_slot(d_n, fs);
+    d_total = lpx_slot(d_total, fs);
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     unsigned long long carry = 0;
@@ -265,12 +281,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint32_t *in, 
         *d_total = carry;
 }
 
-__global__ void copy_u32_kernel(const uint32_t *__restrict__ a, uint32_t *__restrict__ b, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        b[i] = a[i];
-}
 }  // namespace
 
 static inline uint32_t sort_blocks(uint32_t n)
@@ -280,23 +290,21 @@ static inline uint32_t sort_blocks(uint32_t n)
 
 constexpr uint32_t FUSED_SCAN_MAX_BLOCKS = 128;
 
-// hist buffer: bytes [0,8) scan-total scratch, [32,36) the ticket of the fused scan, [64,...) the table
+// hist buffer: bytes [0,8) scan-total scratch, [32,36) the ticket of the fused scan (zero between launches),
+// [64,...) the table.  Sized with the frame arena (lpx_ensure_capacity).
 static int ensure_hist(lpx_ctx *ctx, uint32_t nblocks)
 {
     const size_t need = 64 + (size_t)RADIX * nblocks * sizeof(uint32_t) + 64;
     if (ctx->hist.bytes >= need && ctx->hist.p)
         return LPX_OK;
-    int rc = lpx_ensure(ctx, ctx->hist, need);
-    if (rc)
-        return rc;
-    LPX_HIP(ctx, hipMemsetAsync(ctx->hist.p, 0, 64, ctx->stream));  // the ticket starts at zero
-    return LPX_OK;
+    return lpx_fail(ctx, LPX_ERR_INTERNAL, "histogram table of %u blocks does not fit the workspace", nblocks);
 }
 
 int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n,
                        uint64_t *d_total)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, d_total);
+    hipLaunchKernelGGL(scan_kernel, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, d_total,
+                       ctx->fstride);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
@@ -311,15 +319,17 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     uint32_t *hist = (uint32_t *)((char *)ctx->hist.p + 64);
     uint32_t *ticket = (nblocks <= FUSED_SCAN_MAX_BLOCKS) ? (uint32_t *)((char *)ctx->hist.p + 32) : nullptr;
     uint32_t *ka = keys_a, *kb = keys_b, *va = vals_a, *vb = vals_b;
+    const uint32_t B = ctx->cur_b;
+    const size_t fs = ctx->fstride;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
-        hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
-                           d_n, shift, hist, nblocks, ticket);
+        hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
+                           d_n, shift, hist, nblocks, ticket, fs);
         if (!ticket)
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist, RADIX * nblocks,
-                               (const uint32_t *)nullptr, (uint64_t *)nullptr);
-        hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream,
-                           ka, kb, va, vb, n, d_n, shift, hist, nblocks);
+            hipLaunchKernelGGL(scan_kernel, dim3(1, 1, B), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist,
+                               RADIX * nblocks, (const uint32_t *)nullptr, (uint64_t *)nullptr, fs);
+        hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
+                           ctx->stream, ka, kb, va, vb, n, d_n, shift, hist, nblocks, fs);
         uint32_t *t = ka;
         ka = kb;
         kb = t;
@@ -333,7 +343,8 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     return LPX_OK;
 }
 
-int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, uint32_t bits, uint64_t **keys_out)
+int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, const uint32_t *d_n, uint32_t bits,
+                    uint64_t **keys_out)
 {
     const uint32_t nblocks = sort_blocks(n);
     int rc = ensure_hist(ctx, nblocks);
@@ -342,16 +353,18 @@ int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n
     uint32_t *hist = (uint32_t *)((char *)ctx->hist.p + 64);
     uint32_t *ticket = (nblocks <= FUSED_SCAN_MAX_BLOCKS) ? (uint32_t *)((char *)ctx->hist.p + 32) : nullptr;
     uint64_t *ka = keys_a, *kb = keys_b;
+    const uint32_t B = ctx->cur_b;
+    const size_t fs = ctx->fstride;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
-        hipLaunchKernelGGL((radix_hist_kernel<uint64_t>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
-                           (const uint32_t *)nullptr, shift, hist, nblocks, ticket);
+        hipLaunchKernelGGL((radix_hist_kernel<uint64_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
+                           d_n, shift, hist, nblocks, ticket, fs);
         if (!ticket)
-            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist, RADIX * nblocks,
-                               (const uint32_t *)nullptr, (uint64_t *)nullptr);
-        hipLaunchKernelGGL((radix_scatter_kernel<uint64_t, false>), dim3(nblocks), dim3(SORT_THREADS), 0, ctx->stream,
-                           ka, kb, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, (const uint32_t *)nullptr, shift,
-                           hist, nblocks);
+            hipLaunchKernelGGL(scan_kernel, dim3(1, 1, B), dim3(SCAN_THREADS), 0, ctx->stream, hist, hist,
+                               RADIX * nblocks, (const uint32_t *)nullptr, (uint64_t *)nullptr, fs);
+        hipLaunchKernelGGL((radix_scatter_kernel<uint64_t, false>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
+                           ctx->stream, ka, kb, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, d_n, shift, hist,
+                           nblocks, fs);
         uint64_t *t = ka;
         ka = kb;
         kb = t;

@@ -28,8 +28,8 @@ constexpr float FIX_LIMIT = 2048.0f;
 
 struct SegParams
 {
-    uint32_t n;        // points in the frame
-    uint32_t n_per;    // points per segment (n / P)
+    uint32_t n;        // points in the frame      } host values are the maximum over the frames of the
+    uint32_t n_per;    // points per segment (n / P) } call; kernels rebind both to their own frame
     uint32_t P;
     uint32_t I;
     uint32_t bps;      // blocks per segment
@@ -40,16 +40,68 @@ struct SegParams
     uint32_t n_lpr;
 };
 
+// per-frame sizes: the launch geometry (bps) comes from the largest frame of the call, the ranges
+// from the frame's own point count; blocks past the end of a short segment see an empty range
+__device__ __forceinline__ void seg_bind(SegParams &prm, const FrameState *frame)
+{
+    prm.n = frame->n_in;
+    prm.n_per = prm.n / prm.P;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame state reset + input sizes (first launch of every call), counts hand-over (last)
+// ------------------------------------------------------------------------------------------------
+__global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacles, size_t fs)
+{
+    frame = lpx_slot(frame, fs);
+    if (threadIdx.x == 0)
+    {
+        FrameState f;
+        f.n_ground = 0;
+        f.n_obstacle = as_obstacles ? n.v[blockIdx.z] : 0u;
+        f.n_clusters = 0;
+        f.status = 0;
+        f.nb_total = 0;
+        f.n_roots = 0;
+        f.root_cursor = 0;
+        f.replay_entries = 0;
+        f.n_expansions = 0;
+        f.n_in = n.v[blockIdx.z];
+        *frame = f;
+    }
+}
+
+__global__ void counts_kernel(const FrameState *frame, uint32_t *counts, size_t fs)
+{
+    frame = lpx_slot(frame, fs);
+    counts += 4 * (size_t)blockIdx.z;
+    if (threadIdx.x == 0)
+    {
+        counts[0] = frame->n_ground;
+        counts[1] = frame->n_obstacle;
+        counts[2] = frame->n_clusters;
+        counts[3] = frame->status;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K0 ingest: strided AoS -> SoA, x keys, iota; range check
 // ------------------------------------------------------------------------------------------------
-__global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, uint32_t n, float *__restrict__ X,
+__global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, float *__restrict__ X,
                               float *__restrict__ Y, float *__restrict__ Z, uint32_t *__restrict__ key,
                               uint32_t *__restrict__ val, FrameState *__restrict__ frame,
-                              float4 *__restrict__ nodes)
+                              float4 *__restrict__ nodes, FV fv)
 {
+    pts += (size_t)blockIdx.z * fv.upitch * stride;
+    X = lpx_slot(X, fv.fs);
+    Y = lpx_slot(Y, fv.fs);
+    Z = lpx_slot(Z, fv.fs);
+    key = lpx_slot(key, fv.fs);
+    val = lpx_slot(val, fv.fs);
+    frame = lpx_slot(frame, fv.fs);
+    nodes = lpx_slot(nodes, fv.fs);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    if (i >= frame->n_in)
         return;
     const float *p = (const float *)(pts + (size_t)i * stride);
     const float x = p[0], y = p[1], z = p[2];
@@ -73,8 +125,17 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, uint3
 __global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float *__restrict__ X,
                               const float *__restrict__ Y, const float *__restrict__ Z, float *__restrict__ XS,
                               float *__restrict__ YS, float *__restrict__ ZS, uint64_t *__restrict__ zkey,
-                              SegParams prm)
+                              SegParams prm, const FrameState *__restrict__ frame, size_t fs)
 {
+    sidx = lpx_slot(sidx, fs);
+    X = lpx_slot(X, fs);
+    Y = lpx_slot(Y, fs);
+    Z = lpx_slot(Z, fs);
+    XS = lpx_slot(XS, fs);
+    YS = lpx_slot(YS, fs);
+    ZS = lpx_slot(ZS, fs);
+    zkey = lpx_slot(zkey, fs);
+    seg_bind(prm, lpx_slot(frame, fs));
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= prm.n)
         return;
@@ -96,11 +157,17 @@ constexpr int SEED_LDS = 4096;
 
 __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__restrict__ zsorted, SegParams prm,
                                                             SegState *__restrict__ st, long long *__restrict__ acc,
-                                                            uint32_t *__restrict__ ticket, uint32_t *__restrict__ gen)
+                                                            uint32_t *__restrict__ ticket,
+                                                            const FrameState *__restrict__ frame, size_t fs)
 {
     __shared__ __attribute__((aligned(16))) float zbuf[SEED_LDS];
     __shared__ float s_sum;
     __shared__ uint32_t s_cut;
+    zsorted = lpx_slot(zsorted, fs);
+    st = lpx_slot(st, fs);
+    acc = lpx_slot(acc, fs);
+    ticket = lpx_slot(ticket, fs);
+    seg_bind(prm, lpx_slot(frame, fs));
     const uint32_t s = blockIdx.x;
     const uint32_t ns = prm.n_per;
     const uint64_t *zs = zsorted + (size_t)s * ns;
@@ -109,10 +176,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
     if (tid < LPX_ACC_WORDS)
         acc[s * LPX_ACC_WORDS + tid] = 0;
     if (tid == 0)
-    {
         ticket[s] = 0;
-        gen[s] = 0;
-    }
 
     // first index with z > z_floor (sorted ascending): upper bound
     if (tid == 0)
@@ -422,10 +486,20 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
                                                                   const float *__restrict__ ZS, SegParams prm,
                                                                   uint32_t t, SegState *st, long long *acc,
                                                                   uint32_t *ticket, uint8_t *__restrict__ flags,
-                                                                  uint32_t *__restrict__ blk_counts)
+                                                                  uint32_t *__restrict__ blk_counts,
+                                                                  const FrameState *__restrict__ frame, size_t fs)
 {
     __shared__ long long red[SEG_WAVES][LPX_ACC_WORDS];
     __shared__ uint32_t s_last;
+    XS = lpx_slot(XS, fs);
+    YS = lpx_slot(YS, fs);
+    ZS = lpx_slot(ZS, fs);
+    st = lpx_slot(st, fs);
+    acc = lpx_slot(acc, fs);
+    ticket = lpx_slot(ticket, fs);
+    flags = lpx_slot(flags, fs);
+    blk_counts = lpx_slot(blk_counts, fs);
+    seg_bind(prm, lpx_slot(frame, fs));
     const uint32_t s = blockIdx.y, b = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     const uint32_t seg_lo = s * prm.n_per;
@@ -607,43 +681,52 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
 }
 
 // ------------------------------------------------------------------------------------------------
-// All I+1 passes in ONE launch.  The blocks of a segment keep their points in registers (16 per thread,
-// read from HBM once), and between two passes they meet at a per-segment barrier: the last block to
-// arrive (ticket) solves plane t, publishes it write-through and bumps the segment's generation word;
-// the others poll that word.  Every exchanged word is an agent-scope atomic, so no L2 fence is needed.
-// Used when the whole grid is certainly co-resident (P * bps <= FUSED_MAX_BLOCKS); larger clouds take
-// the launch-per-pass path above.
+// All I+1 passes in ONE launch for segments of up to ONE_MAX_POINTS points: one workgroup of 1024
+// threads per segment keeps its points in registers (read from HBM once), reduces the moments through
+// LDS, lets one lane solve the 3x3 problem and broadcasts the plane through LDS.  Nothing leaves the CU
+// between passes and no workgroup ever waits for another one, so any number of frames can share the
+// device.  Per-block ground/obstacle counts are produced for the same SEG_CHUNK blocks the compaction
+// uses.  Larger segments take the launch-per-pass path above.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t FUSED_MAX_BLOCKS = 512;
-constexpr int PTS_PER_THREAD = SEG_CHUNK / SEG_THREADS;  // 16
+constexpr int ONE_THREADS = 1024;
+constexpr int ONE_WAVES = ONE_THREADS / WAVE;
+constexpr int ONE_PTS = 24;
+constexpr uint32_t ONE_MAX_POINTS = ONE_THREADS * ONE_PTS;  // 24576
+constexpr int ONE_CHUNKS = ONE_MAX_POINTS / SEG_CHUNK;      // 6
+constexpr int ONE_U_PER_CHUNK = SEG_CHUNK / ONE_THREADS;    // 4: point slot u of any thread lies in chunk u / 4
+static_assert(SEG_CHUNK % ONE_THREADS == 0, "chunk of a register slot must not depend on the thread");
 
-__global__ __launch_bounds__(SEG_THREADS) void plane_fused_kernel(const float *__restrict__ XS,
-                                                                   const float *__restrict__ YS,
-                                                                   const float *__restrict__ ZS, SegParams prm,
-                                                                   SegState *st, long long *acc, uint32_t *ticket,
-                                                                   uint32_t *gen, uint8_t *__restrict__ flags,
-                                                                   uint32_t *__restrict__ blk_counts)
+__global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *__restrict__ XS,
+                                                                    const float *__restrict__ YS,
+                                                                    const float *__restrict__ ZS, SegParams prm,
+                                                                    SegState *__restrict__ st,
+                                                                    uint8_t *__restrict__ flags,
+                                                                    uint32_t *__restrict__ blk_counts,
+                                                                    const FrameState *__restrict__ frame, size_t fs)
 {
-    __shared__ long long red[SEG_WAVES][LPX_ACC_WORDS];
-    __shared__ uint32_t s_last;
+    __shared__ long long red[ONE_WAVES][LPX_ACC_WORDS];
     __shared__ float s_plane[6];  // a, b, c, d, thr, failed
-    const uint32_t s = blockIdx.y, b = blockIdx.x;
+    XS = lpx_slot(XS, fs);
+    YS = lpx_slot(YS, fs);
+    ZS = lpx_slot(ZS, fs);
+    st = lpx_slot(st, fs);
+    flags = lpx_slot(flags, fs);
+    blk_counts = lpx_slot(blk_counts, fs);
+    seg_bind(prm, lpx_slot(frame, fs));
+    const uint32_t s = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
-    const uint32_t seg_lo = s * prm.n_per;
-    const uint32_t lo = seg_lo + b * prm.chunk;
-    const uint32_t hi = min(lo + prm.chunk, seg_lo + prm.n_per);
-
+    const uint32_t lo = s * prm.n_per, hi = lo + prm.n_per;
     const SegState sst = st[s];  // written by seed_kernel in the previous launch
     const bool skip = sst.failed == 2;
     const bool seeds_ok = sst.has_seeds != 0;
     bool dead = sst.failed != 0;
     float pa = 0.0f, pb = 0.0f, pc = 0.0f, pd = 0.0f, thr = 0.0f;
 
-    float xs[PTS_PER_THREAD], ys[PTS_PER_THREAD], zs[PTS_PER_THREAD];
+    float xs[ONE_PTS], ys[ONE_PTS], zs[ONE_PTS];
 #pragma unroll
-    for (int u = 0; u < PTS_PER_THREAD; ++u)
+    for (int u = 0; u < ONE_PTS; ++u)
     {
-        const uint32_t p = lo + tid + u * SEG_THREADS;
+        const uint32_t p = lo + tid + u * ONE_THREADS;
         const bool in = p < hi;
         xs[u] = in ? XS[p] : 0.0f;
         ys[u] = in ? YS[p] : 0.0f;
@@ -654,13 +737,19 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_fused_kernel(const float *_
     {
         const bool final_pass = (t == prm.I);
         long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
-        uint32_t cnt_g = 0, cnt_o = 0;
+        uint32_t cnt[ONE_CHUNKS];  // ground | obstacle << 16 per SEG_CHUNK block of the segment
 #pragma unroll
-        for (int u = 0; u < PTS_PER_THREAD; ++u)
+        for (int c = 0; c < ONE_CHUNKS; ++c)
+            cnt[c] = 0;
+#pragma unroll
+        for (int u = 0; u < ONE_PTS; ++u)
         {
-            const uint32_t p = lo + tid + u * SEG_THREADS;
+            const uint32_t p = lo + tid + u * ONE_THREADS;
             const bool in = p < hi;
-            const float x = xs[u], y = ys[u], z = zs[u];
+            float x = xs[u], y = ys[u], z = zs[u];
+            // keep the fixed-point conversions and products inside the pass: hoisted out of the t loop
+            // they would cost 15 more registers per point and this kernel is limited to 128
+            asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
             bool member;
             if (t == 0)
                 member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
@@ -674,10 +763,10 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_fused_kernel(const float *_
             {
                 if (in)
                 {
+                    // number_of_iterations == 0: seeds are ground, the rest stays UNKNOWN (:243-247)
                     const uint8_t f = skip ? 0 : (member ? 1 : ((prm.I == 0 && !dead) ? 0 : 2));
                     flags[p] = f;
-                    cnt_g += (f == 1);
-                    cnt_o += (f == 2);
+                    cnt[u / ONE_U_PER_CHUNK] += (f == 1 ? 1u : 0u) + (f == 2 ? 0x10000u : 0u);
                 }
             }
             else if (member)
@@ -699,31 +788,33 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_fused_kernel(const float *_
         }
         if (final_pass)
         {
-            cnt_g = lpx_wave_sum_u32(cnt_g);
-            cnt_o = lpx_wave_sum_u32(cnt_o);
-            if (lane == 0)
+#pragma unroll
+            for (int c = 0; c < ONE_CHUNKS; ++c)
             {
-                red[w][0] = cnt_g;
-                red[w][1] = cnt_o;
+                const uint32_t tot = lpx_wave_sum_u32(cnt[c]);  // <= 4 per lane: no carry into the high half
+                if (lane == 0)
+                    red[w][c] = tot;
             }
             __syncthreads();
-            if (tid == 0)
+            const uint32_t nb = prm.P * prm.bps;
+            if (tid < prm.bps && tid < (uint32_t)ONE_CHUNKS)
             {
                 uint32_t g = 0, o = 0;
-                for (int i = 0; i < SEG_WAVES; ++i)
+                for (int i = 0; i < ONE_WAVES; ++i)
                 {
-                    g += (uint32_t)red[i][0];
-                    o += (uint32_t)red[i][1];
+                    const uint32_t v = (uint32_t)red[i][tid];
+                    g += v & 0xffffu;
+                    o += v >> 16;
                 }
-                const uint32_t nb = prm.P * prm.bps;
-                blk_counts[s * prm.bps + b] = g;
-                blk_counts[nb + s * prm.bps + b] = o;
-                if (s == 0 && b == 0)
-                    blk_counts[2 * nb] = 0;
+                blk_counts[s * prm.bps + tid] = g;
+                blk_counts[nb + s * prm.bps + tid] = o;
             }
+            if (s == 0 && tid == 0)
+                blk_counts[2 * nb] = 0;  // sentinel: the exclusive scan leaves the grand total here
             return;
         }
 
+        // 16 words: n, sx, sy, sz, then (hi, lo) limbs of the six second moments
         long long v[LPX_ACC_WORDS];
         v[0] = a_n;
         v[1] = a_x;
@@ -748,72 +839,56 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_fused_kernel(const float *_
         {
             long long tot = 0;
 #pragma unroll
-            for (int i = 0; i < SEG_WAVES; ++i)
+            for (int i = 0; i < ONE_WAVES; ++i)
                 tot += red[i][tid];
-            if (tot != 0)
-                atomicAdd((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], (unsigned long long)tot);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // adds performed before the ticket (see plane_pass_kernel)
+            red[0][tid] = tot;  // only thread tid touches column tid of row 0 in this phase
         }
         __syncthreads();
         if (tid == 0)
-            s_last = (atomicAdd(&ticket[s], 1u) == prm.bps - 1) ? 1u : 0u;
-        __syncthreads();
-        if (s_last)
         {
-            if (tid < LPX_ACC_WORDS)
+            long long m[LPX_ACC_WORDS];
+            for (int i = 0; i < LPX_ACC_WORDS; ++i)
+                m[i] = red[0][i];
+            float plane[4] = {pa, pb, pc, pd};
+            float nthr = thr;
+            uint32_t failed = dead ? (skip ? 2u : 1u) : 0u;
+            bool fitted = false;
+            if (!dead)
             {
-                red[0][tid] = (long long)atomicExch((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], 0ull);
-                if (tid == 0)
-                    atomicExch(&ticket[s], 0u);
+                // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
+                if (!plane_from_moments(m, plane))
+                    failed = 1;
+                else
+                {
+                    nthr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
+                    fitted = true;
+                }
             }
-            __syncthreads();
-            if (tid == 0)
+            SegState *o = st + s;
+            if (fitted)
             {
-                long long m[LPX_ACC_WORDS];
-                for (int i = 0; i < LPX_ACC_WORDS; ++i)
-                    m[i] = red[0][i];
-                float plane[4] = {pa, pb, pc, pd};
-                float nthr = thr;
-                uint32_t failed = dead ? (skip ? 2u : 1u) : 0u;
-                uint32_t fitted = 0;
-                if (!dead)
-                {
-                    if (!plane_from_moments(m, plane))
-                        failed = 1;
-                    else
-                    {
-                        nthr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
-                        fitted = 1;
-                    }
-                }
-                // publish write-through, then release the generation word
-                SegState *o = st + s;
-                if (fitted)
-                {
-                    __hip_atomic_store(&o->plane[0], plane[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&o->plane[1], plane[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&o->plane[2], plane[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&o->plane[3], plane[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&o->thr, nthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&o->fitted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(&o->failed, failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&gen[s], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                o->plane[0] = plane[0];
+                o->plane[1] = plane[1];
+                o->plane[2] = plane[2];
+                o->plane[3] = plane[3];
+                o->thr = nthr;
+                o->fitted = 1u;
+                s_plane[0] = plane[0];
+                s_plane[1] = plane[1];
+                s_plane[2] = plane[2];
+                s_plane[3] = plane[3];
+                s_plane[4] = nthr;
             }
-        }
-        // per-segment barrier: wait for plane t
-        if (tid == 0)
-        {
-            while (__hip_atomic_load(&gen[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1)
-                __builtin_amdgcn_s_sleep(2);
-            const SegState *o = st + s;
-            s_plane[0] = __hip_atomic_load(&o->plane[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_plane[1] = __hip_atomic_load(&o->plane[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_plane[2] = __hip_atomic_load(&o->plane[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_plane[3] = __hip_atomic_load(&o->plane[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_plane[4] = __hip_atomic_load(&o->thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_plane[5] = __uint_as_float(__hip_atomic_load(&o->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            else
+            {
+                s_plane[0] = pa;
+                s_plane[1] = pb;
+                s_plane[2] = pc;
+                s_plane[3] = pd;
+                s_plane[4] = thr;
+            }
+            o->failed = failed;
+            s_plane[5] = __uint_as_float(failed);
         }
         __syncthreads();
         pa = s_plane[0];
@@ -841,9 +916,26 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
                                                                float *__restrict__ OX, float *__restrict__ OY,
                                                                float *__restrict__ OZ, float4 *__restrict__ nodes,
                                                                const SegState *__restrict__ st,
-                                                               float *__restrict__ planes, FrameState *frame)
+                                                               float *__restrict__ planes, FrameState *frame, FV fv)
 {
     __shared__ uint32_t wg[SEG_WAVES], wo[SEG_WAVES];
+    flags = lpx_slot(flags, fv.fs);
+    sidx = lpx_slot(sidx, fv.fs);
+    XS = lpx_slot(XS, fv.fs);
+    YS = lpx_slot(YS, fv.fs);
+    ZS = lpx_slot(ZS, fv.fs);
+    blk_offs = lpx_slot(blk_offs, fv.fs);
+    OX = lpx_slot(OX, fv.fs);
+    OY = lpx_slot(OY, fv.fs);
+    OZ = lpx_slot(OZ, fv.fs);
+    nodes = lpx_slot(nodes, fv.fs);
+    st = lpx_slot(st, fv.fs);
+    frame = lpx_slot(frame, fv.fs);
+    labels = lpx_user(labels, fv.upitch);
+    gidx = lpx_user(gidx, fv.upitch);
+    oidx = lpx_user(oidx, fv.upitch);
+    planes = lpx_user(planes, 4u * prm.P);
+    seg_bind(prm, frame);
     const uint32_t s = blockIdx.y, b = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     const uint32_t nb = prm.P * prm.bps;
@@ -969,6 +1061,25 @@ static uint32_t bits_for(uint32_t v)  // number of bits needed to represent valu
     return b ? b : 1;
 }
 
+int lpx_frame_init(lpx_ctx *ctx, const uint32_t *n_points, bool as_obstacles)
+{
+    NArr na;
+    for (uint32_t b = 0; b < LPX_MAX_BATCH; ++b)
+        na.v[b] = b < ctx->cur_b ? n_points[b] : 0u;
+    hipLaunchKernelGGL(frame_init_kernel, dim3(1, 1, ctx->cur_b), dim3(WAVE), 0, ctx->stream, (FrameState *)ctx->frame.p,
+                       na, as_obstacles ? 1u : 0u, ctx->fstride);
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+int lpx_write_counts(lpx_ctx *ctx, uint32_t *d_counts)
+{
+    hipLaunchKernelGGL(counts_kernel, dim3(1, 1, ctx->cur_b), dim3(WAVE), 0, ctx->stream,
+                       (const FrameState *)ctx->frame.p, d_counts, ctx->fstride);
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
 // plane of ALL n points (stride-12 device input) through the moment + Jacobi path; out[0..3] plane, out[4] failed
 int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
 {
@@ -988,13 +1099,18 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
     SegState *sst = (SegState *)ctx->seg_state.p;
     long long *acc = (long long *)ctx->seg_acc.p;
     uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
-    LPX_HIP(ctx, hipMemsetAsync(frame, 0, sizeof(FrameState), ctx->stream));
+    const FV fv = lpx_fv(ctx);
+    int rc = lpx_frame_init(ctx, &n, false);
+    if (rc)
+        return rc;
     if (n)
         hipLaunchKernelGGL(ingest_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const char *)d_pts,
-                           (size_t)12, n, XS, YS, ZS, (uint32_t *)nullptr, (uint32_t *)nullptr, frame, (float4 *)nullptr);
+                           (size_t)12, XS, YS, ZS, (uint32_t *)nullptr, (uint32_t *)nullptr, frame, (float4 *)nullptr,
+                           fv);
     hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, acc, ticket);
     hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
-                       0u, sst, acc, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr);
+                       0u, sst, acc, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr, (const FrameState *)frame,
+                       fv.fs);
     hipLaunchKernelGGL(dbg_plane_out_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, d_out);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
@@ -1003,18 +1119,21 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
 int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m)
 {
     FrameState *frame = (FrameState *)ctx->frame.p;
+    int rc = lpx_frame_init(ctx, &m, true);
+    if (rc)
+        return rc;
     if (m)
     {
         hipLaunchKernelGGL(ingest_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (const char *)d_pts,
-                           stride, m, (float *)ctx->OX.p, (float *)ctx->OY.p, (float *)ctx->OZ.p,
-                           (uint32_t *)nullptr, (uint32_t *)nullptr, frame, (float4 *)ctx->nodes.p);
+                           stride, (float *)ctx->OX.p, (float *)ctx->OY.p, (float *)ctx->OZ.p, (uint32_t *)nullptr,
+                           (uint32_t *)nullptr, frame, (float4 *)ctx->nodes.p, lpx_fv(ctx));
     }
-    LPX_HIP(ctx, hipMemcpyAsync(&frame->n_obstacle, &m, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
 
-int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
+// n_points: the point count of every frame of the call (ctx->cur_b entries)
+int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32_t *n_points, const lpx_seg_cfg *cfg,
                     uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes)
 {
     FrameState *frame = (FrameState *)ctx->frame.p;
@@ -1024,11 +1143,22 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
         return lpx_fail(ctx, LPX_ERR_ARG, "partitions must be 1..%u and iterations 0..%u", LPX_MAX_PARTITIONS,
                         LPX_MAX_ITERATIONS);
     hipStream_t st = ctx->stream;
-    LPX_HIP(ctx, hipMemsetAsync(frame, 0, sizeof(FrameState), st));
-    if (d_planes && n / P == 0)  // no segment gets a point: nothing else writes the planes
+    const uint32_t B = ctx->cur_b;
+    const FV fv = lpx_fv(ctx);
+    uint32_t n = 0;  // the largest frame sizes every launch; kernels use their own frame's count
+    for (uint32_t b = 0; b < B; ++b)
+        n = n_points[b] > n ? n_points[b] : n;
+    int rc = lpx_frame_init(ctx, n_points, false);
+    if (rc)
+        return rc;
+    if (B == 1 && d_planes && n / P == 0)  // no segment gets a point: nothing else writes the planes
         LPX_HIP(ctx, hipMemsetAsync(d_planes, 0, sizeof(float) * 4 * P, st));
     if (n == 0)
+    {
+        if (B > 1 && d_planes)
+            LPX_HIP(ctx, hipMemsetAsync(d_planes, 0, sizeof(float) * 4 * P * B, st));
         return LPX_OK;
+    }
 
     SegParams prm;
     prm.n = n;
@@ -1044,66 +1174,67 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
 
     float *X = (float *)ctx->X.p, *Y = (float *)ctx->Y.p, *Z = (float *)ctx->Z.p;
     float *XS = (float *)ctx->XS.p, *YS = (float *)ctx->YS.p, *ZS = (float *)ctx->ZS.p;
-    const dim3 blk(256), grd((n + 255) / 256);
+    const dim3 blk(256), grd((n + 255) / 256, 1, B);
 
     {
         StageTimer tm(ctx, ST_INGEST);
-        hipLaunchKernelGGL(ingest_kernel, grd, blk, 0, st, (const char *)d_pts, stride, n, X, Y, Z,
-                           (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->val_a.p, frame, (float4 *)nullptr);
+        hipLaunchKernelGGL(ingest_kernel, grd, blk, 0, st, (const char *)d_pts, stride, X, Y, Z,
+                           (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->val_a.p, frame, (float4 *)nullptr, fv);
     }
     uint32_t *skeys = nullptr, *sidx = nullptr;
     {
         StageTimer tm(ctx, ST_XSORT);
-        int rc = lpx_sort_pairs(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_b.p, (uint32_t *)ctx->val_a.p,
-                                (uint32_t *)ctx->val_b.p, n, nullptr, 32, &skeys, &sidx);
+        rc = lpx_sort_pairs(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_b.p, (uint32_t *)ctx->val_a.p,
+                            (uint32_t *)ctx->val_b.p, n, &frame->n_in, 32, &skeys, &sidx);
         if (rc)
             return rc;
     }
-    if (prm.n_per == 0)
+    if (B == 1 && prm.n_per == 0)
     {
         // fewer points than partitions: no segment holds a point, every label is UNKNOWN
-        hipLaunchKernelGGL(fill_u32_kernel, grd, blk, 0, st, d_labels, LPX_LABEL_UNKNOWN, n);
+        hipLaunchKernelGGL(fill_u32_kernel, dim3((n + 255) / 256), blk, 0, st, d_labels, LPX_LABEL_UNKNOWN, n);
         LPX_HIP(ctx, hipGetLastError());
         return LPX_OK;
     }
     {
         StageTimer tm(ctx, ST_GATHER);
-        hipLaunchKernelGGL(gather_kernel, grd, blk, 0, st, sidx, X, Y, Z, XS, YS, ZS, (uint64_t *)ctx->key64_a.p, prm);
+        hipLaunchKernelGGL(gather_kernel, grd, blk, 0, st, sidx, X, Y, Z, XS, YS, ZS, (uint64_t *)ctx->key64_a.p, prm,
+                           (const FrameState *)frame, fv.fs);
     }
     uint64_t *zsorted = nullptr;
     {
         StageTimer tm(ctx, ST_ZSORT);
-        int rc = lpx_sort_keys64(ctx, (uint64_t *)ctx->key64_a.p, (uint64_t *)ctx->key64_b.p, n, 32 + bits_for(P),
-                                 &zsorted);
+        rc = lpx_sort_keys64(ctx, (uint64_t *)ctx->key64_a.p, (uint64_t *)ctx->key64_b.p, n, &frame->n_in,
+                             32 + bits_for(P), &zsorted);
         if (rc)
             return rc;
     }
     SegState *sst = (SegState *)ctx->seg_state.p;
     long long *acc = (long long *)ctx->seg_acc.p;
     uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
-    uint32_t *gen = ticket + LPX_MAX_PARTITIONS;
     {
         StageTimer tm(ctx, ST_SEEDS);
-        hipLaunchKernelGGL(seed_kernel, dim3(P), dim3(SEG_THREADS), 0, st, zsorted, prm, sst, acc, ticket, gen);
+        hipLaunchKernelGGL(seed_kernel, dim3(P, 1, B), dim3(SEG_THREADS), 0, st, zsorted, prm, sst, acc, ticket,
+                           (const FrameState *)frame, fv.fs);
     }
     const uint32_t nb = P * prm.bps;
-    int rc = lpx_ensure(ctx, ctx->blk_counts, sizeof(uint32_t) * (2 * (size_t)nb + 2));
-    if (rc)
-        return rc;
+    if (sizeof(uint32_t) * (2 * (size_t)nb + 2) > ctx->blk_counts.bytes)
+        return lpx_fail(ctx, LPX_ERR_INTERNAL, "block count table of %u blocks does not fit the workspace", nb);
     uint32_t *blk_counts = (uint32_t *)ctx->blk_counts.p;
     {
         StageTimer tm(ctx, ST_PLANE);
-        const dim3 g2(prm.bps, P);
-        if (P * prm.bps <= FUSED_MAX_BLOCKS)
-            hipLaunchKernelGGL(plane_fused_kernel, g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, sst, acc, ticket, gen,
-                               (uint8_t *)ctx->flags.p, blk_counts);
+        if (prm.n_per <= ONE_MAX_POINTS)
+            hipLaunchKernelGGL(plane_single_kernel, dim3(P, 1, B), dim3(ONE_THREADS), 0, st, XS, YS, ZS, prm, sst,
+                               (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
         else
-        for (uint32_t t = 0; t < I; ++t)
-            hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, t, sst, acc,
-                               ticket, (uint8_t *)ctx->flags.p, blk_counts);
-        if (P * prm.bps > FUSED_MAX_BLOCKS)
+        {
+            const dim3 g2(prm.bps, P, B);
+            for (uint32_t t = 0; t < I; ++t)
+                hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, t, sst, acc,
+                                   ticket, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
             hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, I, sst, acc,
-                               ticket, (uint8_t *)ctx->flags.p, blk_counts);
+                               ticket, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
+        }
     }
     {
         StageTimer tm(ctx, ST_COMPACT);
@@ -1111,9 +1242,9 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n, 
         rc = lpx_exclusive_scan(ctx, blk_counts, blk_counts, 2 * nb + 1, nullptr, nullptr);
         if (rc)
             return rc;
-        hipLaunchKernelGGL(compact_kernel, dim3(prm.bps, P), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p,
+        hipLaunchKernelGGL(compact_kernel, dim3(prm.bps, P, B), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p,
                            sidx, XS, YS, ZS, prm, blk_counts, d_labels, d_gidx, d_oidx, (float *)ctx->OX.p,
-                           (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p, sst, d_planes, frame);
+                           (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p, sst, d_planes, frame, fv);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;

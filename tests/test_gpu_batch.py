@@ -1,0 +1,189 @@
+"""GPU parity tests of the device-resident entry points and of the multi-frame launch chain
+(lpx_segment_cluster_device, lpx_segment_cluster_batch_device), through the C-ABI.
+
+Bar: every frame of a batch gets exactly what the single-frame path (itself checked against the oracle and
+the reference goldens in test_gpu_pipeline.py) returns for that frame: labels, index lists, plane words,
+cluster labels and counts, bit for bit; the oracle is compared directly as well."""
+import numpy as np
+import pytest
+
+import oracle
+from lidar_processing_amd import ClusteringConfiguration, Context, LpxError, SegmentationConfiguration
+from util import FRAMES, load_frame, synthetic_scene
+
+pytestmark = pytest.mark.gpu
+
+SEG = dict(number_of_planar_partitions=6, number_of_iterations=5)
+CLU = dict(distance_squared=0.25, cluster_quality=0.5)
+
+
+def run_batch(bctx, clouds, seg_kw, clu_kw, stride_floats=4):
+    """clouds: list of (n_i, >=3) float arrays -> list of per-frame result dicts (device API, pitched arrays)"""
+    import torch
+    dev = torch.device("cuda:0")
+    B = len(clouds)
+    pitch = max(1, max(c.shape[0] for c in clouds)) + 7
+    P = seg_kw.get("number_of_planar_partitions", 2)
+    host = np.zeros((B, pitch, stride_floats), np.float32)
+    for b, c in enumerate(clouds):
+        host[b, :c.shape[0], :min(stride_floats, c.shape[1])] = c[:, :stride_floats]
+    d_pts = torch.from_numpy(host).to(dev)
+    d_labels = torch.full((B, pitch), 0xdeadbeef, dtype=torch.int64, device=dev).to(torch.int32)
+    d_gidx = torch.zeros((B, pitch), dtype=torch.int32, device=dev)
+    d_oidx = torch.zeros((B, pitch), dtype=torch.int32, device=dev)
+    d_planes = torch.full((B, 4 * P), 7.0, dtype=torch.float32, device=dev)
+    d_clab = torch.full((B, pitch), -77, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    n = [c.shape[0] for c in clouds]
+    bctx.segment_cluster_batch_device(n, d_pts.data_ptr(), 4 * stride_floats, pitch, SegmentationConfiguration(**seg_kw),
+                                      ClusteringConfiguration(**clu_kw), d_labels.data_ptr(), d_gidx.data_ptr(),
+                                      d_oidx.data_ptr(), d_planes.data_ptr(), d_clab.data_ptr(), d_counts.data_ptr())
+    bctx.synchronize()
+    counts = d_counts.cpu().numpy().view(np.uint32)
+    out = []
+    for b in range(B):
+        ng, no, nc, status = (int(v) for v in counts[b])
+        out.append(dict(status=status, n_clusters=nc,
+                        labels=d_labels[b, :n[b]].cpu().numpy().view(np.uint32),
+                        ground_idx=d_gidx[b, :ng].cpu().numpy().view(np.uint32),
+                        obstacle_idx=d_oidx[b, :no].cpu().numpy().view(np.uint32),
+                        planes=d_planes[b].cpu().numpy().reshape(P, 4),
+                        cluster_labels=d_clab[b, :no].cpu().numpy(),
+                        tail_labels=d_clab[b, no:].cpu().numpy()))
+    return out
+
+
+def check_frame(res, ref):
+    assert res["status"] == 0
+    assert np.array_equal(res["labels"], ref["labels"])
+    assert np.array_equal(res["ground_idx"], ref["ground_idx"])
+    assert np.array_equal(res["obstacle_idx"], ref["obstacle_idx"])
+    assert np.array_equal(res["planes"].view(np.uint32), ref["planes"].view(np.uint32))
+    assert np.array_equal(res["cluster_labels"], ref["cluster_labels"])
+    assert res["n_clusters"] == ref["n_clusters"]
+    assert (res["tail_labels"] == -77).all(), "wrote past the obstacle count of the frame"
+
+
+def single(ctx, cloud, seg_kw, clu_kw):
+    return ctx.segment_cluster(cloud, SegmentationConfiguration(**seg_kw), ClusteringConfiguration(**clu_kw))
+
+
+def test_batch_of_real_frames_matches_single_frame_path_and_oracle(ctx):
+    clouds = [load_frame(f) for f in FRAMES] + [load_frame(FRAMES[0])[:50_000]]
+    bctx = Context(0, batch=4)
+    try:
+        res = run_batch(bctx, clouds, SEG, CLU)
+    finally:
+        bctx.close()
+    for c, r in zip(clouds, res):
+        check_frame(r, single(ctx, c, SEG, CLU))
+        o = oracle.segment(c, oracle.SegCfg(**SEG))
+        assert np.array_equal(r["labels"], o["labels"]) and np.array_equal(r["obstacle_idx"], o["obstacle_idx"])
+        oc_labels = oracle.cluster(c[o["obstacle_idx"]], oracle.CluCfg(**CLU))[0]
+        assert np.array_equal(r["cluster_labels"], oc_labels)
+
+
+@pytest.mark.parametrize("B", [1, 2, 7])
+def test_batch_ragged_frames(ctx, B):
+    """frames of very different sizes in one call, including an empty one and one with fewer points than
+    partitions (every label UNKNOWN, src/segmentation.cpp:104-149)"""
+    sizes = [30_000, 0, 3, 11_111, 4096 * 2 + 1, 64, 20_001][:B]
+    clouds = []
+    for i, n in enumerate(sizes):
+        if n >= 64:
+            clouds.append(synthetic_scene(n - n // 3, 8, max(1, (n // 3) // 8), seed=100 + i)[:n])
+        else:
+            clouds.append(synthetic_scene(64, 1, 8, seed=100 + i)[:n])
+    seg_kw = dict(number_of_planar_partitions=4, number_of_iterations=3)
+    clu_kw = dict(distance_squared=0.36, cluster_quality=0.3, min_cluster_size=3)
+    bctx = Context(0, batch=8)
+    try:
+        res = run_batch(bctx, clouds, seg_kw, clu_kw)
+        res2 = run_batch(bctx, clouds[::-1], seg_kw, clu_kw)[::-1]  # slots are reused with other sizes
+    finally:
+        bctx.close()
+    for c, r, r2 in zip(clouds, res, res2):
+        ref = single(ctx, c, seg_kw, clu_kw)
+        check_frame(r, ref)
+        check_frame(r2, ref)
+
+
+def test_batch_large_segments_take_the_pass_per_launch_path(ctx):
+    """segments above the single-workgroup limit (24576 points) in a batch"""
+    clouds = [synthetic_scene(120_000, 60, 500, seed=7), synthetic_scene(90_000, 40, 400, seed=8)]
+    seg_kw = dict(number_of_planar_partitions=2, number_of_iterations=3)
+    bctx = Context(0, batch=2)
+    try:
+        res = run_batch(bctx, clouds, seg_kw, CLU)
+    finally:
+        bctx.close()
+    for c, r in zip(clouds, res):
+        check_frame(r, single(ctx, c, seg_kw, CLU))
+
+
+def test_batch_stride_and_range_error_are_per_frame(ctx):
+    good = load_frame(FRAMES[1])[:20_000]
+    bad = good.copy()
+    bad[123, 1] = 5000.0  # outside the fixed-point range: that frame reports LPX_ERR_RANGE, the others are fine
+    bctx = Context(0, batch=3)
+    try:
+        res = run_batch(bctx, [good, bad, good], SEG, CLU, stride_floats=8)
+    finally:
+        bctx.close()
+    ref = single(ctx, good, SEG, CLU)
+    check_frame(res[0], ref)
+    check_frame(res[2], ref)
+    assert res[1]["status"] == 2  # -LPX_ERR_RANGE
+
+
+def test_batch_argument_errors(ctx):
+    bctx = Context(0, batch=2)
+    try:
+        with pytest.raises(LpxError):
+            run_batch(bctx, [load_frame(FRAMES[0])[:1000]] * 3, SEG, CLU)  # more frames than slots
+        res = run_batch(bctx, [load_frame(FRAMES[0])[:1000]] * 2, SEG, CLU)  # and the context still works
+        assert res[0]["status"] == 0
+    finally:
+        bctx.close()
+    with pytest.raises(LpxError):
+        Context(0, batch=65)
+
+
+def test_batch_context_serves_single_frame_entry_points(ctx):
+    c = load_frame(FRAMES[2])
+    bctx = Context(0, batch=3)
+    try:
+        a = single(bctx, c, SEG, CLU)
+    finally:
+        bctx.close()
+    b = single(ctx, c, SEG, CLU)
+    for k in ("labels", "ground_idx", "obstacle_idx", "cluster_labels"):
+        assert np.array_equal(a[k], b[k])
+
+
+def test_device_entry_point_matches_host_entry_point(ctx):
+    import torch
+    dev = torch.device("cuda:0")
+    c = load_frame(FRAMES[0])
+    n = c.shape[0]
+    d_pts = torch.from_numpy(c).to(dev)
+    d_labels = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_gidx = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_oidx = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_planes = torch.zeros(4 * 6, dtype=torch.float32, device=dev)
+    d_clab = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.segment_cluster_device(d_pts.data_ptr(), 16, n, SegmentationConfiguration(**SEG), ClusteringConfiguration(**CLU),
+                               d_labels.data_ptr(), d_gidx.data_ptr(), d_oidx.data_ptr(), d_planes.data_ptr(),
+                               d_clab.data_ptr(), d_counts.data_ptr())
+    ctx.synchronize()
+    ng, no, nc, status = (int(v) for v in d_counts.cpu().numpy().view(np.uint32))
+    ref = single(ctx, c, SEG, CLU)
+    assert status == 0 and nc == ref["n_clusters"]
+    assert np.array_equal(d_labels.cpu().numpy().view(np.uint32), ref["labels"])
+    assert np.array_equal(d_gidx[:ng].cpu().numpy().view(np.uint32), ref["ground_idx"])
+    assert np.array_equal(d_oidx[:no].cpu().numpy().view(np.uint32), ref["obstacle_idx"])
+    assert np.array_equal(d_clab[:no].cpu().numpy(), ref["cluster_labels"])
+    assert np.array_equal(d_planes.cpu().numpy().view(np.uint32).reshape(6, 4), ref["planes"].view(np.uint32))
