@@ -5,9 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (lpx_segment_cluster_device: Segmenter::segment followed by
-Clusterer::cluster with the obstacle cloud kept on the device) over one batch of frames whose points
-are already resident in HBM.  Workload = BASELINE.json configs[1]: real 120k-point KITTI frames
+A "step" is one pass of the hot path (lpx_segment_cluster_batch_device: Segmenter::segment followed by
+Clusterer::cluster with the obstacle cloud kept on the device, `--batch` frames per launch chain) over
+one batch of frames whose points are already resident in HBM.  Workload = BASELINE.json configs[1]: real 120k-point KITTI frames
 (tests/golden/frames.npz, bit-identical to the reference's data/*.pcd), 6 segments, 5 plane-fit
 iterations, FEC d = 0.5 m (distance_squared 0.25), quality 0.5.  Frames are independent, so with N
 GPUs every rank runs its own batch (frame i -> GPU i mod N, "weak" scaling) and there is no
@@ -109,9 +109,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=64, help="frames in one batch (per GPU)")
-    ap.add_argument("--contexts", type=int, default=32, help="concurrent lpx contexts (HIP streams) per GPU")
-    ap.add_argument("--threads", type=int, default=4, help="host threads that enqueue (ctypes releases the GIL)")
+    ap.add_argument("--frames-per-step", type=int, default=128, help="frames in one step (per GPU)")
+    ap.add_argument("--batch", type=int, default=16, help="frames per launch chain (lpx_segment_cluster_batch_device)")
+    ap.add_argument("--contexts", type=int, default=8, help="concurrent lpx contexts (HIP streams) per GPU")
+    ap.add_argument("--threads", type=int, default=2, help="host threads that enqueue (ctypes releases the GIL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,45 +136,47 @@ def main():
 
     scfg = SegmentationConfiguration(**SEG)
     ccfg = ClusteringConfiguration(**CLU)
+    P = SEG["number_of_planar_partitions"]
 
-    # ---- inputs: resident in HBM before the timed region (32-byte PointXYZI records) ----
+    # ---- inputs: resident in HBM before the timed region (32-byte PointXYZI records, one pitched array) ----
     host_frames = [load_frame(f) for f in FRAMES]
     F = args.frames_per_step
+    B = max(1, min(args.batch, F))
     my_ids = frame_ids_for_rank(rank, world, F, len(host_frames))
-    recs = []
-    for hf in host_frames:
-        rec = np.zeros((hf.shape[0], 8), np.float32)
-        rec[:, :4] = hf
-        recs.append(torch.from_numpy(rec).to(dev))
-    nmax = max(hf.shape[0] for hf in host_frames)
-    C = max(1, min(args.contexts, F))
-    ctxs = [Context(local_rank) for _ in range(C)]
+    pitch = max(hf.shape[0] for hf in host_frames)
+    host_in = np.zeros((F, pitch, 8), np.float32)
+    for j, fid in enumerate(my_ids):
+        host_in[j, :host_frames[fid].shape[0], :4] = host_frames[fid]
+    d_pts = torch.from_numpy(host_in).to(dev)
+    del host_in
+    n_points = np.array([host_frames[fid].shape[0] for fid in my_ids], np.uint32)
+    chains = [(k, min(k + B, F)) for k in range(0, F, B)]  # frames [lo, hi) of every launch chain
+    C = max(1, min(args.contexts, len(chains)))
+    ctxs = [Context(local_rank, batch=B) for _ in range(C)]
     for c in ctxs:
-        c.reserve(nmax)
-    outs = []
-    for _ in range(F):
-        outs.append(dict(labels=torch.empty(nmax, dtype=torch.int32, device=dev),
-                         gidx=torch.empty(nmax, dtype=torch.int32, device=dev),
-                         oidx=torch.empty(nmax, dtype=torch.int32, device=dev),
-                         planes=torch.empty(SEG["number_of_planar_partitions"] * 4, dtype=torch.float32, device=dev),
-                         clabels=torch.empty(nmax, dtype=torch.int32, device=dev),
-                         counts=torch.zeros(4, dtype=torch.int32, device=dev)))
-    points_per_step = sum(host_frames[i].shape[0] for i in my_ids)
+        c.reserve(pitch)
+    d_labels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
+    d_gidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
+    d_oidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
+    d_planes = torch.empty((F, 4 * P), dtype=torch.float32, device=dev)
+    d_clabels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros((F, 4), dtype=torch.int32, device=dev)
+    points_per_step = int(n_points.sum())
 
     import concurrent.futures
     T = max(1, min(args.threads, C))
     pool = concurrent.futures.ThreadPoolExecutor(T) if T > 1 else None
 
     def enqueue(tid):
-        # thread tid owns contexts tid, tid + T, ... and therefore frames j with (j % C) % T == tid
+        # thread tid owns contexts tid, tid + T, ... and therefore chains k with (k % C) % T == tid
         torch.cuda.set_device(local_rank)
-        for j, fid in enumerate(my_ids):
-            if (j % C) % T != tid:
+        for k, (lo, hi) in enumerate(chains):
+            if (k % C) % T != tid:
                 continue
-            o = outs[j]
-            ctxs[j % C].segment_cluster_device(recs[fid].data_ptr(), 32, host_frames[fid].shape[0], scfg, ccfg,
-                                               o["labels"].data_ptr(), o["gidx"].data_ptr(), o["oidx"].data_ptr(),
-                                               o["planes"].data_ptr(), o["clabels"].data_ptr(), o["counts"].data_ptr())
+            ctxs[k % C].segment_cluster_batch_device(n_points[lo:hi], d_pts[lo].data_ptr(), 32, pitch, scfg, ccfg,
+                                                     d_labels[lo].data_ptr(), d_gidx[lo].data_ptr(),
+                                                     d_oidx[lo].data_ptr(), d_planes[lo].data_ptr(),
+                                                     d_clabels[lo].data_ptr(), d_counts[lo].data_ptr())
 
     def step():
         if pool is None:
@@ -203,9 +206,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    counts = [o["counts"].cpu().numpy() for o in outs]
-    if any(int(c[3]) != 0 for c in counts):
-        raise SystemExit(f"device status != 0: {[int(c[3]) for c in counts]}")
+    counts = d_counts.cpu().numpy().view(np.uint32)
+    if (counts[:, 3] != 0).any():
+        raise SystemExit(f"device status != 0: {counts[:, 3].tolist()}")
 
     elapsed, total_points_per_step = aggregate(elapsed, points_per_step, dev, world)
 
@@ -227,19 +230,21 @@ def main():
         dom = max(stage_ms, key=stage_ms.get)
         n_launch = max(1, launches[dom])
         avg_ms = stage_ms[dom] / n_launch
-        # frame-averaged sizes of this rank's batch; list sizes come from the device counters of the last
-        # frame each context processed
-        Nn = np.mean([host_frames[i].shape[0] for i in my_ids])
-        Mm = np.mean([int(c[1]) for c in counts])
-        fst = [c.frame_stats() for c in ctxs]
+        # one launch (group) of a stage covers the B frames of a chain: frame-averaged sizes of this rank's
+        # batch times the frames per chain; list sizes come from the device counters of the frame slots
+        frames_per_launch = float(np.mean([hi - lo for lo, hi in chains]))
+        Nn = float(n_points.mean())
+        Mm = float(counts[:, 1].mean())
+        fst = [c.frame_stats(slot) for c in ctxs for slot in range(B)]
         E = float(np.mean([f["neighbour_entries"] for f in fst]))
         E_replay = float(np.mean([f["replay_entries"] for f in fst]))
-        algo = algorithmic_bytes(dom, Nn, Mm, E, SEG["number_of_iterations"], SEG["number_of_planar_partitions"],
-                                 E_replay)
+        algo = frames_per_launch * algorithmic_bytes(dom, Nn, Mm, E, SEG["number_of_iterations"], P, E_replay)
         achieved = algo / (avg_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom),
-                    "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(algo)}
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(algo),
+                    "frames_per_launch": frames_per_launch}
 
     # ---- CPU baseline: the oracle restatement on this host, bounded sample (rank 0, N = 1 only) ----
     cpu = None
@@ -276,7 +281,8 @@ def main():
             "dtype": "f32",
             "data": "real KITTI frames (committed fixture of the reference's data/*.pcd), random-free",
             "config": {"workload": "configs[1]: 120k-pt KITTI frames, 6 segments, 5 iters, FEC d=0.5 m q=0.5",
-                       "frames_per_step_per_gpu": F, "contexts_per_gpu": C, "host_threads_per_gpu": T,
+                       "frames_per_step_per_gpu": F, "frames_per_launch_chain": B, "contexts_per_gpu": C,
+                       "host_threads_per_gpu": T,
                        "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "points_per_step": int(total_points_per_step),
                        "frames_per_s": round(F * world * args.steps / elapsed, 2)},

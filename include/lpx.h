@@ -182,6 +182,8 @@ int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uin
  * {n_ground, n_obstacle, n_clusters, status, neighbour entries lo/hi, components, expansions,
  *  entries read by the replay lo/hi} */
 int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out10);
+/* the same for frame slot `slot` of a batch context */
+int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out10);
 /* plane from points through the device moment/Jacobi path */
 int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane);
 

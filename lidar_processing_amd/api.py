@@ -196,11 +196,11 @@ class Context:
                                                             _vp(n), C.byref(sc), C.byref(cc), d_labels, d_ground_idx,
                                                             d_obstacle_idx, d_planes, d_cluster_labels, d_counts))
 
-    def frame_stats(self):
-        """counters of the last frame of this context (synchronises)"""
+    def frame_stats(self, slot=0):
+        """counters of the last frame processed in frame slot `slot` of this context (synchronises)"""
         o = np.zeros(10, np.uint32)
-        self._L.lpx_dbg_frame_stats.argtypes = [C.c_void_p, C.c_void_p]
-        self.check(self._L.lpx_dbg_frame_stats(self._h, _vp(o)))
+        self._L.lpx_dbg_frame_stats_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        self.check(self._L.lpx_dbg_frame_stats_slot(self._h, slot, _vp(o)))
         return dict(n_ground=int(o[0]), n_obstacle=int(o[1]), n_clusters=int(o[2]), status=int(o[3]),
                     neighbour_entries=int(o[4]) | (int(o[5]) << 32), components=int(o[6]), expansions=int(o[7]),
                     replay_entries=int(o[8]) | (int(o[9]) << 32))

@@ -676,12 +676,13 @@ extern "C" int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, 
 
 // frame statistics of the last call on this context: {n_ground, n_obstacle, n_clusters, status,
 // neighbour entries (lo, hi), components, expansions, entries read by the replay (lo, hi)}
-extern "C" int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out10)
+extern "C" int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out10)
 {
-    if (!ctx || !out10)
+    if (!ctx || !out10 || slot >= ctx->batch)
         return LPX_ERR_ARG;
     FrameState fs;
-    LPX_HIP(ctx, hipMemcpyAsync(&fs, ctx->frame.p, sizeof fs, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipMemcpyAsync(&fs, (const char *)ctx->frame.p + (size_t)slot * ctx->fstride, sizeof fs,
+                                hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out10[0] = fs.n_ground;
     out10[1] = fs.n_obstacle;
@@ -694,6 +695,11 @@ extern "C" int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out10)
     out10[8] = (uint32_t)fs.replay_entries;
     out10[9] = (uint32_t)(fs.replay_entries >> 32);
     return LPX_OK;
+}
+
+extern "C" int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out10)
+{
+    return lpx_dbg_frame_stats_slot(ctx, 0, out10);
 }
 
 // tools only: per-group statistics of the neighbour kernel ({T, intervals, queries, hits, cycles to

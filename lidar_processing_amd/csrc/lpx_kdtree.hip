@@ -1425,14 +1425,40 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
     for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE; i < M; i += stride)
     {
         const uint32_t o = off[i], n = len[i];
-        uint32_t ri = uf_ld(parent + i);
-        for (uint32_t t = lane; t < n; t += WAVE)
+        // values known to lie in i's component: its cached root and up to three (possibly stale) roots met
+        // in this list.  Stale roots repeat all over a list, so each distinct one costs ONE union attempt
+        // by one lane instead of a divergent find per entry.
+        uint32_t a0 = uf_ld(parent + i), a1 = a0, a2 = a0, a3 = a0;
+        // four chunks of the list per trip: the index loads, then the parent gathers, are issued together
+        for (uint32_t t0 = 0; t0 < n; t0 += 4 * WAVE)
         {
-            const uint32_t k = nb_idx[o + t];
-            if (k < i && uf_ld(parent + k) != ri)
+            uint32_t k[4], pk[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
             {
-                uf_unite(parent, i, k);
-                ri = uf_find(parent, i);
+                const uint32_t t = t0 + c * WAVE + lane;
+                k[c] = (t < n) ? nb_idx[o + t] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                pk[c] = uf_ld(parent + (k[c] < i ? k[c] : i));  // entries >= i (and padding) read parent[i]
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                bool bad = k[c] < i && pk[c] != a0 && pk[c] != a1 && pk[c] != a2 && pk[c] != a3;
+                unsigned long long bm = __ballot(bad);
+                while (bm)
+                {
+                    const int f = __ffsll((long long)bm) - 1;
+                    const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)pk[c], f);
+                    if (lane == 0)
+                        uf_unite(parent, i, cand);  // cand is an ancestor of a neighbour: same component as i
+                    a3 = a2;
+                    a2 = a1;
+                    a1 = cand;
+                    bad = bad && pk[c] != cand;
+                    bm = __ballot(bad);
+                }
             }
         }
     }
