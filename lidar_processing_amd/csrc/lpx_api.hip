@@ -407,7 +407,7 @@ extern "C" int lpx_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride
         return rc;
     if ((rc = lpx_ingest_obstacles(ctx, d_pts, stride, m)))
         return rc;
-    return lpx_run_cluster(ctx, m, cfg, d_labels, d_counts);
+    return lpx_run_cluster(ctx, m, cfg, d_labels, d_counts, false);
 }
 
 extern "C" int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n,
@@ -427,7 +427,7 @@ extern "C" int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_
         return rc;
     if (!d_clabels)
         d_clabels = (int32_t *)ctx->d_clabels.p;
-    return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts);  // n bounds the obstacle count
+    return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts, false);  // n bounds the obstacle count
 }
 
 // B frames per launch chain: every kernel covers all frames (gridDim.z), so the launch count of the chain
@@ -461,7 +461,7 @@ extern "C" int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames,
         return rc;
     if ((rc = lpx_run_segment(ctx, d_pts, stride, n_points, seg_cfg, d_labels, d_gidx, d_oidx, d_planes)))
         return rc;
-    return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts);
+    return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -474,6 +474,20 @@ static int upload(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n)
         return rc;
     if (n)
         LPX_HIP(ctx, hipMemcpyAsync(ctx->in_aos.p, pts, stride * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    return LPX_OK;
+}
+
+// Before the neighbour stage runs again with a larger workspace (frame slot 0): clears status and every
+// counter behind it, keeps the point counts.
+static int reset_neighbour_state(lpx_ctx *ctx)
+{
+    char *f = (char *)ctx->frame.p;
+    const size_t lo = offsetof(FrameState, status), hi = offsetof(FrameState, n_in);
+    static_assert(offsetof(FrameState, nb_total) > offsetof(FrameState, status) &&
+                      offsetof(FrameState, n_expansions) < offsetof(FrameState, n_in) &&
+                      offsetof(FrameState, n_obstacle) < offsetof(FrameState, status),
+                  "FrameState layout");
+    LPX_HIP(ctx, hipMemsetAsync(f + lo, 0, hi - lo, ctx->stream));
     return LPX_OK;
 }
 
@@ -543,11 +557,13 @@ static int cluster_resident(lpx_ctx *ctx, uint32_t m, const lpx_clu_cfg *cfg, in
     FrameState fs;
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        if ((rc = lpx_run_cluster(ctx, m, cfg, (int32_t *)ctx->d_clabels.p, nullptr)))
+        // the kd-tree of a first attempt stays valid (and must not be rebuilt from the permuted node array:
+        // the layout depends on the input order, src/kdtree.hpp:174-225)
+        if ((rc = lpx_run_cluster(ctx, m, cfg, (int32_t *)ctx->d_clabels.p, nullptr, attempt > 0)))
             return rc;
         if ((rc = read_frame(ctx, &fs)))
             return rc;
-        if (fs.status == (uint32_t)(-LPX_ERR_CAPACITY) && attempt == 0)
+        if (fs.status == (uint32_t)(-LPX_ERR_CAPACITY) && attempt < 2)
         {
             if (fs.nb_total > 0xfffffff0ull)
                 return lpx_fail(ctx, LPX_ERR_CAPACITY, "neighbour lists need %llu entries (> 2^32)",
@@ -557,8 +573,8 @@ static int cluster_resident(lpx_ctx *ctx, uint32_t m, const lpx_clu_cfg *cfg, in
                 want = 0xfffffff0ull;
             if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, want)))
                 return rc;
-            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->status, 0, 4, ctx->stream));
-            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->nb_total, 0, 8, ctx->stream));
+            if ((rc = reset_neighbour_state(ctx)))
+                return rc;
             continue;
         }
         break;
@@ -826,8 +842,8 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
         {
             if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, fs.nb_total + 1024)))
                 return rc;
-            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->status, 0, 4, ctx->stream));
-            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->nb_total, 0, 8, ctx->stream));
+            if ((rc = reset_neighbour_state(ctx)))
+                return rc;
             continue;
         }
         break;
@@ -902,8 +918,8 @@ extern "C" int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
         {
             if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, fs.nb_total + 1024)))
                 return rc;
-            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->status, 0, 4, ctx->stream));
-            LPX_HIP(ctx, hipMemsetAsync(&((FrameState *)ctx->frame.p)->nb_total, 0, 8, ctx->stream));
+            if ((rc = reset_neighbour_state(ctx)))
+                return rc;
             continue;
         }
         break;

@@ -565,14 +565,15 @@ static uint32_t bits_for_count(uint32_t n)  // bits to hold values 0..n-1
     return b;
 }
 
-int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels, uint32_t *d_counts)
+int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels, uint32_t *d_counts,
+                    bool kd_ready)
 {
     FrameState *frame = (FrameState *)ctx->frame.p;
     hipStream_t st = ctx->stream;
     const FV fv = lpx_fv(ctx);
     if (m_max == 0)
         return d_counts ? lpx_write_counts(ctx, d_counts) : LPX_OK;
-    int rc = lpx_kd_build(ctx, m_max);
+    int rc = kd_ready ? LPX_OK : lpx_kd_build(ctx, m_max);
     if (rc)
         return rc;
     rc = lpx_neighbours(ctx, m_max, cfg->distance_squared, true);

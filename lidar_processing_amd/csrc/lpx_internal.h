@@ -204,8 +204,10 @@ int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t
 int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32_t *n_points, const lpx_seg_cfg *cfg,
                     uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes);
 // clustering of the obstacle SoA already in ctx->OX/OY/OZ, count in frame->n_obstacle (bound m_max);
-// d_counts (optional) receives {n_ground, n_obstacle, n_clusters, status} from the last kernel
-int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels, uint32_t *d_counts);
+// d_counts (optional) receives {n_ground, n_obstacle, n_clusters, status} from the last kernel;
+// kd_ready: the tree of a previous attempt on the same cloud is kept
+int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels, uint32_t *d_counts,
+                    bool kd_ready);
 // AoS (device) -> ctx->OX/OY/OZ, sets frame->n_obstacle = m
 int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m);
 // resets the FrameState of every slot of the call and stores the per-frame input sizes
