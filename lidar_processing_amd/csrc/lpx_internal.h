@@ -291,4 +291,26 @@ __device__ __forceinline__ uint32_t lpx_wave_incl_scan_u32(uint32_t v)
     return (uint32_t)x;
 }
 
+// wave-wide min / max with the same DPP sequence: the result is valid in lane 63.  Lanes without a DPP
+// source keep their own value (old == src), which is neutral for min and max.
+#define LPX_DPP_REDUCE(T, NAME, OP, TOI, FROMI)                                                        \
+    __device__ __forceinline__ T NAME(T v)                                                             \
+    {                                                                                                  \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x111, 0xf, 0xf, false)));         \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x112, 0xf, 0xf, false)));         \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x114, 0xf, 0xf, false)));         \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x118, 0xf, 0xf, false)));         \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x142, 0xa, 0xf, false)));         \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x143, 0xc, 0xf, false)));         \
+        return v;                                                                                      \
+    }
+__device__ __forceinline__ uint32_t lpx_umin(uint32_t a, uint32_t b)
+{
+    return a < b ? a : b;
+}
+LPX_DPP_REDUCE(float, lpx_wave_min63_f32, fminf, __float_as_int, __int_as_float)
+LPX_DPP_REDUCE(float, lpx_wave_max63_f32, fmaxf, __float_as_int, __int_as_float)
+LPX_DPP_REDUCE(uint32_t, lpx_wave_min63_u32, lpx_umin, (int), (uint32_t))
+#undef LPX_DPP_REDUCE
+
 #endif  // __HIPCC__

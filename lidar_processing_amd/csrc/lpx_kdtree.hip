@@ -1172,7 +1172,9 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
         for (uint32_t t0 = 0; t0 < T; t0 += tile_cap)
         {
             const uint32_t tn = min(tile_cap, T - t0);
-            for (uint32_t c = tix; c < tn; c += nthr)
+            // a group whose candidates fit one tile keeps tile and chunk boxes from the counting pass
+            const bool stage = pass == 0 || T > tile_cap;
+            for (uint32_t c = tix; stage && c < tn; c += nthr)
             {
                 const uint32_t ci = t0 + c;
                 uint32_t lo = 0, hi = n_cur - 1;  // last interval with pre <= ci
@@ -1192,22 +1194,15 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                 Coop<WAVE>::sync();
             // bounding box of each chunk of 64 consecutive candidates (rank order keeps them compact)
             const uint32_t nchunks = (tn + WAVE - 1) / WAVE;
-            for (uint32_t c = wix; c < nchunks; c += nwav)
+            for (uint32_t c = wix; stage && c < nchunks; c += nwav)
             {
                 const bool valid = c * WAVE + lane < tn;
                 const Node nd = tile[valid ? c * WAVE + lane : c * WAVE];
-                float lo0 = nd.x, lo1 = nd.y, lo2 = nd.z, hi0 = nd.x, hi1 = nd.y, hi2 = nd.z;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
-                {
-                    lo0 = fminf(lo0, __shfl_xor(lo0, o, 64));
-                    lo1 = fminf(lo1, __shfl_xor(lo1, o, 64));
-                    lo2 = fminf(lo2, __shfl_xor(lo2, o, 64));
-                    hi0 = fmaxf(hi0, __shfl_xor(hi0, o, 64));
-                    hi1 = fmaxf(hi1, __shfl_xor(hi1, o, 64));
-                    hi2 = fmaxf(hi2, __shfl_xor(hi2, o, 64));
-                }
-                if (lane == 0)
+                // DPP reductions (VALU only); the results are valid in lane 63
+                const float lo0 = lpx_wave_min63_f32(nd.x), lo1 = lpx_wave_min63_f32(nd.y);
+                const float lo2 = lpx_wave_min63_f32(nd.z), hi0 = lpx_wave_max63_f32(nd.x);
+                const float hi1 = lpx_wave_max63_f32(nd.y), hi2 = lpx_wave_max63_f32(nd.z);
+                if (lane == WAVE - 1)
                 {
                     cbox[c][0] = lo0;
                     cbox[c][1] = lo1;
@@ -1253,8 +1248,10 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                     const Node n1 = tile[v1 ? c1 + lane : 0u];
                     const float a0 = qx - n0.x, a1 = qy - n0.y, a2 = qz - n0.z;
                     const float b0 = qx - n1.x, b1 = qy - n1.y, b2 = qz - n1.z;
-                    const float da = a0 * a0 + (a1 * a1 + (a2 * a2 + 0.0f));  // src/kdtree.hpp:145-157
-                    const float db = b0 * b0 + (b1 * b1 + (b2 * b2 + 0.0f));
+                    // src/kdtree.hpp:145-157 sums d^2 from the last axis into 0.0f; a square is never -0, so the
+                    // "+ 0.0f" of the reference is the identity and is not issued
+                    const float da = a0 * a0 + (a1 * a1 + a2 * a2);
+                    const float db = b0 * b0 + (b1 * b1 + b2 * b2);
                     const bool ia = v0 && da <= r2, ib = v1 && db <= r2;      // :315 inclusive
                     const unsigned long long ma = __ballot(ia), mb = __ballot(ib);
                     const uint32_t na = __popcll(ma);
@@ -1283,11 +1280,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                     run += na + __popcll(mb);
                 }
                 if (pass == 0)
-                {
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1)
-                        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
-                }
+                    mn = (uint32_t)__builtin_amdgcn_readlane((int)lpx_wave_min63_u32(mn), WAVE - 1);
                 if (lane == j)
                 {
                     if (pass == 0)
@@ -1410,7 +1403,7 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
                                                        const uint32_t *__restrict__ off,
                                                        const uint32_t *__restrict__ len,
                                                        const uint32_t *__restrict__ nb_idx, uint32_t *parent,
-                                                       uint64_t cap, FV fv)
+                                                       uint64_t cap, uint32_t roots_only, FV fv)
 {
     frame = lpx_slot(frame, fv.fs);
     off = lpx_slot(off, fv.fs);
@@ -1424,6 +1417,12 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
     const uint32_t stride = gridDim.x * (blockDim.x / WAVE);
     for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE; i < M; i += stride)
     {
+        // roots_only: a first, cheap round over the lists of the forest's roots alone.  A root has no
+        // smaller neighbour; any neighbour that hangs under another tree merges the two, which removes
+        // most stale-root mismatches from the full round that follows (after another flatten).
+        if (roots_only && uf_ld(parent + i) != i)
+            continue;
+        const uint32_t lim = roots_only ? 0xffffffffu : i;  // a root's neighbours all have larger indices
         const uint32_t o = off[i], n = len[i];
         // values known to lie in i's component: its cached root and up to three (possibly stale) roots met
         // in this list.  Stale roots repeat all over a list, so each distinct one costs ONE union attempt
@@ -1441,11 +1440,11 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                pk[c] = uf_ld(parent + (k[c] < i ? k[c] : i));  // entries >= i (and padding) read parent[i]
+                pk[c] = uf_ld(parent + (k[c] < lim ? k[c] : i));  // other entries (and padding) read parent[i]
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
-                bool bad = k[c] < i && pk[c] != a0 && pk[c] != a1 && pk[c] != a2 && pk[c] != a3;
+                bool bad = k[c] < lim && pk[c] != a0 && pk[c] != a1 && pk[c] != a2 && pk[c] != a3;
                 unsigned long long bm = __ballot(bad);
                 while (bm)
                 {
@@ -1548,9 +1547,16 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
         hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
                            (uint32_t *)ctx->parent.p, ctx->fstride);
         const uint32_t hgrid = (m_max + 3) / 4 < 4096u ? (m_max + 3) / 4 : 4096u;
-        hipLaunchKernelGGL(cc_hook_kernel, dim3(hgrid, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
-                           (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
-                           (uint32_t *)ctx->parent.p, ctx->cap_nb, lpx_fv(ctx));
+        for (uint32_t roots_only = 1;; roots_only = 0)
+        {
+            hipLaunchKernelGGL(cc_hook_kernel, dim3(hgrid, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
+                               (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
+                               (uint32_t *)ctx->parent.p, ctx->cap_nb, roots_only, lpx_fv(ctx));
+            if (!roots_only)
+                break;
+            hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream,
+                               frame, (uint32_t *)ctx->parent.p, ctx->fstride);
+        }
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
