@@ -123,12 +123,10 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             ctx->nb_arena = nullptr;
             ctx->cap_nb = 0;
         }
-        LPX_HIP(ctx, hipMalloc(&ctx->nb_arena, 2 * one * ctx->batch));
+        LPX_HIP(ctx, hipMalloc(&ctx->nb_arena, one * ctx->batch));  // one word per neighbour
         ctx->nb_idx.p = ctx->nb_arena;
         ctx->nb_idx.bytes = one;
-        ctx->nb_dist.p = (char *)ctx->nb_arena + one;
-        ctx->nb_dist.bytes = one;
-        ctx->nb_fstride = 2 * one;
+        ctx->nb_fstride = one;
         ctx->cap_nb = nb;
     }
     return LPX_OK;
@@ -836,7 +834,7 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     FrameState fs;
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        if ((rc = lpx_neighbours(ctx, m, r2, false)) || (rc = read_frame(ctx, &fs)))
+        if ((rc = lpx_neighbours(ctx, m, r2, r2, false)) || (rc = read_frame(ctx, &fs)))
             return rc;
         if (fs.status == (uint32_t)(-LPX_ERR_CAPACITY) && attempt == 0 && fs.nb_total <= 0xfffffff0ull)
         {
@@ -850,17 +848,14 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     }
     if ((rc = status_to_rc(ctx, fs.status)))
         return rc;
-    // device lists are grouped by kd bucket; hand them back as a CSR ordered by point index
+    // device lists are grouped by kd bucket and hold index | absorb << 31; hand them back as a CSR ordered by
+    // point index with the distance KDTree::radius_search reports (src/kdtree.hpp:145-157, :315)
     uint32_t *off32 = (uint32_t *)malloc(4 * (size_t)m), *len32 = (uint32_t *)malloc(4 * (size_t)m);
     uint32_t *didx = (uint32_t *)malloc(4 * (size_t)fs.nb_total + 4);
-    float *ddist = (float *)malloc(4 * (size_t)fs.nb_total + 4);
     LPX_HIP(ctx, hipMemcpyAsync(off32, ctx->nb_off.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipMemcpyAsync(len32, ctx->nb_len.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     if (fs.nb_total)
-    {
         LPX_HIP(ctx, hipMemcpyAsync(didx, ctx->nb_idx.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
-        LPX_HIP(ctx, hipMemcpyAsync(ddist, ctx->nb_dist.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
-    }
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t run = 0;
     for (uint32_t i = 0; i < m; ++i)
@@ -877,15 +872,34 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
         rc = lpx_fail(ctx, LPX_ERR_CAPACITY, "caller buffers hold %llu entries, %llu needed",
                       (unsigned long long)capacity, (unsigned long long)run);
     else
-        for (uint32_t i = 0; i < m; ++i)
+        for (uint32_t i = 0; i < m && rc == LPX_OK; ++i)
         {
-            memcpy(idx + offsets[i], didx + off32[i], 4 * (size_t)len32[i]);
-            memcpy(dist + offsets[i], ddist + off32[i], 4 * (size_t)len32[i]);
+            const float qx = xyz[3 * (size_t)i], qy = xyz[3 * (size_t)i + 1], qz = xyz[3 * (size_t)i + 2];
+            for (uint32_t t = 0; t < len32[i]; ++t)
+            {
+                const uint32_t w = didx[(size_t)off32[i] + t], k = w & 0x7fffffffu;
+                if (k >= m)
+                {
+                    rc = lpx_fail(ctx, LPX_ERR_INTERNAL, "list of point %u names point %u", i, k);
+                    break;
+                }
+                const float d0 = qx - xyz[3 * (size_t)k], d1 = qy - xyz[3 * (size_t)k + 1];
+                const float d2 = qz - xyz[3 * (size_t)k + 2];
+                const float d = d0 * d0 + (d1 * d1 + d2 * d2);  // no contraction (Makefile): the device's value
+                // with thr_f == r2 every listed neighbour carries the absorb bit
+                if (!(w >> 31) || !(d <= r2))
+                {
+                    rc = lpx_fail(ctx, LPX_ERR_INTERNAL, "list of point %u: entry %u has distance %g, flag %u", i, k,
+                                  (double)d, w >> 31);
+                    break;
+                }
+                idx[offsets[i] + t] = k;
+                dist[offsets[i] + t] = d;
+            }
         }
     free(off32);
     free(len32);
     free(didx);
-    free(ddist);
     return rc;
 }
 
@@ -912,7 +926,7 @@ extern "C" int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     FrameState fs;
     for (int attempt = 0; attempt < 2; ++attempt)
     {
-        if ((rc = lpx_neighbours(ctx, m, r2, true)) || (rc = read_frame(ctx, &fs)))
+        if ((rc = lpx_neighbours(ctx, m, r2, r2, true)) || (rc = read_frame(ctx, &fs)))
             return rc;
         if (fs.status == (uint32_t)(-LPX_ERR_CAPACITY) && attempt == 0 && fs.nb_total <= 0xfffffff0ull)
         {

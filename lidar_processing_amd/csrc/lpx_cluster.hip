@@ -104,8 +104,7 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
                                                                  const uint32_t *__restrict__ members,
                                                                  const uint32_t *__restrict__ nb_off,
                                                                  const uint32_t *__restrict__ nb_len,
-                                                                 const uint32_t *__restrict__ nb_idx,
-                                                                 const float *__restrict__ nb_dist, uint8_t *state,
+                                                                 const uint32_t *__restrict__ nb_idx, uint8_t *state,
                                                                  int32_t *seed_of, uint32_t *queue, uint32_t *valid,
                                                                  ReplayParams prm, uint64_t cap, FV fv)
 {
@@ -116,7 +115,6 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
     nb_off = lpx_slot(nb_off, fv.fs);
     nb_len = lpx_slot(nb_len, fv.fs);
     nb_idx = lpx_slot(nb_idx, fv.fs_nb);
-    nb_dist = lpx_slot(nb_dist, fv.fs_nb);
     state = lpx_slot(state, fv.fs);
     seed_of = lpx_slot(seed_of, fv.fs);
     queue = lpx_slot(queue, fv.fs);
@@ -183,12 +181,12 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
             {
                 const uint32_t t = base + lane;
                 const bool in = t < cnt;
-                const uint32_t k = in ? nb_idx[o0 + t] : 0u;
-                const float d = in ? nb_dist[o0 + t] : 0.0f;
+                const uint32_t kw = in ? nb_idx[o0 + t] : 0u;  // index | absorb << 31
+                const uint32_t k = kw & 0x7fffffffu;
                 const uint8_t sk = in ? state[k] : (uint8_t)PT_REMOVED;
                 const bool vis = in && sk != PT_REMOVED;
                 touches += __popcll(__ballot(vis));
-                const bool absorb = vis && ((double)d <= prm.thr);
+                const bool absorb = vis && (kw >> 31);
                 const bool push = vis && !absorb && sk == PT_FRESH;
                 const unsigned long long pm = __ballot(push);
                 if (vis)
@@ -220,7 +218,6 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                                                            const uint32_t *__restrict__ nb_off,
                                                            const uint32_t *__restrict__ nb_len,
                                                            const uint32_t *__restrict__ nb_idx,
-                                                           const float *__restrict__ nb_dist,
                                                            const float *__restrict__ OX, const float *__restrict__ OY,
                                                            const float *__restrict__ OZ, int32_t *seed_of,
                                                            uint32_t *queue, uint32_t *valid, ReplayParams prm,
@@ -237,7 +234,6 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
     nb_off = lpx_slot(nb_off, fv.fs);
     nb_len = lpx_slot(nb_len, fv.fs);
     nb_idx = lpx_slot(nb_idx, fv.fs_nb);
-    nb_dist = lpx_slot(nb_dist, fv.fs_nb);
     OX = lpx_slot(OX, fv.fs);
     OY = lpx_slot(OY, fv.fs);
     OZ = lpx_slot(OZ, fv.fs);
@@ -356,8 +352,7 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                 continue;
             // software pipeline, RP_DEPTH lists in flight: slot s holds the first four chunks of the
             // expansion that will be processed RP_DEPTH steps after the one that last used the slot
-            uint32_t K4[RP_DEPTH][4];
-            float D4[RP_DEPTH][4];
+            uint32_t K4[RP_DEPTH][4];  // words index | absorb << 31; 0xffffffff past the end of the list
             unsigned long long lm = em;  // expansions whose list still has to be requested
 #pragma unroll
             for (int sl = 0; sl < RP_DEPTH; ++sl)
@@ -374,7 +369,6 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                         const uint32_t t = c * WAVE + lane;
                         const bool in = t < cg;
                         K4[sl][c] = in ? nb_idx[og + t] : 0xffffffffu;
-                        D4[sl][c] = in ? nb_dist[og + t] : 0.0f;
                     }
                 }
             }
@@ -392,13 +386,9 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                     st_entries += cnt;
                     ++st_exp;
                     uint32_t kk[4];
-                    float dd[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                    {
                         kk[c] = K4[sl][c];
-                        dd[c] = D4[sl][c];
-                    }
                     if (lm)
                     {
                         // refill the slot with the list of the expansion RP_DEPTH steps ahead
@@ -412,7 +402,6 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                             const uint32_t t = c * WAVE + lane;
                             const bool in = t < cg;
                             K4[sl][c] = in ? nb_idx[og + t] : 0xffffffffu;
-                            D4[sl][c] = in ? nb_dist[og + t] : 0.0f;
                         }
                     }
                     for (uint32_t base = 0; base < cnt; base += 4 * WAVE)
@@ -425,7 +414,6 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                                 const uint32_t t = base + c * WAVE + lane;
                                 const bool in = t < cnt;
                                 kk[c] = in ? nb_idx[o0 + t] : 0xffffffffu;
-                                dd[c] = in ? nb_dist[o0 + t] : 0.0f;
                             }
                         }
 #pragma unroll
@@ -434,11 +422,11 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                             if (base + c * WAVE >= cnt)
                                 break;
                             const bool in = kk[c] != 0xffffffffu;
-                            const uint32_t k = in ? kk[c] : 0u;
+                            const uint32_t k = in ? (kk[c] & 0x7fffffffu) : 0u;
                             const uint32_t sk = in ? ST_GET(k) : 2u;
                             const bool vis = in && !(sk & 2u);
                             touches += __popcll(__ballot(vis));
-                            const bool absorb = vis && (dd[c] <= prm.thr_f);
+                            const bool absorb = vis && (kk[c] >> 31);
                             const bool push = vis && !absorb && sk == 0u;
                             const unsigned long long pm = __ballot(push);
                             if (vis && sk == 0u)
@@ -576,7 +564,16 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     int rc = kd_ready ? LPX_OK : lpx_kd_build(ctx, m_max);
     if (rc)
         return rc;
-    rc = lpx_neighbours(ctx, m_max, cfg->distance_squared, true);
+    ReplayParams prm;
+    const double one_minus_q = 1.0 - (double)cfg->cluster_quality;
+    prm.thr = (one_minus_q * one_minus_q) * (double)cfg->distance_squared;  // std::pow(x, 2) == x*x exactly
+    prm.thr_f = (float)prm.thr;
+    if ((double)prm.thr_f > prm.thr)
+        prm.thr_f = nextafterf(prm.thr_f, -INFINITY);
+    prm.r2 = cfg->distance_squared;
+    prm.min_size = cfg->min_cluster_size;
+    prm.max_size = cfg->max_cluster_size;
+    rc = lpx_neighbours(ctx, m_max, cfg->distance_squared, prm.thr_f, true);
     if (rc)
         return rc;
 
@@ -598,15 +595,6 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     }
     {
         StageTimer tm(ctx, ST_REPLAY);
-        ReplayParams prm;
-        const double one_minus_q = 1.0 - (double)cfg->cluster_quality;
-        prm.thr = (one_minus_q * one_minus_q) * (double)cfg->distance_squared;  // std::pow(x, 2) == x*x exactly
-        prm.thr_f = (float)prm.thr;
-        if ((double)prm.thr_f > prm.thr)
-            prm.thr_f = nextafterf(prm.thr_f, -INFINITY);
-        prm.r2 = cfg->distance_squared;
-        prm.min_size = cfg->min_cluster_size;
-        prm.max_size = cfg->max_cluster_size;
         const size_t lds = sizeof(uint32_t) * (((((size_t)m_max + 15) / 16 + 3) & ~(size_t)3) + RP_RING);
         if (lds <= 112 * 1024)
         {
@@ -620,8 +608,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
             hipLaunchKernelGGL(replay_lds_kernel, dim3(rgrid, 1, ctx->cur_b), dim3(WAVE), lds, st, frame, cc_lo, cc_hi,
                                members,
                                (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,
-                               (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->nb_dist.p,
-                               (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p,
+                               (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p,
                                (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb, frame,
                                (const uint32_t *)ctx->rpos.p, (uint32_t *)ctx->dbg_buf, fv);
         }
@@ -629,8 +616,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
             hipLaunchKernelGGL(replay_kernel, dim3((m_max + RP_WAVES - 1) / RP_WAVES, 1, ctx->cur_b),
                                dim3(RP_WAVES * WAVE), 0, st,
                                frame, cc_lo, cc_hi, members, (const uint32_t *)ctx->nb_off.p,
-                               (const uint32_t *)ctx->nb_len.p, (const uint32_t *)ctx->nb_idx.p,
-                               (const float *)ctx->nb_dist.p, (uint8_t *)ctx->state.p, (int32_t *)ctx->seed_of.p,
+                               (const uint32_t *)ctx->nb_len.p, (const uint32_t *)ctx->nb_idx.p, (uint8_t *)ctx->state.p, (int32_t *)ctx->seed_of.p,
                                (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb, fv);
     }
     {

@@ -124,7 +124,7 @@ struct lpx_ctx
     Buf nodes_pre;             // the same nodes in pre-order rank layout
     Buf lpos, rpos;            // partition scratch
     Buf nb_len, nb_off;        // u32 len, u32 off (cap_n + 1)
-    Buf nb_idx, nb_dist;       // cap_nb
+    Buf nb_idx;                // cap_nb words: neighbour index | (within the absorb radius) << 31
     Buf parent;                // union-find
     Buf cc_lo, cc_hi;          // member range per root
     Buf state;                 // u8 replay state
@@ -219,7 +219,9 @@ int lpx_write_counts(lpx_ctx *ctx, uint32_t *d_counts);
 int lpx_run_groups(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets, uint32_t *d_indices);
 
 int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max);
-int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook);
+// thr_f: absorb threshold of the clustering (largest float <= (1-q)^2 d^2), stored as bit 31 of every list
+// word; hook: also build the connected components
+int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hook);
 
 // ------------------------------------------------------------------------------------------------
 // device helpers

@@ -1044,10 +1044,10 @@ __device__ uint32_t nb_traverse(const Node *__restrict__ PR, uint32_t M, uint32_
 // Both count, allocate (64-bit atomic bump of frame->nb_total, one block of list storage per group)
 // and fill in the same launch; off[i] / len[i] locate the list of point i.
 __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__restrict__ PR, FrameState *frame,
-                                                               float r2, float rr, uint32_t *__restrict__ len,
+                                                               float r2, float rr, float thr_f,
+                                                               uint32_t *__restrict__ len,
                                                                uint32_t *__restrict__ off,
-                                                               uint32_t *__restrict__ nb_idx,
-                                                               float *__restrict__ nb_dist, uint64_t cap,
+                                                               uint32_t *__restrict__ nb_idx, uint64_t cap,
                                                                uint32_t *__restrict__ parent,
                                                                uint32_t *__restrict__ dbg, FV fv)
 {
@@ -1058,7 +1058,6 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
     off = lpx_slot(off, fv.fs);
     parent = lpx_slot(parent, fv.fs);
     nb_idx = lpx_slot(nb_idx, fv.fs_nb);
-    nb_dist = lpx_slot(nb_dist, fv.fs_nb);
     __shared__ uint32_t s_pre[NB_SEQ / 2 + 8 * NB_WAVES];
     __shared__ Node s_tile[NB_NODES];
     __shared__ float s_cbox[NB_NODES / WAVE][6];
@@ -1266,15 +1265,14 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                     {
                         if (ia)
                         {
-                            const uint32_t pos = run + __popcll(ma & lt);
-                            nb_idx[pos] = __float_as_uint(n0.w);
-                            nb_dist[pos] = da;
+                            // one word per neighbour: index | (within the absorb radius) << 31.  For a float d,
+                            // (double)d <= thr of src/clustering.cpp:102 <=> d <= thr_f
+                            nb_idx[run + __popcll(ma & lt)] = __float_as_uint(n0.w) | (da <= thr_f ? 0x80000000u : 0u);
                         }
                         if (ib)
                         {
-                            const uint32_t pos = run + na + __popcll(mb & lt);
-                            nb_idx[pos] = __float_as_uint(n1.w);
-                            nb_dist[pos] = db;
+                            nb_idx[run + na + __popcll(mb & lt)] =
+                                __float_as_uint(n1.w) | (db <= thr_f ? 0x80000000u : 0u);
                         }
                     }
                     run += na + __popcll(mb);
@@ -1436,7 +1434,7 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
             for (int c = 0; c < 4; ++c)
             {
                 const uint32_t t = t0 + c * WAVE + lane;
-                k[c] = (t < n) ? nb_idx[o + t] : 0xffffffffu;
+                k[c] = (t < n) ? (nb_idx[o + t] & 0x7fffffffu) : 0xffffffffu;
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -1516,7 +1514,7 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     return LPX_OK;
 }
 
-int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
+int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hook)
 {
     if (m_max == 0)
         return LPX_OK;
@@ -1536,8 +1534,8 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, bool hook)
         // host's bound; surplus blocks return at once.
         const uint32_t nbk = groups / 2;
         hipLaunchKernelGGL(nb_group_kernel, dim3(nbk + (nbk + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b),
-                           dim3(NB_THREADS), 0, ctx->stream, (const Node *)PR, frame, r2, rr, len, off,
-                           (uint32_t *)ctx->nb_idx.p, (float *)ctx->nb_dist.p, ctx->cap_nb,
+                           dim3(NB_THREADS), 0, ctx->stream, (const Node *)PR, frame, r2, rr, thr_f, len, off,
+                           (uint32_t *)ctx->nb_idx.p, ctx->cap_nb,
                            hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf,
                            lpx_fv(ctx));
     }
