@@ -476,13 +476,13 @@ __device__ __forceinline__ void descend(int &b, int &e, uint32_t r, int level)
 // kernels
 // ------------------------------------------------------------------------------------------------
 constexpr int BLK_G = 1024;
-constexpr int BLK_CAP = 4096;  // nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch
+constexpr int BLK_CAP_MAX = 4096;  // most nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch (blk_cap is a launch argument)
 constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
 
 // one workgroup per range of `level`: std::nth_element(b, mid, e) on axis level % 3
 __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
                                                           const FrameState *__restrict__ frame, int level,
-                                                          size_t fs)
+                                                          int BLK_CAP, size_t fs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     nodes = lpx_slot(nodes, fs);
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
 }
 
 // ------------------------------------------------------------------------------------------------
-// Whole subtree of a range that fits LDS (<= BLK_CAP nodes), one workgroup.
+// Whole subtree of a range that fits LDS (<= blk_cap nodes), one workgroup.
 //
 // Sub-level s has 2^s independent ranges; they are partitioned SIMULTANEOUSLY by 2^s groups of
 // 1024 >> s consecutive threads (whole wavefronts while the group has >= 64 threads, lane segments of
@@ -625,7 +625,7 @@ constexpr int LG = 256;  // threads of kd_lds_kernel: one wavefront per SIMD, li
 
 __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restrict__ PR,
                                                     const FrameState *__restrict__ frame,
-                                                    uint32_t *__restrict__ dbg, size_t fs)
+                                                    uint32_t *__restrict__ dbg, int BLK_CAP, size_t fs)
 {
     nodes = lpx_slot(nodes, fs);
     PR = lpx_slot(PR, fs);
@@ -1489,27 +1489,32 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     uint32_t *lpos = (uint32_t *)ctx->lpos.p, *rasc = (uint32_t *)ctx->rpos.p;
     StageTimer tm(ctx, ST_KD_BUILD);
     // the node array {x, y, z, index} was written by the producer of the obstacle cloud (compact / ingest)
-    const size_t blk_lds = sizeof(Node) * BLK_CAP + 2 * sizeof(uint32_t) * BLK_CAP + 64 * sizeof(uint32_t);
+    // A single frame stages up to 4096 nodes per workgroup (96 KiB of LDS: fewest global-memory rounds, best
+    // latency).  A batch shares the device with the small-LDS workgroups of other chains' neighbour kernels,
+    // next to which a 96 KiB workgroup rarely finds room; half the capacity (48 KiB) schedules freely.
+    const int blk_cap = ctx->cur_b > 1 ? BLK_CAP_MAX / 2 : BLK_CAP_MAX;
+    const size_t blk_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint32_t) * blk_cap + 64 * sizeof(uint32_t);
     if (!ctx->attr_kd)
     {
+        const size_t max_lds = sizeof(Node) * BLK_CAP_MAX + 2 * sizeof(uint32_t) * BLK_CAP_MAX + 64 * sizeof(uint32_t);
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)blk_lds));
+                                         (int)max_lds));
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)blk_lds));
+                                         (int)max_lds));
         ctx->attr_kd = true;
     }
     // global-memory levels while a range can exceed the LDS capacity, then the whole rest in one launch
     int level = 0;
     uint32_t size = m_max;
-    while (size > (uint32_t)BLK_CAP)
+    while (size > (uint32_t)blk_cap)
     {
         hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G), blk_lds, ctx->stream, nodes,
-                           lpos, rasc, frame, level, ctx->fstride);
+                           lpos, rasc, frame, level, blk_cap, ctx->fstride);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
     hipLaunchKernelGGL(kd_lds_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(LG), blk_lds, ctx->stream, nodes,
-                       (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, ctx->fstride);
+                       (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fstride);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
