@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per launch chain (lpx_segment_cluster_batch_device)")
     ap.add_argument("--contexts", type=int, default=8, help="concurrent lpx contexts (HIP streams) per GPU")
     ap.add_argument("--threads", type=int, default=2, help="host threads that enqueue (ctypes releases the GIL)")
+    ap.add_argument("--neighbour-words", type=int, default=256, help="neighbour workspace per point (lpx_reserve)")
+    ap.add_argument("--single-pass-words", type=int, default=640,
+                    help="extra neighbour workspace per point for single-pass lists (lpx_reserve_single_pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -154,7 +157,8 @@ def main():
     C = max(1, min(args.contexts, len(chains)))
     ctxs = [Context(local_rank, batch=B) for _ in range(C)]
     for c in ctxs:
-        c.reserve(pitch)
+        c.reserve_single_pass(args.single_pass_words)
+        c.reserve(pitch, args.neighbour_words)
     d_labels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
     d_gidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
     d_oidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)

@@ -82,6 +82,10 @@ void lpx_destroy(lpx_ctx *ctx);
  * src/clustering.cpp:37-45): pre-size all device scratch for n points.  Scratch also grows on
  * demand.  neighbours_per_point sizes the radius-neighbour lists (0 = default 256). */
 int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_per_point);
+/* Extra neighbour workspace (32-bit words per point, default 512) in which the neighbour kernel may keep
+ * lists reserved by an upper bound of their length, which saves its counting pass.  It never changes what
+ * fits: a kd group that finds no room there counts first and uses the lpx_reserve workspace.  0 disables. */
+int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point);
 const char *lpx_last_error(const lpx_ctx *ctx);
 /* blocks until everything enqueued on the context stream has finished */
 int lpx_synchronize(lpx_ctx *ctx);
@@ -178,12 +182,12 @@ int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uin
                        float *dist, uint64_t capacity);
 /* connected-component root (smallest original index of the component) per point */
 int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint32_t *root);
-/* statistics of the last frame processed by this context (synchronises): out[10] =
+/* statistics of the last frame processed by this context (synchronises): out[12] =
  * {n_ground, n_obstacle, n_clusters, status, neighbour entries lo/hi, components, expansions,
- *  entries read by the replay lo/hi} */
-int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out10);
+ *  entries read by the replay lo/hi, words of list storage handed out lo/hi} */
+int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out12);
 /* the same for frame slot `slot` of a batch context */
-int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out10);
+int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out12);
 /* plane from points through the device moment/Jacobi path */
 int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane);
 

@@ -52,6 +52,7 @@ def lib():
     L.lpx_destroy.argtypes = [vp]
     L.lpx_destroy.restype = None
     L.lpx_reserve.argtypes = [vp, u32, u32]
+    L.lpx_reserve_single_pass.argtypes = [vp, u32]
     L.lpx_last_error.argtypes = [vp]
     L.lpx_last_error.restype = C.c_char_p
     L.lpx_synchronize.argtypes = [vp]

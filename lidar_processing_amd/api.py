@@ -110,6 +110,10 @@ class Context:
     def reserve(self, n_points, neighbours_per_point=0):
         self.check(self._L.lpx_reserve(self._h, int(n_points), int(neighbours_per_point)))
 
+    def reserve_single_pass(self, words_per_point):
+        """lpx_reserve_single_pass: extra neighbour workspace for lists reserved by an upper bound (0 = off)"""
+        self.check(self._L.lpx_reserve_single_pass(self._h, int(words_per_point)))
+
     def synchronize(self):
         self.check(self._L.lpx_synchronize(self._h))
 
@@ -198,12 +202,12 @@ class Context:
 
     def frame_stats(self, slot=0):
         """counters of the last frame processed in frame slot `slot` of this context (synchronises)"""
-        o = np.zeros(10, np.uint32)
+        o = np.zeros(12, np.uint32)
         self._L.lpx_dbg_frame_stats_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         self.check(self._L.lpx_dbg_frame_stats_slot(self._h, slot, _vp(o)))
         return dict(n_ground=int(o[0]), n_obstacle=int(o[1]), n_clusters=int(o[2]), status=int(o[3]),
                     neighbour_entries=int(o[4]) | (int(o[5]) << 32), components=int(o[6]), expansions=int(o[7]),
-                    replay_entries=int(o[8]) | (int(o[9]) << 32))
+                    replay_entries=int(o[8]) | (int(o[9]) << 32), neighbour_words=int(o[10]) | (int(o[11]) << 32))
 
     # ---- stage-level entry points (parity tests) ----
     def dbg_sort_pairs(self, keys, values, bits=32):

@@ -111,23 +111,31 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         ctx->fstride = total;
         ctx->cap_n = n;
     }
-    if (nb > ctx->cap_nb || !ctx->nb_arena)
+    // Neighbour workspace of a slot: cap_nb words for lists of exact length (what lpx_reserve promises), then
+    // cap_rs words the neighbour kernel may use for single-pass lists reserved by an upper bound; a group that
+    // finds no room there falls back to counting, so the second region only ever buys speed.
+    uint64_t rs = (uint64_t)ctx->cap_n * ctx->rs_per_point;
+    if (nb < ctx->cap_nb)
+        nb = ctx->cap_nb;
+    if (nb + rs > 0xfffffff0ull)
+        rs = 0xfffffff0ull - nb;  // offsets are 32-bit
+    if (nb != ctx->cap_nb || rs != ctx->cap_rs || !ctx->nb_arena)
     {
-        if (nb < ctx->cap_nb)
-            nb = ctx->cap_nb;
-        const size_t one = align256(sizeof(uint32_t) * (nb + 64));
+        const size_t one = align256(sizeof(uint32_t) * (nb + rs + 64));  // one word per neighbour
         if (ctx->nb_arena)
         {
             LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
             LPX_HIP(ctx, hipFree(ctx->nb_arena));
             ctx->nb_arena = nullptr;
             ctx->cap_nb = 0;
+            ctx->cap_rs = 0;
         }
-        LPX_HIP(ctx, hipMalloc(&ctx->nb_arena, one * ctx->batch));  // one word per neighbour
+        LPX_HIP(ctx, hipMalloc(&ctx->nb_arena, one * ctx->batch));
         ctx->nb_idx.p = ctx->nb_arena;
         ctx->nb_idx.bytes = one;
         ctx->nb_fstride = one;
         ctx->cap_nb = nb;
+        ctx->cap_rs = rs;
     }
     return LPX_OK;
 }
@@ -329,6 +337,15 @@ extern "C" int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_
     return ensure_for(ctx, n_points);
 }
 
+extern "C" int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->rs_per_point = words_per_point;
+    return lpx_ensure_capacity(ctx, ctx->cap_n, ctx->cap_nb);
+}
+
 extern "C" int lpx_synchronize(lpx_ctx *ctx)
 {
     if (!ctx)
@@ -480,12 +497,13 @@ static int upload(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n)
 static int reset_neighbour_state(lpx_ctx *ctx)
 {
     char *f = (char *)ctx->frame.p;
-    const size_t lo = offsetof(FrameState, status), hi = offsetof(FrameState, n_in);
+    const size_t lo = offsetof(FrameState, status), nin = offsetof(FrameState, n_in), hi = sizeof(FrameState);
     static_assert(offsetof(FrameState, nb_total) > offsetof(FrameState, status) &&
-                      offsetof(FrameState, n_expansions) < offsetof(FrameState, n_in) &&
                       offsetof(FrameState, n_obstacle) < offsetof(FrameState, status),
                   "FrameState layout");
-    LPX_HIP(ctx, hipMemsetAsync(f + lo, 0, hi - lo, ctx->stream));
+    // n_in sits between the counters: clear around it
+    LPX_HIP(ctx, hipMemsetAsync(f + lo, 0, nin - lo, ctx->stream));
+    LPX_HIP(ctx, hipMemsetAsync(f + nin + sizeof(uint32_t), 0, hi - nin - sizeof(uint32_t), ctx->stream));
     return LPX_OK;
 }
 
@@ -690,30 +708,33 @@ extern "C" int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, 
 
 // frame statistics of the last call on this context: {n_ground, n_obstacle, n_clusters, status,
 // neighbour entries (lo, hi), components, expansions, entries read by the replay (lo, hi)}
-extern "C" int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out10)
+extern "C" int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out12)
 {
-    if (!ctx || !out10 || slot >= ctx->batch)
+    if (!ctx || !out12 || slot >= ctx->batch)
         return LPX_ERR_ARG;
     FrameState fs;
     LPX_HIP(ctx, hipMemcpyAsync(&fs, (const char *)ctx->frame.p + (size_t)slot * ctx->fstride, sizeof fs,
                                 hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    out10[0] = fs.n_ground;
-    out10[1] = fs.n_obstacle;
-    out10[2] = fs.n_clusters;
-    out10[3] = fs.status;
-    out10[4] = (uint32_t)fs.nb_total;
-    out10[5] = (uint32_t)(fs.nb_total >> 32);
-    out10[6] = fs.n_roots;
-    out10[7] = fs.n_expansions;
-    out10[8] = (uint32_t)fs.replay_entries;
-    out10[9] = (uint32_t)(fs.replay_entries >> 32);
+    out12[0] = fs.n_ground;
+    out12[1] = fs.n_obstacle;
+    out12[2] = fs.n_clusters;
+    out12[3] = fs.status;
+    out12[4] = (uint32_t)fs.nb_entries;
+    out12[5] = (uint32_t)(fs.nb_entries >> 32);
+    out12[6] = fs.n_roots;
+    out12[7] = fs.n_expansions;
+    out12[8] = (uint32_t)fs.replay_entries;
+    out12[9] = (uint32_t)(fs.replay_entries >> 32);
+    const uint64_t words = fs.nb_total + (fs.rs_total < ctx->cap_rs ? fs.rs_total : ctx->cap_rs);
+    out12[10] = (uint32_t)words;
+    out12[11] = (uint32_t)(words >> 32);
     return LPX_OK;
 }
 
-extern "C" int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out10)
+extern "C" int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out12)
 {
-    return lpx_dbg_frame_stats_slot(ctx, 0, out10);
+    return lpx_dbg_frame_stats_slot(ctx, 0, out12);
 }
 
 // tools only: per-group statistics of the neighbour kernel ({T, intervals, queries, hits, cycles to
@@ -851,11 +872,12 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     // device lists are grouped by kd bucket and hold index | absorb << 31; hand them back as a CSR ordered by
     // point index with the distance KDTree::radius_search reports (src/kdtree.hpp:145-157, :315)
     uint32_t *off32 = (uint32_t *)malloc(4 * (size_t)m), *len32 = (uint32_t *)malloc(4 * (size_t)m);
-    uint32_t *didx = (uint32_t *)malloc(4 * (size_t)fs.nb_total + 4);
+    const uint64_t span = fs.rs_total ? ctx->cap_nb + (fs.rs_total < ctx->cap_rs ? fs.rs_total : ctx->cap_rs) : fs.nb_total;
+    uint32_t *didx = (uint32_t *)malloc(4 * (size_t)span + 4);
     LPX_HIP(ctx, hipMemcpyAsync(off32, ctx->nb_off.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipMemcpyAsync(len32, ctx->nb_len.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-    if (fs.nb_total)
-        LPX_HIP(ctx, hipMemcpyAsync(didx, ctx->nb_idx.p, 4 * fs.nb_total, hipMemcpyDeviceToHost, ctx->stream));
+    if (span)
+        LPX_HIP(ctx, hipMemcpyAsync(didx, ctx->nb_idx.p, 4 * span, hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t run = 0;
     for (uint32_t i = 0; i < m; ++i)
@@ -865,9 +887,9 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     }
     offsets[m] = run;
     rc = LPX_OK;
-    if (run != fs.nb_total)
-        rc = lpx_fail(ctx, LPX_ERR_INTERNAL, "list lengths sum to %llu, allocated %llu", (unsigned long long)run,
-                      (unsigned long long)fs.nb_total);
+    if (run != fs.nb_entries || run > span)
+        rc = lpx_fail(ctx, LPX_ERR_INTERNAL, "list lengths sum to %llu, %llu written, %llu words in use",
+                      (unsigned long long)run, (unsigned long long)fs.nb_entries, (unsigned long long)span);
     else if (run > capacity)
         rc = lpx_fail(ctx, LPX_ERR_CAPACITY, "caller buffers hold %llu entries, %llu needed",
                       (unsigned long long)capacity, (unsigned long long)run);

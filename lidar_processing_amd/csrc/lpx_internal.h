@@ -39,12 +39,14 @@ struct FrameState
     uint32_t n_obstacle;  // M: number of points handed to clustering
     uint32_t n_clusters;
     uint32_t status;      // 0 ok, else -LPX_ERR_*
-    uint64_t nb_total;    // total neighbour entries required
+    uint64_t nb_total;    // words of exact-length list storage required (workspace region [0, cap_nb))
     uint32_t n_roots;     // connected components of the d-graph
     uint32_t root_cursor; // work queue head of the replay
     uint64_t replay_entries;  // neighbour entries read by the replay (lists of expanded points)
     uint32_t n_expansions;    // radius_search calls the reference would have made
     uint32_t n_in;            // points of the input cloud of this frame slot
+    uint64_t nb_entries;      // neighbour entries written (sum of the list lengths)
+    uint64_t rs_total;        // words asked from the single-pass region [cap_nb, cap_nb + cap_rs)
 };
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
@@ -99,6 +101,8 @@ struct lpx_ctx
     uint32_t cap_n = 0;        // points per frame slot
     uint64_t cap_nb = 0;       // neighbour entries per frame slot
     uint32_t nb_per_point = 256;
+    uint64_t cap_rs = 0;       // words of the single-pass list region per frame slot (behind the cap_nb words)
+    uint32_t rs_per_point = 512;
     uint32_t batch = 1;        // frame slots
     uint32_t cur_b = 1;        // frames of the call being enqueued (gridDim.z)
     uint32_t upitch = 0;       // pitch of the caller arrays of that call

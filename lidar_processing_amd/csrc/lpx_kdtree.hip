@@ -1048,6 +1048,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                                                                uint32_t *__restrict__ len,
                                                                uint32_t *__restrict__ off,
                                                                uint32_t *__restrict__ nb_idx, uint64_t cap,
+                                                               uint64_t cap_rs,
                                                                uint32_t *__restrict__ parent,
                                                                uint32_t *__restrict__ dbg, FV fv)
 {
@@ -1163,16 +1164,30 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
     }
 
     const unsigned long long lt = lpx_lanemask_lt();
-    uint32_t my_cnt = 0;     // lane j (of the wavefront that owns query j): list length of query j
-    uint32_t my_cursor = 0;  // ... and its write position
+    uint32_t my_cnt = 0;     // lane j (of the wavefront that owns query j): room asked for the list of query j
+    uint32_t my_cursor = 0;  // ... its write position
+    uint32_t my_len = 0;     // ... the number of neighbours written
     uint32_t my_min = qi;    // ... and the smallest neighbour index (first union-find link)
-    for (int pass = 0; pass < 2; ++pass)
+    // Phases.  RESERVE asks for room without computing a distance: every candidate of every chunk that
+    // survives the cull of a query could be a neighbour, so that sum bounds the list length.  If the
+    // single-pass region [cap, cap + cap_rs) of the workspace has that much room the distances are evaluated
+    // ONCE (FILL) and the lists keep a gap at the end; otherwise COUNT evaluates them to get exact lengths
+    // first and the lists go to the exact region [0, cap).  FILL writes the lists in place.
+    enum
+    {
+        PH_RESERVE,
+        PH_COUNT,
+        PH_FILL
+    };
+    int phase = (frame->rs_total < cap_rs) ? PH_RESERVE : PH_COUNT;  // region exhausted: do not even try
+    bool staged_once = false;
+    for (;;)
     {
         for (uint32_t t0 = 0; t0 < T; t0 += tile_cap)
         {
             const uint32_t tn = min(tile_cap, T - t0);
-            // a group whose candidates fit one tile keeps tile and chunk boxes from the counting pass
-            const bool stage = pass == 0 || T > tile_cap;
+            // a group whose candidates fit one tile keeps tile and chunk boxes from its first phase
+            const bool stage = !staged_once || T > tile_cap;
             for (uint32_t c = tix; stage && c < tn; c += nthr)
             {
                 const uint32_t ci = t0 + c;
@@ -1230,7 +1245,16 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                     keep = (ex * ex + ey * ey + ez * ez) <= r2c;
                 }
                 unsigned long long km = __ballot(keep);
-                uint32_t run = (pass == 0) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)my_cursor, j);
+                if (phase == PH_RESERVE)
+                {
+                    uint32_t ub = (uint32_t)__popcll(km) * WAVE;
+                    if (nchunks && ((km >> (nchunks - 1)) & 1ull))
+                        ub -= nchunks * WAVE - tn;  // the last chunk of the tile may be partial
+                    if (lane == j)
+                        my_cnt += ub;
+                    continue;
+                }
+                uint32_t run = (phase == PH_COUNT) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)my_cursor, j);
                 const uint32_t run0 = run;
                 uint32_t mn = 0xffffffffu;
                 while (km)
@@ -1251,43 +1275,39 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                     // "+ 0.0f" of the reference is the identity and is not issued
                     const float da = a0 * a0 + (a1 * a1 + a2 * a2);
                     const float db = b0 * b0 + (b1 * b1 + b2 * b2);
-                    const bool ia = v0 && da <= r2, ib = v1 && db <= r2;      // :315 inclusive
+                    const bool ia = v0 && da <= r2, ib = v1 && db <= r2;  // :315 inclusive
                     const unsigned long long ma = __ballot(ia), mb = __ballot(ib);
                     const uint32_t na = __popcll(ma);
-                    if (pass == 0)
-                    {
-                        if (ia)
-                            mn = min(mn, __float_as_uint(n0.w));
-                        if (ib)
-                            mn = min(mn, __float_as_uint(n1.w));
-                    }
-                    if (pass == 1)
+                    if (phase == PH_FILL)
                     {
                         if (ia)
                         {
+                            mn = min(mn, __float_as_uint(n0.w));
                             // one word per neighbour: index | (within the absorb radius) << 31.  For a float d,
                             // (double)d <= thr of src/clustering.cpp:102 <=> d <= thr_f
                             nb_idx[run + __popcll(ma & lt)] = __float_as_uint(n0.w) | (da <= thr_f ? 0x80000000u : 0u);
                         }
                         if (ib)
                         {
+                            mn = min(mn, __float_as_uint(n1.w));
                             nb_idx[run + na + __popcll(mb & lt)] =
                                 __float_as_uint(n1.w) | (db <= thr_f ? 0x80000000u : 0u);
                         }
                     }
                     run += na + __popcll(mb);
                 }
-                if (pass == 0)
+                if (phase == PH_FILL)
                     mn = (uint32_t)__builtin_amdgcn_readlane((int)lpx_wave_min63_u32(mn), WAVE - 1);
                 if (lane == j)
                 {
-                    if (pass == 0)
-                    {
+                    if (phase == PH_COUNT)
                         my_cnt += run;
-                        my_min = min(my_min, mn);
-                    }
                     else
+                    {
+                        my_min = min(my_min, mn);
                         my_cursor += run - run0;
+                        my_len += run - run0;
+                    }
                 }
             }
             if (BLOCK)
@@ -1295,73 +1315,52 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
             else
                 Coop<WAVE>::sync();
         }
-        if (pass == 0)
+        staged_once = true;
+        const bool mine = active && (!BLOCK || (lane % NB_WAVES) == w);
+        if (phase == PH_FILL)
         {
-            // first link of the union-find forest: every point under its smallest neighbour
-            if (parent && active && (!BLOCK || (lane % NB_WAVES) == w))
-                parent[qi] = my_min;
-            if (BLOCK)
+            if (mine)
             {
-                // gather the per-query counts (query j lives in lane j of wavefront j % 4)
-                if (active && (lane % NB_WAVES) == w)
-                    s_q[0][lane] = my_cnt;
-                __syncthreads();
-                if (w == 0)
-                {
-                    const uint32_t c = active ? s_q[0][lane] : 0u;
-                    const uint32_t incl = lpx_wave_incl_scan_u32(c);
-                    const uint32_t total = __shfl(incl, WAVE - 1, 64);
-                    unsigned long long base = 0;
-                    if (lane == 0)
-                        base = atomicAdd((unsigned long long *)&frame->nb_total, (unsigned long long)total);
-                    base = __shfl(base, 0, 64);
-                    const bool ok = base + total <= cap;
-                    if (ok && active)
-                    {
-                        const uint32_t o = (uint32_t)base + incl - c;
-                        s_q[1][lane] = o;
-                        off[qi] = o;
-                        len[qi] = c;
-                    }
-                    if (lane == 0)
-                    {
-                        s_n[3] = ok ? 0u : 1u;
-                        if (!ok)
-                            frame->status = (uint32_t)(-LPX_ERR_CAPACITY);
-                        if (dbg)
-                        {
-                            dbg[gid * 8 + 0] = T;
-                            dbg[gid * 8 + 1] = n_cur;
-                            dbg[gid * 8 + 2] = nq;
-                            dbg[gid * 8 + 3] = total;
-                            dbg[gid * 8 + 4] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (s_n[3])
-                    return;  // nb_total keeps growing to the required size
-                if (active && (lane % NB_WAVES) == w)
-                    my_cursor = s_q[1][lane];
+                len[qi] = my_len;
+                // first link of the union-find forest: every point under its smallest neighbour
+                if (parent)
+                    parent[qi] = my_min;
             }
-            else
+            const uint32_t wrote = lpx_wave_sum_u32(mine ? my_len : 0u);
+            if (lane == 0 && wrote)
+                atomicAdd((unsigned long long *)&frame->nb_entries, (unsigned long long)wrote);
+            break;
+        }
+        // allocate the group's list storage: one 64-bit atomic bump of frame->nb_total per group
+        bool ok;
+        if (BLOCK)
+        {
+            // gather the per-query sizes (query j lives in lane j of wavefront j % 4)
+            if (mine)
+                s_q[0][lane] = my_cnt;
+            __syncthreads();
+            if (w == 0)
             {
-                const uint32_t total = __builtin_amdgcn_readlane((int)my_cnt, 0);
+                const uint32_t c = active ? s_q[0][lane] : 0u;
+                const uint32_t incl = lpx_wave_incl_scan_u32(c);
+                const uint32_t total = __shfl(incl, WAVE - 1, 64);
                 unsigned long long base = 0;
+                unsigned long long *counter = (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_total : &frame->nb_total);
                 if (lane == 0)
-                    base = atomicAdd((unsigned long long *)&frame->nb_total, (unsigned long long)total);
+                    base = atomicAdd(counter, (unsigned long long)total);
                 base = __shfl(base, 0, 64);
-                if (base + total > cap)
+                const bool fits = base + total <= (phase == PH_RESERVE ? cap_rs : cap);
+                if (phase == PH_RESERVE)
+                    base += cap;  // the single-pass region lies behind the exact one
+                if (fits && active)
                 {
-                    if (lane == 0)
-                        frame->status = (uint32_t)(-LPX_ERR_CAPACITY);
-                    return;
+                    const uint32_t o = (uint32_t)base + incl - c;
+                    s_q[1][lane] = o;
+                    off[qi] = o;
                 }
-                my_cursor = (uint32_t)base;
                 if (lane == 0)
                 {
-                    off[qi] = my_cursor;
-                    len[qi] = my_cnt;
+                    s_n[3] = fits ? 0u : 1u;
                     if (dbg)
                     {
                         dbg[gid * 8 + 0] = T;
@@ -1372,6 +1371,53 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                     }
                 }
             }
+            __syncthreads();
+            ok = s_n[3] == 0;
+            if (ok && mine)
+                my_cursor = s_q[1][lane];
+            __syncthreads();  // s_q / s_n are reused if the group has to count
+        }
+        else
+        {
+            const uint32_t total = __builtin_amdgcn_readlane((int)my_cnt, 0);
+            unsigned long long base = 0;
+            unsigned long long *counter = (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_total : &frame->nb_total);
+            if (lane == 0)
+                base = atomicAdd(counter, (unsigned long long)total);
+            base = __shfl(base, 0, 64);
+            ok = base + total <= (phase == PH_RESERVE ? cap_rs : cap);
+            if (phase == PH_RESERVE)
+                base += cap;
+            if (ok)
+            {
+                my_cursor = (uint32_t)base;
+                if (lane == 0)
+                {
+                    off[qi] = my_cursor;
+                    if (dbg)
+                    {
+                        dbg[gid * 8 + 0] = T;
+                        dbg[gid * 8 + 1] = n_cur;
+                        dbg[gid * 8 + 2] = nq;
+                        dbg[gid * 8 + 3] = total;
+                        dbg[gid * 8 + 4] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+                    }
+                }
+            }
+        }
+        if (ok)
+            phase = PH_FILL;
+        else if (phase == PH_RESERVE)
+        {
+            phase = PH_COUNT;
+            my_cnt = 0;
+        }
+        else
+        {
+            // exact lengths do not fit: nb_total keeps growing to (at least) the required size
+            if (lane == 0 && (!BLOCK || w == 0))
+                atomicCAS(&frame->status, 0u, (uint32_t)(-LPX_ERR_CAPACITY));  // an earlier error code stays
+            return;
         }
     }
     if (dbg && lane == 0 && (!BLOCK || w == 0))
@@ -1540,7 +1586,7 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
         const uint32_t nbk = groups / 2;
         hipLaunchKernelGGL(nb_group_kernel, dim3(nbk + (nbk + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b),
                            dim3(NB_THREADS), 0, ctx->stream, (const Node *)PR, frame, r2, rr, thr_f, len, off,
-                           (uint32_t *)ctx->nb_idx.p, ctx->cap_nb,
+                           (uint32_t *)ctx->nb_idx.p, ctx->cap_nb, ctx->cap_rs,
                            hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf,
                            lpx_fv(ctx));
     }

@@ -67,6 +67,8 @@ __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacl
         f.replay_entries = 0;
         f.n_expansions = 0;
         f.n_in = n.v[blockIdx.z];
+        f.nb_entries = 0;
+        f.rs_total = 0;
         *frame = f;
     }
 }
