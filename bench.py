@@ -13,9 +13,10 @@ iterations, FEC d = 0.5 m (distance_squared 0.25), quality 0.5.  Frames are inde
 GPUs every rank runs its own batch (frame i -> GPU i mod N, "weak" scaling) and there is no
 data-path collective; RCCL is used only for the barrier and the max-over-ranks time.
 
-Prints ONE JSON line (rank 0) with the metric, a `roofline` object for the dominant kernel stage
-(HIP-event time measured live in a second, profiled run of the same K steps) and, at N = 1, a
-`cpu_baseline` object: the oracle restatement of the reference path timed on this host.
+Prints ONE JSON line (rank 0) with the metric, a `roofline` object for the kernel that fills the device
+(HIP-event times measured live: the same K steps under load, and one step with every chain alone on the
+device) and, at N = 1, a `cpu_baseline` object: the oracle restatement of the reference path timed on this
+host.
 """
 import argparse
 import json
@@ -43,16 +44,16 @@ CLU = dict(distance_squared=0.25, cluster_quality=0.5)
 # stage -> kernel that dominates it (names as rocprofv3 prints them), for the PMC traffic lookup
 STAGE_KERNEL = {"ingest": "ingest_kernel", "xsort": "radix_scatter_kernel<unsigned int, true>", "gather": "gather_kernel",
                 "zsort": "radix_scatter_kernel<unsigned long, false>", "seeds": "seed_kernel",
-                "plane_passes": "plane_pass_kernel<false>", "compact": "compact_kernel", "kd_build": "kd_block_kernel",
-                "kd_preorder": "kd_preorder_kernel", "cc_hook": "cc_hook_kernel", "neighbours": "nb_group_kernel",
+                "plane_passes": "plane_single_kernel", "compact": "compact_kernel", "kd_build": "kd_block_kernel",
+                "cc_hook": "cc_hook_kernel", "neighbours": "nb_group_kernel",
                 "components": "radix_scatter_kernel<unsigned int, true>", "replay": "replay_lds_kernel",
                 "labels": "relabel_kernel"}
 
 
 def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None):
-    """Algorithmic HBM bytes of one launch group of `stage` for a frame with N points, M obstacle
-    points, E neighbour-list entries, E_replay entries in the lists of the points the reference would
-    expand (DESIGN.md, "Kernels and their algorithmic bytes")."""
+    """Algorithmic HBM bytes of `stage` for ONE frame with N points, M obstacle points, E neighbour-list
+    entries, E_replay entries in the lists of the points the reference would expand ("Kernels and
+    their algorithmic bytes").  A launch group of a batched chain processes frames_per_launch frames."""
     if E_replay is None:
         E_replay = E
     return {
@@ -61,23 +62,23 @@ def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None):
         "gather": N * (4 + 12 + 12 + 8),             # index, gather, x-sorted SoA, (segment, z) key
         "zsort": 5 * N * (8 + 8 + 8),
         "seeds": min(N, 5000 * P) * 8 + P * 64,
-        "plane_passes": N * 12 * (I + 1) + N,        # I+1 streams of the SoA + flag write
-        "compact": N * (1 + 4 + 4 + 4) + M * 12,     # flag, index, label, list, obstacle SoA
+        "plane_passes": N * 12 + N,                  # the SoA is read once and stays in registers; flag write
+        "compact": N * (1 + 4 + 4 + 4) + M * (12 + 16),  # flag, index, label, list, obstacle SoA + kd nodes
         "kd_build": M * 16 * 2 * 17,                 # ~log2(M) levels, each reads + writes the node array
-        "kd_preorder": M * 32,                       # node array read + pre-order copy write
-        "cc_hook": E * 4 + M * (8 + 8),              # list indices read, offsets/lengths, parents
-        "neighbours": M * 16 + E * 8 + M * 8,        # nodes read once, (index, distance) lists written, off/len
+        "cc_hook": E * 4 + M * (8 + 8),              # list words read, offsets/lengths, parents
+        "neighbours": M * 16 + E * 4 + M * 8,        # nodes read once, one word per neighbour written, off/len
         "components": M * (4 + 4 + 4 + 1 + 4 + 8) + 3 * M * 24,
-        "replay": E_replay * 8 + M * (8 + 1 + 4 + 4 + 4),  # expanded lists, off/len, state, seed, queue, valid
+        "replay": E_replay * 4 + M * (8 + 4 + 4 + 4),  # expanded lists, off/len, seed, queue, valid
         "labels": M * (4 + 4 + 4 + 4),
+        "groups": M * (4 + 4 + 4) + 2 * M * 24,
     }[stage]
 
 
 def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's dominant kernel from the committed rocprofv3 --pmc summary
-    (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half of a coalesced read on
-    gfx950 (guides/MI355X_MICROARCH.md, HBM).  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")
+    """HBM bytes per launch of the stage's dominant kernel from the committed rocprofv3 --pmc summary of this
+    same command (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half of a coalesced
+    read on gfx950 (guides/MI355X_MICROARCH.md, HBM).  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_fetch_write_per_kernel.json")
     try:
         d = json.load(open(path))
         k = next(v for name, v in d.items() if name.startswith(STAGE_KERNEL[stage][:40]))
@@ -109,9 +110,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=128, help="frames in one step (per GPU)")
+    ap.add_argument("--frames-per-step", type=int, default=192, help="frames in one step (per GPU)")
     ap.add_argument("--batch", type=int, default=16, help="frames per launch chain (lpx_segment_cluster_batch_device)")
-    ap.add_argument("--contexts", type=int, default=8, help="concurrent lpx contexts (HIP streams) per GPU")
+    ap.add_argument("--contexts", type=int, default=12, help="concurrent lpx contexts (HIP streams) per GPU")
     ap.add_argument("--threads", type=int, default=2, help="host threads that enqueue (ctypes releases the GIL)")
     ap.add_argument("--neighbour-words", type=int, default=256, help="neighbour workspace per point (lpx_reserve)")
     ap.add_argument("--single-pass-words", type=int, default=640,
@@ -216,24 +217,46 @@ def main():
 
     elapsed, total_points_per_step = aggregate(elapsed, points_per_step, dev, world)
 
-    # ---- roofline of the dominant stage: same K steps with HIP-event pairs around every stage ----
+    # ---- stage times: HIP-event pairs around every stage (lpx_profile_*), on the streams the kernels run on ----
+    # (1) the same K steps under the same load as the timed region: what a launch group costs while eleven other
+    #     chains compete for the device (mostly waiting for free CUs);
+    # (2) every chain of one step alone on the device: the launch duration of the kernels themselves.
+    # The roofline object is for the kernel that dominates (2) -- the one that fills the device -- and also
+    # carries its average duration under load.
     roofline = None
     stage_ms = {}
     if rank == 0:
-        for c in ctxs:
-            c.profile_enable(True)
-        for _ in range(args.steps):
-            step()
-        sync()
-        launches = {}
-        for c in ctxs:
-            for k, (ms, cnt) in c.profile_read().items():
-                stage_ms[k] = stage_ms.get(k, 0.0) + ms
-                launches[k] = launches.get(k, 0) + cnt
-            c.profile_enable(False)
-        dom = max(stage_ms, key=stage_ms.get)
-        n_launch = max(1, launches[dom])
-        avg_ms = stage_ms[dom] / n_launch
+        def profiled(run):
+            for c in ctxs:
+                c.profile_enable(True)
+            run()
+            sync()
+            ms_tot, n_tot = {}, {}
+            for c in ctxs:
+                for k, (ms, cnt) in c.profile_read().items():
+                    ms_tot[k] = ms_tot.get(k, 0.0) + ms
+                    n_tot[k] = n_tot.get(k, 0) + cnt
+                c.profile_enable(False)
+            return ms_tot, n_tot
+
+        def loaded():
+            for _ in range(args.steps):
+                step()
+
+        def isolated():
+            for k, (lo, hi) in enumerate(chains):
+                c = ctxs[k % C]
+                c.segment_cluster_batch_device(n_points[lo:hi], d_pts[lo].data_ptr(), 32, pitch, scfg, ccfg,
+                                               d_labels[lo].data_ptr(), d_gidx[lo].data_ptr(), d_oidx[lo].data_ptr(),
+                                               d_planes[lo].data_ptr(), d_clabels[lo].data_ptr(),
+                                               d_counts[lo].data_ptr())
+                c.synchronize()
+
+        stage_ms, launches = profiled(loaded)
+        iso_ms, iso_launches = profiled(isolated)
+        dom = max(iso_ms, key=iso_ms.get)
+        avg_ms = iso_ms[dom] / max(1, iso_launches[dom])
+        avg_ms_loaded = stage_ms[dom] / max(1, launches[dom])
         # one launch (group) of a stage covers the B frames of a chain: frame-averaged sizes of this rank's
         # batch times the frames per chain; list sizes come from the device counters of the frame slots
         frames_per_launch = float(np.mean([hi - lo for lo, hi in chains]))
@@ -244,11 +267,12 @@ def main():
         E_replay = float(np.mean([f["replay_entries"] for f in fst]))
         algo = frames_per_launch * algorithmic_bytes(dom, Nn, Mm, E, SEG["number_of_iterations"], P, E_replay)
         achieved = algo / (avg_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(dom)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(algo),
-                    "frames_per_launch": frames_per_launch}
+        roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "achieved": round(achieved, 3),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                    "traffic": pmc_traffic(dom), "avg_launch_ms": round(avg_ms, 5),
+                    "avg_launch_ms_under_load": round(avg_ms_loaded, 5), "algorithmic_bytes_per_launch": int(algo),
+                    "frames_per_launch": frames_per_launch,
+                    "stage_ms_per_launch_alone": {k: round(v / max(1, iso_launches[k]), 5) for k, v in iso_ms.items()}}
 
     # ---- CPU baseline: the oracle restatement on this host, bounded sample (rank 0, N = 1 only) ----
     cpu = None
@@ -292,7 +316,7 @@ def main():
                        "frames_per_s": round(F * world * args.steps / elapsed, 2)},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "stage_ms_per_frame": {k: round(v / (args.steps * F), 5) for k, v in stage_ms.items()},
+            "stage_ms_per_frame_under_load": {k: round(v / (args.steps * F), 5) for k, v in stage_ms.items()},
         }
         print(json.dumps(line))
     if world > 1:

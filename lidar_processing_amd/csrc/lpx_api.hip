@@ -162,7 +162,7 @@ static int ensure_for(lpx_ctx *ctx, uint32_t n)
 // profiling
 // ------------------------------------------------------------------------------------------------
 static const char *k_stage_names[ST_COUNT] = {"ingest",   "xsort",   "gather",  "zsort", "seeds",  "plane_passes", "compact",
-                                              "kd_build", "kd_preorder", "cc_hook", "neighbours", "components", "replay", "labels",
+                                              "kd_build", "cc_hook", "neighbours", "components", "replay", "labels",
                                               "groups"};
 
 StageTimer::StageTimer(lpx_ctx *c, int s) : ctx(c), stage(s)

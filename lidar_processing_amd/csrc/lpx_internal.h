@@ -19,8 +19,7 @@ enum lpx_stage
     ST_SEEDS,        // per-segment seed thresholds
     ST_PLANE,        // fused inlier test + moment accumulation + 3x3 solve (I launches + seed pass)
     ST_COMPACT,      // final flags -> labels, ground/obstacle lists, obstacle SoA
-    ST_KD_BUILD,     // kd-tree layout (libstdc++ introselect order)
-    ST_NB_COUNT,     // pre-order rank layout of the kd nodes
+    ST_KD_BUILD,     // kd-tree layout (libstdc++ introselect order) + pre-order rank layout
     ST_NB_SCAN,      // union-find hooking over the neighbour lists
     ST_NB_FILL,      // radius neighbour lists (count + allocate + fill, one launch)
     ST_CC,           // flatten roots, sort members by (root, index), component ranges

@@ -64,7 +64,7 @@ def test_profile_stage_names(liblpx):
     liblpx.lpx_profile_stage_name.restype = C.c_char_p
     n = liblpx.lpx_profile_stage_count()
     names = [liblpx.lpx_profile_stage_name(i).decode() for i in range(n)]
-    assert n == 15 and len(set(names)) == n and "replay" in names and "plane_passes" in names
+    assert n == 14 and len(set(names)) == n and "replay" in names and "plane_passes" in names
     sys.path.insert(0, ROOT)
     import bench
     for s in names:  # every stage has an algorithmic-bytes formula

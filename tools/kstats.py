@@ -5,9 +5,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 24]:
-    n = r["Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
-    if "<" in r["Name"].split("(")[0]:
-        n = r["Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+    n = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     print("%-44s calls %6d total_ms %9.2f avg_us %9.1f %6.2f%%" % (
         n[:44], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
         float(r["Percentage"])))
