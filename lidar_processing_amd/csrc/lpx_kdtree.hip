@@ -1188,19 +1188,26 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
             const uint32_t tn = min(tile_cap, T - t0);
             // a group whose candidates fit one tile keeps tile and chunk boxes from its first phase
             const bool stage = !staged_once || T > tile_cap;
-            for (uint32_t c = tix; stage && c < tn; c += nthr)
+            // the last chunk is padded with nodes infinitely far away, so the distance loop needs no bounds test
+            const uint32_t tn_pad = (tn + WAVE - 1) & ~(uint32_t)(WAVE - 1);
+            for (uint32_t c = tix; stage && c < tn_pad; c += nthr)
             {
-                const uint32_t ci = t0 + c;
-                uint32_t lo = 0, hi = n_cur - 1;  // last interval with pre <= ci
-                while (lo < hi)
+                Node nd = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __uint_as_float(0xffffffffu));
+                if (c < tn)
                 {
-                    const uint32_t m2 = (lo + hi + 1) / 2;
-                    if (pre[m2] <= ci)
-                        lo = m2;
-                    else
-                        hi = m2 - 1;
+                    const uint32_t ci = t0 + c;
+                    uint32_t lo = 0, hi = n_cur - 1;  // last interval with pre <= ci
+                    while (lo < hi)
+                    {
+                        const uint32_t m2 = (lo + hi + 1) / 2;
+                        if (pre[m2] <= ci)
+                            lo = m2;
+                        else
+                            hi = m2 - 1;
+                    }
+                    nd = PR[cur[lo].rank + (ci - pre[lo])];
                 }
-                tile[c] = PR[cur[lo].rank + (ci - pre[lo])];
+                tile[c] = nd;
             }
             if (BLOCK)
                 __syncthreads();
@@ -1266,17 +1273,16 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                     const uint32_t c1 = two ? (uint32_t)(__ffsll((long long)km) - 1) * WAVE : c0;
                     if (two)
                         km &= km - 1;
-                    const bool v0 = c0 + lane < tn, v1 = two && (c1 + lane < tn);
-                    const Node n0 = tile[v0 ? c0 + lane : 0u];
-                    const Node n1 = tile[v1 ? c1 + lane : 0u];
+                    const Node n0 = tile[c0 + lane];
+                    const Node n1 = tile[c1 + lane];
                     const float a0 = qx - n0.x, a1 = qy - n0.y, a2 = qz - n0.z;
                     const float b0 = qx - n1.x, b1 = qy - n1.y, b2 = qz - n1.z;
                     // src/kdtree.hpp:145-157 sums d^2 from the last axis into 0.0f; a square is never -0, so the
                     // "+ 0.0f" of the reference is the identity and is not issued
                     const float da = a0 * a0 + (a1 * a1 + a2 * a2);
                     const float db = b0 * b0 + (b1 * b1 + b2 * b2);
-                    const bool ia = v0 && da <= r2, ib = v1 && db <= r2;  // :315 inclusive
-                    const unsigned long long ma = __ballot(ia), mb = __ballot(ib);
+                    const bool ia = da <= r2, ib = two && db <= r2;  // :315 inclusive; padding is never in range
+                    const unsigned long long ma = __ballot(ia), mb = two ? __ballot(db <= r2) : 0ull;
                     const uint32_t na = __popcll(ma);
                     if (phase == PH_FILL)
                     {

@@ -249,6 +249,34 @@ def test_workspace_retry_keeps_the_tree_of_the_first_attempt(frame):
         c.close()
 
 
+@pytest.mark.parametrize("words", [0, 64, 2048])
+def test_single_pass_region_never_changes_results(words):
+    """lists reserved by an upper bound (lpx_reserve_single_pass) or counted exactly, or a mix of both when the
+    region is too small for every kd group: same labels as the reference build, same neighbour lists"""
+    from lidar_processing_amd import Context
+    frame = "0000000153"
+    pts = load_frame(frame)
+    obs = pts[oracle.segment(pts, oracle.SegCfg(number_of_planar_partitions=6, number_of_iterations=5))["obstacle_idx"]]
+    c = Context(0)
+    try:
+        c.reserve_single_pass(words)
+        c.reserve(obs.shape[0])
+        lab, nc = c.cluster(obs, ClusteringConfiguration(0.25, 0.5))
+        assert np.array_equal(lab, gold()[f"clu_{frame}_p6i5_d025q05_labels"])
+        st = c.frame_stats()
+        assert st["neighbour_words"] >= st["neighbour_entries"]
+        if words == 0:
+            assert st["neighbour_words"] == st["neighbour_entries"]  # exact lengths only
+        sub = obs[:20000]
+        off, idx, dist = c.dbg_neighbours(sub[:, :3], 0.25)
+        for i in (0, 1234, 19999):
+            want_i, want_d = oracle.radius_search(sub[:, :3], sub[i, :3], 0.25)
+            assert np.array_equal(idx[off[i]:off[i + 1]], want_i)
+            assert np.array_equal(dist[off[i]:off[i + 1]].view(np.uint32), want_d.view(np.uint32))
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("frame", FRAMES)
 def test_fused_segment_cluster(ctx, frame):
     """lpx_segment_cluster == the two reference calls back to back (src/processor.cpp:150-178)"""
