@@ -313,6 +313,19 @@ __device__ __forceinline__ uint32_t lpx_umin(uint32_t a, uint32_t b)
 {
     return a < b ? a : b;
 }
+// the same inside every row of 16 lanes: the result of row r is valid in lane 16 * r + 15
+#define LPX_DPP_ROW_REDUCE(T, NAME, OP, TOI, FROMI)                                                    \
+    __device__ __forceinline__ T NAME(T v)                                                             \
+    {                                                                                                  \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x111, 0xf, 0xf, false)));         \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x112, 0xf, 0xf, false)));         \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x114, 0xf, 0xf, false)));         \
+        v = OP(v, FROMI(__builtin_amdgcn_update_dpp(TOI(v), TOI(v), 0x118, 0xf, 0xf, false)));         \
+        return v;                                                                                      \
+    }
+LPX_DPP_ROW_REDUCE(float, lpx_row_min15_f32, fminf, __float_as_int, __int_as_float)
+LPX_DPP_ROW_REDUCE(float, lpx_row_max15_f32, fmaxf, __float_as_int, __int_as_float)
+#undef LPX_DPP_ROW_REDUCE
 LPX_DPP_REDUCE(float, lpx_wave_min63_f32, fminf, __float_as_int, __int_as_float)
 LPX_DPP_REDUCE(float, lpx_wave_max63_f32, fmaxf, __float_as_int, __int_as_float)
 LPX_DPP_REDUCE(uint32_t, lpx_wave_min63_u32, lpx_umin, (int), (uint32_t))

@@ -915,6 +915,7 @@ constexpr int NB_THREADS = NB_WAVES * WAVE;
 constexpr int NB_SEQ = 512;     // interval items in LDS per block (6 KiB)
 constexpr int NB_NODES = 1024;  // candidate nodes staged in LDS per block (16 KiB): 6 workgroups per CU
 constexpr int NB_BUCKET = 64;
+constexpr int NB_GRAN = 16;     // candidates per cull granule: one row of 16 lanes
 constexpr uint32_t NB_FINAL = 0x80000000u;
 
 struct Item
@@ -1060,8 +1061,8 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
     parent = lpx_slot(parent, fv.fs);
     nb_idx = lpx_slot(nb_idx, fv.fs_nb);
     __shared__ uint32_t s_pre[NB_SEQ / 2 + 8 * NB_WAVES];
-    __shared__ Node s_tile[NB_NODES];
-    __shared__ float s_cbox[NB_NODES / WAVE][6];
+    __shared__ Node s_tile[NB_NODES + NB_WAVES * NB_GRAN];  // + one granule of far-away nodes per wavefront
+    __shared__ float s_cbox[NB_NODES / NB_GRAN][6];
     __shared__ uint32_t s_q[2][WAVE];  // per-query counts / write cursors (BLOCK mode)
     __shared__ uint32_t s_n[4];        // n_cur, T, cur offset, abort
     const uint32_t w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
@@ -1122,7 +1123,13 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
     Item *seqbuf = BLOCK ? s_seq : s_seq + w * (NB_SEQ / NB_WAVES);
     uint32_t *pre = BLOCK ? s_pre : s_pre + w * (NB_SEQ / 2 / NB_WAVES + 8);
     Node *tile = BLOCK ? s_tile : s_tile + w * (NB_NODES / NB_WAVES);
-    float(*cbox)[6] = BLOCK ? s_cbox : s_cbox + w * (NB_NODES / WAVE / NB_WAVES);
+    float(*cbox)[6] = BLOCK ? s_cbox : s_cbox + w * (NB_NODES / NB_GRAN / NB_WAVES);
+    // granule index (relative to `tile`) of this wavefront's far-away granule: what a distance step reads
+    // in the lane rows it has no surviving granule for
+    const uint32_t pad_g = BLOCK ? (uint32_t)(NB_NODES / NB_GRAN) + w
+                                 : (uint32_t)(NB_NODES / NB_GRAN) + w - w * (NB_NODES / NB_WAVES / NB_GRAN);
+    if (lane < (uint32_t)NB_GRAN)
+        s_tile[NB_NODES + w * NB_GRAN + lane] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __uint_as_float(0xffffffffu));
     const uint32_t nthr = BLOCK ? NB_THREADS : WAVE;
     const uint32_t tix = BLOCK ? threadIdx.x : lane;
     const uint32_t nwav = BLOCK ? NB_WAVES : 1;
@@ -1188,8 +1195,8 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
             const uint32_t tn = min(tile_cap, T - t0);
             // a group whose candidates fit one tile keeps tile and chunk boxes from its first phase
             const bool stage = !staged_once || T > tile_cap;
-            // the last chunk is padded with nodes infinitely far away, so the distance loop needs no bounds test
-            const uint32_t tn_pad = (tn + WAVE - 1) & ~(uint32_t)(WAVE - 1);
+            // the last granule is padded with nodes infinitely far away, so the distance loop needs no bounds test
+            const uint32_t tn_pad = (tn + NB_GRAN - 1) & ~(uint32_t)(NB_GRAN - 1);
             for (uint32_t c = tix; stage && c < tn_pad; c += nthr)
             {
                 Node nd = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __uint_as_float(0xffffffffu));
@@ -1213,24 +1220,27 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                 __syncthreads();
             else
                 Coop<WAVE>::sync();
-            // bounding box of each chunk of 64 consecutive candidates (rank order keeps them compact)
-            const uint32_t nchunks = (tn + WAVE - 1) / WAVE;
-            for (uint32_t c = wix; stage && c < nchunks; c += nwav)
+            // bounding box of each granule of 16 consecutive candidates (rank order keeps them compact): a
+            // wavefront reduces four granules at a time, one per row of 16 lanes, with DPP row shifts
+            const uint32_t ngran = tn_pad / NB_GRAN;
+            for (uint32_t s4 = wix * 4; stage && s4 < ngran; s4 += nwav * 4)
             {
-                const bool valid = c * WAVE + lane < tn;
-                const Node nd = tile[valid ? c * WAVE + lane : c * WAVE];
-                // DPP reductions (VALU only); the results are valid in lane 63
-                const float lo0 = lpx_wave_min63_f32(nd.x), lo1 = lpx_wave_min63_f32(nd.y);
-                const float lo2 = lpx_wave_min63_f32(nd.z), hi0 = lpx_wave_max63_f32(nd.x);
-                const float hi1 = lpx_wave_max63_f32(nd.y), hi2 = lpx_wave_max63_f32(nd.z);
-                if (lane == WAVE - 1)
+                const uint32_t c = s4 * NB_GRAN + lane;
+                const bool valid = c < tn;
+                // lanes past the end repeat the first node of their granule (which is always a real one)
+                const Node nd = tile[valid ? c : min(c & ~(uint32_t)(NB_GRAN - 1), tn - 1)];
+                const float lo0 = lpx_row_min15_f32(nd.x), lo1 = lpx_row_min15_f32(nd.y);
+                const float lo2 = lpx_row_min15_f32(nd.z), hi0 = lpx_row_max15_f32(nd.x);
+                const float hi1 = lpx_row_max15_f32(nd.y), hi2 = lpx_row_max15_f32(nd.z);
+                const uint32_t g = s4 + lane / NB_GRAN;
+                if ((lane % NB_GRAN) == NB_GRAN - 1 && g < ngran)
                 {
-                    cbox[c][0] = lo0;
-                    cbox[c][1] = lo1;
-                    cbox[c][2] = lo2;
-                    cbox[c][3] = hi0;
-                    cbox[c][4] = hi1;
-                    cbox[c][5] = hi2;
+                    cbox[g][0] = lo0;
+                    cbox[g][1] = lo1;
+                    cbox[g][2] = lo2;
+                    cbox[g][3] = hi0;
+                    cbox[g][4] = hi1;
+                    cbox[g][5] = hi2;
                 }
             }
             if (BLOCK)
@@ -1242,9 +1252,9 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                 const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), j));
                 const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), j));
                 const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), j));
-                // cull: lane c tests chunk c's box against the query sphere (conservatively)
+                // cull: lane g tests granule g's box against the query sphere (conservatively)
                 bool keep = false;
-                if (lane < nchunks)
+                if (lane < ngran)
                 {
                     const float ex = fmaxf(fmaxf(cbox[lane][0] - qx, qx - cbox[lane][3]), 0.0f);
                     const float ey = fmaxf(fmaxf(cbox[lane][1] - qy, qy - cbox[lane][4]), 0.0f);
@@ -1254,9 +1264,9 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                 unsigned long long km = __ballot(keep);
                 if (phase == PH_RESERVE)
                 {
-                    uint32_t ub = (uint32_t)__popcll(km) * WAVE;
-                    if (nchunks && ((km >> (nchunks - 1)) & 1ull))
-                        ub -= nchunks * WAVE - tn;  // the last chunk of the tile may be partial
+                    uint32_t ub = (uint32_t)__popcll(km) * NB_GRAN;
+                    if (ngran && ((km >> (ngran - 1)) & 1ull))
+                        ub -= ngran * NB_GRAN - tn;  // the last granule of the tile may be partial
                     if (lane == j)
                         my_cnt += ub;
                     continue;
@@ -1264,43 +1274,45 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                 uint32_t run = (phase == PH_COUNT) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)my_cursor, j);
                 const uint32_t run0 = run;
                 uint32_t mn = 0xffffffffu;
+                const uint32_t row = lane / NB_GRAN, col = lane % NB_GRAN;
                 while (km)
                 {
-                    // two surviving chunks per step: their LDS reads and compares overlap
-                    const uint32_t c0 = (uint32_t)(__ffsll((long long)km) - 1) * WAVE;
+                    // four surviving granules per step, one per row of 16 lanes, in candidate order; rows
+                    // without a granule read the far-away one
+                    uint32_t g0, g1 = pad_g, g2 = pad_g, g3 = pad_g;
+                    g0 = (uint32_t)(__ffsll((long long)km) - 1);
                     km &= km - 1;
-                    const bool two = km != 0;
-                    const uint32_t c1 = two ? (uint32_t)(__ffsll((long long)km) - 1) * WAVE : c0;
-                    if (two)
+                    if (km)
+                    {
+                        g1 = (uint32_t)(__ffsll((long long)km) - 1);
                         km &= km - 1;
-                    const Node n0 = tile[c0 + lane];
-                    const Node n1 = tile[c1 + lane];
+                    }
+                    if (km)
+                    {
+                        g2 = (uint32_t)(__ffsll((long long)km) - 1);
+                        km &= km - 1;
+                    }
+                    if (km)
+                    {
+                        g3 = (uint32_t)(__ffsll((long long)km) - 1);
+                        km &= km - 1;
+                    }
+                    const uint32_t gs = row == 0 ? g0 : (row == 1 ? g1 : (row == 2 ? g2 : g3));
+                    const Node n0 = tile[gs * NB_GRAN + col];
                     const float a0 = qx - n0.x, a1 = qy - n0.y, a2 = qz - n0.z;
-                    const float b0 = qx - n1.x, b1 = qy - n1.y, b2 = qz - n1.z;
                     // src/kdtree.hpp:145-157 sums d^2 from the last axis into 0.0f; a square is never -0, so the
                     // "+ 0.0f" of the reference is the identity and is not issued
                     const float da = a0 * a0 + (a1 * a1 + a2 * a2);
-                    const float db = b0 * b0 + (b1 * b1 + b2 * b2);
-                    const bool ia = da <= r2, ib = two && db <= r2;  // :315 inclusive; padding is never in range
-                    const unsigned long long ma = __ballot(ia), mb = two ? __ballot(db <= r2) : 0ull;
-                    const uint32_t na = __popcll(ma);
-                    if (phase == PH_FILL)
+                    const bool ia = da <= r2;  // :315 inclusive; padding is never in range
+                    const unsigned long long ma = __ballot(ia);
+                    if (phase == PH_FILL && ia)
                     {
-                        if (ia)
-                        {
-                            mn = min(mn, __float_as_uint(n0.w));
-                            // one word per neighbour: index | (within the absorb radius) << 31.  For a float d,
-                            // (double)d <= thr of src/clustering.cpp:102 <=> d <= thr_f
-                            nb_idx[run + __popcll(ma & lt)] = __float_as_uint(n0.w) | (da <= thr_f ? 0x80000000u : 0u);
-                        }
-                        if (ib)
-                        {
-                            mn = min(mn, __float_as_uint(n1.w));
-                            nb_idx[run + na + __popcll(mb & lt)] =
-                                __float_as_uint(n1.w) | (db <= thr_f ? 0x80000000u : 0u);
-                        }
+                        mn = min(mn, __float_as_uint(n0.w));
+                        // one word per neighbour: index | (within the absorb radius) << 31.  For a float d,
+                        // (double)d <= thr of src/clustering.cpp:102 <=> d <= thr_f
+                        nb_idx[run + __popcll(ma & lt)] = __float_as_uint(n0.w) | (da <= thr_f ? 0x80000000u : 0u);
                     }
-                    run += na + __popcll(mb);
+                    run += (uint32_t)__popcll(ma);
                 }
                 if (phase == PH_FILL)
                     mn = (uint32_t)__builtin_amdgcn_readlane((int)lpx_wave_min63_u32(mn), WAVE - 1);
