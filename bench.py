@@ -110,12 +110,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=192, help="frames in one step (per GPU)")
-    ap.add_argument("--batch", type=int, default=16, help="frames per launch chain (lpx_segment_cluster_batch_device)")
-    ap.add_argument("--contexts", type=int, default=12, help="concurrent lpx contexts (HIP streams) per GPU")
+    ap.add_argument("--frames-per-step", type=int, default=256, help="frames in one step (per GPU)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per launch chain (lpx_segment_cluster_batch_device)")
+    ap.add_argument("--contexts", type=int, default=8, help="concurrent lpx contexts (HIP streams) per GPU")
     ap.add_argument("--threads", type=int, default=2, help="host threads that enqueue (ctypes releases the GIL)")
     ap.add_argument("--neighbour-words", type=int, default=256, help="neighbour workspace per point (lpx_reserve)")
-    ap.add_argument("--single-pass-words", type=int, default=640,
+    ap.add_argument("--single-pass-words", type=int, default=384,
                     help="extra neighbour workspace per point for single-pass lists (lpx_reserve_single_pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -889,6 +889,9 @@ __device__ void uf_unite(uint32_t *parent, uint32_t a, uint32_t b)
         const uint32_t old = atomicCAS(parent + a, a, b);  // hook the larger root under the smaller
         if (old == a)
             return;
+        // a was no root any more (the cached find saw an old value): the CAS returned its current parent
+        // from the coherence point, an ancestor -- continue from there instead of trusting the cache again
+        a = old;
     }
 }
 
