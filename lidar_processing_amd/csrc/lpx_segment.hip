@@ -149,7 +149,8 @@ __global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float *__
     uint32_t seg = prm.n_per ? p / prm.n_per : prm.P;
     if (seg > prm.P)
         seg = prm.P;  // the N mod P tail (Q2) sorts behind every segment
-    zkey[p] = ((uint64_t)seg << 32) | lpx_float_key(z);
+    if (zkey)  // only the sort-based seed path needs the composite keys
+        zkey[p] = ((uint64_t)seg << 32) | lpx_float_key(z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,6 +257,294 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
                 lo = mid + 1;
         }
         const uint32_t n_seed = (lo < nrem) ? lo : 0u;
+        SegState o;
+        o.lo_excl = (cut > 0) ? prm.z_floor : -INFINITY;
+        o.hi_incl = z_max;
+        o.has_seeds = n_seed > 0;
+        o.failed = (ns < 3) ? 2u : 0u;  // :224-229 nothing is labelled
+        o.plane[0] = o.plane[1] = o.plane[2] = o.plane[3] = 0.0f;
+        o.fitted = 0;
+        o.thr = 0.0f;
+        o.pad[0] = o.pad[1] = 0;
+        st[s] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// seeds without sorting the segment: the statistics of extract_initial_seeds (:151-217) only need the
+// n_lpr LOWEST z above the floor in ascending order (the float sum at :193-197 is sequential), plus two
+// counts.  One workgroup per segment keeps the segment's keys in registers, finds the key of rank n_rep
+// by a 4-round radix select on LDS histograms (9 + 9 + 9 + 5 bits, one private histogram per wavefront:
+// ground z values share their leading bits and would serialise a shared one), collects the keys below it, sorts
+// those <= 8192 keys in LDS (bitonic) and sums them with one lane.  Same results as seed_kernel over the
+// sorted segment; replaces five radix-sort passes over all N points.
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_PTS = 24;
+constexpr uint32_t SEL_MAX_POINTS = SEL_THREADS * SEL_PTS;  // 24576 points per segment
+constexpr uint32_t SEL_MAX_LPR = 8192;                     // keys sorted in LDS
+constexpr int SEL_BINS = 512;  // per wavefront; the 16 private histograms alias the sort buffer
+
+__device__ __forceinline__ uint32_t sel_block_sum(uint32_t v, uint32_t *red, uint32_t tid)
+{
+    v = lpx_wave_sum_u32(v);
+    if ((tid % WAVE) == 0)
+        red[tid / WAVE] = v;
+    __syncthreads();
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SEL_THREADS / WAVE; ++i)
+        s += red[i];
+    __syncthreads();
+    return s;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *__restrict__ ZS, SegParams prm,
+                                                                   SegState *__restrict__ st,
+                                                                   long long *__restrict__ acc,
+                                                                   uint32_t *__restrict__ ticket,
+                                                                   const FrameState *__restrict__ frame, size_t fs)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[SEL_MAX_LPR];
+    static_assert(SEL_BINS * (SEL_THREADS / WAVE) <= (int)SEL_MAX_LPR, "private histograms alias the sort buffer");
+    uint32_t *s_hist = s_buf;  // [wavefront][bin] during the select, before the buffer is filled
+    __shared__ uint32_t s_red[SEL_THREADS / WAVE];
+    __shared__ uint32_t s_pick[2];  // bin, count before the bin
+    __shared__ uint32_t s_fill;
+    __shared__ float s_zmax;
+    ZS = lpx_slot(ZS, fs);
+    st = lpx_slot(st, fs);
+    acc = lpx_slot(acc, fs);
+    ticket = lpx_slot(ticket, fs);
+    seg_bind(prm, lpx_slot(frame, fs));
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint32_t ns = prm.n_per;
+    const uint32_t base = s * ns;
+    if (tid < LPX_ACC_WORDS)
+        acc[s * LPX_ACC_WORDS + tid] = 0;
+    if (tid == 0)
+        ticket[s] = 0;
+
+    uint32_t key[SEL_PTS];
+    uint32_t vmask = 0;  // bit u: slot u holds a point of the segment
+#pragma unroll
+    for (int u = 0; u < SEL_PTS; ++u)
+    {
+        const uint32_t p = tid + u * SEL_THREADS;
+        const bool in = p < ns;
+        key[u] = in ? lpx_float_key(ZS[base + p]) : 0xffffffffu;
+        vmask |= (in ? 1u : 0u) << u;
+    }
+    // points at or below the floor are dropped, unless that leaves nothing (:171-182)
+    const uint32_t floor_key = lpx_float_key(prm.z_floor);
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < SEL_PTS; ++u)
+        c += ((vmask >> u) & 1u) && key[u] <= floor_key;
+    const uint32_t c_floor = sel_block_sum(c, s_red, tid);
+    const uint32_t cut = (c_floor < ns) ? c_floor : 0u;
+    const uint32_t nrem = ns - cut;
+    const uint32_t n_rep = min(nrem, prm.n_lpr);
+    uint32_t rmask = 0;  // bit u: slot u is in the remainder
+#pragma unroll
+    for (int u = 0; u < SEL_PTS; ++u)
+        rmask |= ((((vmask >> u) & 1u) && (cut == 0 || key[u] > floor_key)) ? 1u : 0u) << u;
+
+    // key K of rank n_rep (1-based) among the remainder, `need` = how many copies of K belong to the n_rep lowest
+    uint32_t prefix = 0, pmask = 0, need = n_rep;
+    if (n_rep)
+    {
+        const int shifts[4] = {23, 14, 5, 0}, bits[4] = {9, 9, 9, 5};
+        const uint32_t wv = tid / WAVE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            for (uint32_t i = tid; i < SEL_BINS * (SEL_THREADS / WAVE); i += SEL_THREADS)
+                s_hist[i] = 0;
+            __syncthreads();
+            const uint32_t dmask = (1u << bits[r]) - 1u;
+#pragma unroll
+            for (int u = 0; u < SEL_PTS; ++u)
+                if (((rmask >> u) & 1u) && (key[u] & pmask) == prefix)
+                    atomicAdd(&s_hist[wv * SEL_BINS + ((key[u] >> shifts[r]) & dmask)], 1u);
+            __syncthreads();
+            // bin totals over the wavefronts (thread t < 512 owns bin t), then the first bin whose inclusive
+            // prefix count reaches `need`
+            uint32_t h = 0;
+            if (tid < (uint32_t)SEL_BINS)
+                for (int ww = 0; ww < SEL_THREADS / WAVE; ++ww)
+                    h += s_hist[ww * SEL_BINS + tid];
+            const uint32_t incl = lpx_wave_incl_scan_u32(h);
+            if ((tid % WAVE) == WAVE - 1)
+                s_red[tid / WAVE] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (uint32_t i = 0; i < tid / WAVE; ++i)
+                wbase += s_red[i];
+            const uint32_t before = wbase + incl - h;  // keys in bins < tid
+            if (tid < (uint32_t)SEL_BINS && before < need && need <= before + h)
+            {
+                s_pick[0] = tid;
+                s_pick[1] = before;
+            }
+            __syncthreads();
+            prefix |= s_pick[0] << shifts[r];
+            pmask |= dmask << shifts[r];
+            need -= s_pick[1];
+            __syncthreads();
+        }
+    }
+    const uint32_t K = prefix;
+    // the n_rep lowest keys: everything below K, then `need` copies of K; padded to a power of two for the sort
+    uint32_t n_sort = 1;
+    while (n_sort < n_rep)
+        n_sort <<= 1;
+    if (tid == 0)
+        s_fill = 0;
+    for (uint32_t i = tid; i < SEL_MAX_LPR; i += SEL_THREADS)
+        s_buf[i] = 0xffffffffu;
+    __syncthreads();
+    if (n_rep)
+    {
+        // one LDS atomic per wavefront and slot, not per key
+        const unsigned long long lt = lpx_lanemask_lt();
+#pragma unroll
+        for (int u = 0; u < SEL_PTS; ++u)
+        {
+            const bool take = ((rmask >> u) & 1u) && key[u] < K;
+            const unsigned long long tm = __ballot(take);
+            if (tm)
+            {
+                uint32_t pos = 0;
+                if ((tid % WAVE) == 0)
+                    pos = atomicAdd(&s_fill, (uint32_t)__popcll(tm));
+                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                if (take)
+                    s_buf[pos + __popcll(tm & lt)] = key[u];
+            }
+        }
+        __syncthreads();
+        const uint32_t below = s_fill;  // == n_rep - need
+        for (uint32_t i = tid; i < need; i += SEL_THREADS)
+            s_buf[below + i] = K;
+        __syncthreads();
+        // Bitonic sort, ascending, of the 8 keys per thread i = 512 w + 64 t + lane.  A compare-exchange at
+        // distance j2 pairs: the same lane of another register (j2 = 64, 128, 256), another lane of the same
+        // register (j2 < 64, one cross-lane read) or another wavefront's block (j2 >= 512, through LDS with
+        // workgroup barriers: 10 of the 91 stages).
+        const uint32_t w = tid / WAVE, lane = tid % WAVE;
+        uint32_t e[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            e[t] = s_buf[w * 512 + t * WAVE + lane];
+        for (uint32_t k2 = 2; k2 <= n_sort; k2 <<= 1)
+            for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1)
+            {
+                if (j2 >= 512)
+                {
+                    __syncthreads();
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        s_buf[w * 512 + t * WAVE + lane] = e[t];
+                    __syncthreads();
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                    {
+                        const uint32_t i = w * 512 + t * WAVE + lane;
+                        const uint32_t pv = s_buf[(i ^ j2) & (SEL_MAX_LPR - 1)];
+                        const bool keep_min = ((i & j2) == 0) == ((i & k2) == 0);
+                        e[t] = keep_min ? min(e[t], pv) : max(e[t], pv);
+                    }
+                }
+                else if (j2 >= (uint32_t)WAVE)
+                {
+                    // registers (a, b = a + j2 / 64) of one thread: a holds the lower index of the pair
+#define SEL_CE(a, b)                                                              \
+    {                                                                             \
+        const bool up = (((w * 512 + (a) * WAVE + lane) & k2) == 0);              \
+        const uint32_t mn = min(e[a], e[b]), mx = max(e[a], e[b]);                \
+        e[a] = up ? mn : mx;                                                      \
+        e[b] = up ? mx : mn;                                                      \
+    }
+                    if (j2 == 64)
+                    {
+                        SEL_CE(0, 1) SEL_CE(2, 3) SEL_CE(4, 5) SEL_CE(6, 7)
+                    }
+                    else if (j2 == 128)
+                    {
+                        SEL_CE(0, 2) SEL_CE(1, 3) SEL_CE(4, 6) SEL_CE(5, 7)
+                    }
+                    else
+                    {
+                        SEL_CE(0, 4) SEL_CE(1, 5) SEL_CE(2, 6) SEL_CE(3, 7)
+                    }
+#undef SEL_CE
+                }
+                else
+                {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                    {
+                        const uint32_t i = w * 512 + t * WAVE + lane;
+                        const uint32_t pv = (uint32_t)__shfl_xor((int)e[t], (int)j2, WAVE);
+                        const bool keep_min = ((i & j2) == 0) == ((i & k2) == 0);
+                        e[t] = keep_min ? min(e[t], pv) : max(e[t], pv);
+                    }
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            s_buf[w * 512 + t * WAVE + lane] = e[t];
+        __syncthreads();
+        // keys -> float bits in place, so that the summing lane reads floats
+        for (uint32_t i = tid; i < n_sort; i += SEL_THREADS)
+            s_buf[i] = __float_as_uint(lpx_key_float(s_buf[i]));
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        // strictly sequential adds in ascending z (bit-exact with the reference's loop, :193-197); the LDS reads
+        // are hoisted sixteen at a time so that only the add chain is serial
+        const float *zf = (const float *)s_buf;
+        float sum = 0.0f;
+        uint32_t i = 0;
+        for (; i + 16 <= n_rep; i += 16)
+        {
+            const float4 a = *(const float4 *)&zf[i], b = *(const float4 *)&zf[i + 4];
+            const float4 c4 = *(const float4 *)&zf[i + 8], d = *(const float4 *)&zf[i + 12];
+            sum += a.x;
+            sum += a.y;
+            sum += a.z;
+            sum += a.w;
+            sum += b.x;
+            sum += b.y;
+            sum += b.z;
+            sum += b.w;
+            sum += c4.x;
+            sum += c4.y;
+            sum += c4.z;
+            sum += c4.w;
+            sum += d.x;
+            sum += d.y;
+            sum += d.z;
+            sum += d.w;
+        }
+        for (; i < n_rep; ++i)
+            sum += zf[i];
+        s_zmax = sum / (float)n_rep + prm.seed_thr;
+    }
+    __syncthreads();
+    const float z_max = s_zmax;
+    // points of the remainder up to z_max; none above z_max -> no seeds (Q4)
+    c = 0;
+#pragma unroll
+    for (int u = 0; u < SEL_PTS; ++u)
+        c += ((rmask >> u) & 1u) && !(lpx_key_float(key[u]) > z_max);
+    const uint32_t cnt_le = sel_block_sum(c, s_red, tid);
+    if (tid == 0)
+    {
+        const uint32_t n_seed = (cnt_le < nrem) ? cnt_le : 0u;
         SegState o;
         o.lo_excl = (cut > 0) ? prm.z_floor : -INFINITY;
         o.hi_incl = z_max;
@@ -1198,23 +1487,34 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         LPX_HIP(ctx, hipGetLastError());
         return LPX_OK;
     }
+    // segments that fit one workgroup's registers get their seed statistics by selection; larger ones (or more
+    // representatives than the LDS sort holds) by the full (segment, z) sort
+    const bool select_seeds = prm.n_per <= SEL_MAX_POINTS && prm.n_lpr <= SEL_MAX_LPR;
     {
         StageTimer tm(ctx, ST_GATHER);
-        hipLaunchKernelGGL(gather_kernel, grd, blk, 0, st, sidx, X, Y, Z, XS, YS, ZS, (uint64_t *)ctx->key64_a.p, prm,
+        hipLaunchKernelGGL(gather_kernel, grd, blk, 0, st, sidx, X, Y, Z, XS, YS, ZS,
+                           select_seeds ? (uint64_t *)nullptr : (uint64_t *)ctx->key64_a.p, prm,
                            (const FrameState *)frame, fv.fs);
-    }
-    uint64_t *zsorted = nullptr;
-    {
-        StageTimer tm(ctx, ST_ZSORT);
-        rc = lpx_sort_keys64(ctx, (uint64_t *)ctx->key64_a.p, (uint64_t *)ctx->key64_b.p, n, &frame->n_in,
-                             32 + bits_for(P), &zsorted);
-        if (rc)
-            return rc;
     }
     SegState *sst = (SegState *)ctx->seg_state.p;
     long long *acc = (long long *)ctx->seg_acc.p;
     uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
+    if (select_seeds)
     {
+        StageTimer tm(ctx, ST_SEEDS);
+        hipLaunchKernelGGL(seed_select_kernel, dim3(P, 1, B), dim3(SEL_THREADS), 0, st, ZS, prm, sst, acc, ticket,
+                           (const FrameState *)frame, fv.fs);
+    }
+    else
+    {
+        uint64_t *zsorted = nullptr;
+        {
+            StageTimer tm(ctx, ST_ZSORT);
+            rc = lpx_sort_keys64(ctx, (uint64_t *)ctx->key64_a.p, (uint64_t *)ctx->key64_b.p, n, &frame->n_in,
+                                 32 + bits_for(P), &zsorted);
+            if (rc)
+                return rc;
+        }
         StageTimer tm(ctx, ST_SEEDS);
         hipLaunchKernelGGL(seed_kernel, dim3(P, 1, B), dim3(SEG_THREADS), 0, st, zsorted, prm, sst, acc, ticket,
                            (const FrameState *)frame, fv.fs);

@@ -64,6 +64,16 @@ def test_segment_small_and_ragged(ctx, n, P):
     check_segment(ctx, pts, number_of_planar_partitions=P)
 
 
+@pytest.mark.parametrize("n_lpr", [0, 1, 10, 5000, 8192, 8193, 20000, 10**6])
+def test_segment_seed_representatives(ctx, n_lpr):
+    """number_of_lower_point_representatives from none to more than a segment holds: the selection-based seed
+    kernel (<= 8192 representatives, segments <= 24576 points) and the sort-based one agree with the oracle"""
+    check_segment(ctx, load_frame(FRAMES[1]), number_of_planar_partitions=6, number_of_iterations=3,
+                  number_of_lower_point_representatives=n_lpr)
+    check_segment(ctx, load_frame(FRAMES[2])[:70_000], number_of_planar_partitions=2, number_of_iterations=2,
+                  number_of_lower_point_representatives=n_lpr)  # 35000-point segments: sort-based path
+
+
 def test_segment_no_seed_quirk(ctx):
     """every z within initial_seed_threshold of the mean: the cut-off index stays 0 -> no seeds ->
     the whole segment is obstacle (src/segmentation.cpp:202-216, :251-259)"""
