@@ -61,7 +61,7 @@ def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None):
         "xsort": 4 * N * (8 + 8 + 8),                # per pass: histogram read, scatter read + write of 8 B pairs
         "gather": N * (4 + 12 + 12 + 8),             # index, gather, x-sorted SoA, (segment, z) key
         "zsort": 5 * N * (8 + 8 + 8),
-        "seeds": min(N, 5000 * P) * 8 + P * 64,
+        "seeds": N * 4 + P * 64,                     # the selection kernel reads the x-sorted z once
         "plane_passes": N * 12 + N,                  # the SoA is read once and stays in registers; flag write
         "compact": N * (1 + 4 + 4 + 4) + M * (12 + 16),  # flag, index, label, list, obstacle SoA + kd nodes
         "kd_build": M * 16 * 2 * 17,                 # ~log2(M) levels, each reads + writes the node array
@@ -78,7 +78,7 @@ def pmc_traffic(stage):
     """HBM bytes per launch of the stage's dominant kernel from the committed rocprofv3 --pmc summary of this
     same command (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half of a coalesced
     read on gfx950 (guides/MI355X_MICROARCH.md, HBM).  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_fetch_write_per_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r01_g_pmc_fetch_write_per_kernel.json")
     try:
         d = json.load(open(path))
         k = next(v for name, v in d.items() if name.startswith(STAGE_KERNEL[stage][:40]))
