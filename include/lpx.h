@@ -80,7 +80,9 @@ int lpx_create_on_stream(int device, void *hip_stream, lpx_ctx **out);
 void lpx_destroy(lpx_ctx *ctx);
 /* Segmenter::reserve_memory / Clusterer::reserve_memory (src/segmentation.cpp:44-60,
  * src/clustering.cpp:37-45): pre-size all device scratch for n points.  Scratch also grows on
- * demand.  neighbours_per_point sizes the radius-neighbour lists (0 = default 256). */
+ * demand.  neighbours_per_point sizes the radius-neighbour lists, one 32-bit word per neighbour (0 = default
+ * 256); the host entry points grow this workspace and retry when a frame needs more, the device entry points
+ * report LPX_ERR_CAPACITY in the frame's status word. */
 int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_per_point);
 /* Extra neighbour workspace (32-bit words per point, default 512) in which the neighbour kernel may keep
  * lists reserved by an upper bound of their length, which saves its counting pass.  It never changes what
@@ -177,7 +179,8 @@ int lpx_dbg_scan(lpx_ctx *ctx, uint32_t *data, uint32_t n, uint64_t *total);
 int lpx_dbg_kd_layout(lpx_ctx *ctx, const float *xyz, uint32_t m, uint32_t *layout_idx);
 /* radius-neighbour lists of every point in kd-tree pre-order (src/kdtree.hpp:292-341) as CSR;
  * offsets[m+1]; idx/dist hold `capacity` entries.  Returns LPX_ERR_CAPACITY if too small
- * (offsets[m] still holds the required size). */
+ * (offsets[m] still holds the required size).  The device keeps one word per neighbour (index | within-absorb-
+ * radius bit); the distances handed back are recomputed on the host with the reference's expression. */
 int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint64_t *offsets, uint32_t *idx,
                        float *dist, uint64_t capacity);
 /* connected-component root (smallest original index of the component) per point */
