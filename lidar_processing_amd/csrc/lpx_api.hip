@@ -566,39 +566,40 @@ extern "C" int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
                             &fs);
 }
 
-// run the clustering of the obstacle SoA resident in ctx; grows the neighbour workspace on demand
-static int cluster_resident(lpx_ctx *ctx, uint32_t m, const lpx_clu_cfg *cfg, int32_t *labels, uint32_t *n_clusters)
+// Runs the clustering of the obstacle SoA resident in ctx (count on the device, at most m_bound points) and
+// reads the frame state back; grows the neighbour workspace and retries when the frame needs more.
+static int cluster_resident(lpx_ctx *ctx, uint32_t m_bound, const lpx_clu_cfg *cfg, FrameState *fs)
 {
     int rc;
-    FrameState fs;
-    for (int attempt = 0; attempt < 2; ++attempt)
+    for (int attempt = 0; attempt < 3; ++attempt)
     {
         // the kd-tree of a first attempt stays valid (and must not be rebuilt from the permuted node array:
         // the layout depends on the input order, src/kdtree.hpp:174-225)
-        if ((rc = lpx_run_cluster(ctx, m, cfg, (int32_t *)ctx->d_clabels.p, nullptr, attempt > 0)))
+        if ((rc = lpx_run_cluster(ctx, m_bound, cfg, (int32_t *)ctx->d_clabels.p, nullptr, attempt > 0)))
             return rc;
-        if ((rc = read_frame(ctx, &fs)))
+        if ((rc = read_frame(ctx, fs)))
             return rc;
-        if (fs.status == (uint32_t)(-LPX_ERR_CAPACITY) && attempt < 2)
-        {
-            if (fs.nb_total > 0xfffffff0ull)
-                return lpx_fail(ctx, LPX_ERR_CAPACITY, "neighbour lists need %llu entries (> 2^32)",
-                                (unsigned long long)fs.nb_total);
-            uint64_t want = fs.nb_total + fs.nb_total / 8 + 1024;
-            if (want > 0xfffffff0ull)
-                want = 0xfffffff0ull;
-            if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, want)))
-                return rc;
-            if ((rc = reset_neighbour_state(ctx)))
-                return rc;
-            continue;
-        }
-        break;
+        if (fs->status != (uint32_t)(-LPX_ERR_CAPACITY) || attempt == 2)
+            break;
+        if (fs->nb_total > 0xfffffff0ull)
+            return lpx_fail(ctx, LPX_ERR_CAPACITY, "neighbour lists need %llu entries (> 2^32)",
+                            (unsigned long long)fs->nb_total);
+        uint64_t want = fs->nb_total + fs->nb_total / 8 + 1024;
+        if (want > 0xfffffff0ull)
+            want = 0xfffffff0ull;
+        if ((rc = lpx_ensure_capacity(ctx, ctx->cap_n, want)))
+            return rc;
+        if ((rc = reset_neighbour_state(ctx)))
+            return rc;
     }
-    if ((rc = status_to_rc(ctx, fs.status)))
-        return rc;
-    if (labels && m)
-        LPX_HIP(ctx, hipMemcpyAsync(labels, ctx->d_clabels.p, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream));
+    return status_to_rc(ctx, fs->status);
+}
+
+static int download_clusters(lpx_ctx *ctx, const FrameState &fs, int32_t *labels, uint32_t *n_clusters)
+{
+    if (labels && fs.n_obstacle)
+        LPX_HIP(ctx, hipMemcpyAsync(labels, ctx->d_clabels.p, sizeof(int32_t) * fs.n_obstacle, hipMemcpyDeviceToHost,
+                                    ctx->stream));
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n_clusters)
         *n_clusters = fs.n_clusters;
@@ -624,7 +625,10 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
         return rc;
     if ((rc = lpx_ingest_obstacles(ctx, ctx->in_aos.p, stride, m)))
         return rc;
-    return cluster_resident(ctx, m, cfg, labels, n_clusters);
+    FrameState fs;
+    if ((rc = cluster_resident(ctx, m, cfg, &fs)))
+        return rc;
+    return download_clusters(ctx, fs, labels, n_clusters);
 }
 
 extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *seg_cfg,
@@ -651,13 +655,28 @@ extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride,
     if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, &n, seg_cfg, (uint32_t *)ctx->d_labels.p,
                               (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
         return rc;
+    // The clustering is enqueued right behind the segmentation (n bounds the obstacle count, the kernels take
+    // the real one from the device): no synchronisation or copy in the middle of the chain.  Everything is
+    // downloaded at the end.
     FrameState fs;
-    if ((rc = download_segment(ctx, n, seg_cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle,
-                               planes, &fs)))
+    if ((rc = cluster_resident(ctx, n, clu_cfg, &fs)))
         return rc;
-    if (fs.n_obstacle == 0)
-        return LPX_OK;
-    return cluster_resident(ctx, fs.n_obstacle, clu_cfg, cluster_labels, n_clusters);
+    const uint32_t P = seg_cfg->number_of_planar_partitions;
+    if (labels && n)
+        LPX_HIP(ctx, hipMemcpyAsync(labels, ctx->d_labels.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (planes)
+        LPX_HIP(ctx, hipMemcpyAsync(planes, ctx->d_planes.p, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, ctx->stream));
+    if (gidx && fs.n_ground)
+        LPX_HIP(ctx, hipMemcpyAsync(gidx, ctx->d_gidx.p, sizeof(uint32_t) * fs.n_ground, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    if (oidx && fs.n_obstacle)
+        LPX_HIP(ctx, hipMemcpyAsync(oidx, ctx->d_oidx.p, sizeof(uint32_t) * fs.n_obstacle, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    if (n_ground)
+        *n_ground = fs.n_ground;
+    if (n_obstacle)
+        *n_obstacle = fs.n_obstacle;
+    return download_clusters(ctx, fs, cluster_labels, n_clusters);  // one synchronisation for all copies
 }
 
 // Cluster regrouping (reference src/processor.cpp:180-200) of the labels of the LAST clustering call on

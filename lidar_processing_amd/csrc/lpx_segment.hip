@@ -118,7 +118,10 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, float
     if (nodes)
         nodes[i] = make_float4(x, y, z, __uint_as_float(i));
     if (!(fabsf(x) < FIX_LIMIT) || !(fabsf(y) < FIX_LIMIT) || !(fabsf(z) < FIX_LIMIT))
+    {
         frame->status = (uint32_t)(-LPX_ERR_RANGE);
+        frame->n_obstacle = 0;  // nothing downstream runs on non-finite or out-of-range coordinates
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1297,7 +1300,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
         {
             const uint32_t total = blk_offs[2 * nb];
             frame->n_ground = total_g;
-            frame->n_obstacle = total - total_g;
+            frame->n_obstacle = frame->status ? 0u : total - total_g;  // a frame in error is not clustered
         }
         if (planes)
             for (uint32_t i = tid; i < prm.P * 4; i += SEG_THREADS)
