@@ -137,6 +137,28 @@ def test_batch_stride_and_range_error_are_per_frame(ctx):
     assert res[1]["status"] == 2  # -LPX_ERR_RANGE
 
 
+def test_batch_non_finite_frame_is_flagged_and_not_clustered(ctx):
+    good = load_frame(FRAMES[0])[:30_000]
+    bad = good.copy()
+    bad[7, 0] = np.nan
+    bad[20_000, 2] = np.inf
+    bad[29_999, 1] = -np.inf
+    bctx = Context(0, batch=3)
+    try:
+        res = run_batch(bctx, [bad, good, bad], SEG, CLU)
+    finally:
+        bctx.close()
+    check_frame(res[1], single(ctx, good, SEG, CLU))
+    for r in (res[0], res[2]):
+        assert r["status"] == 2  # -LPX_ERR_RANGE
+        assert r["n_clusters"] == 0 and r["obstacle_idx"].shape[0] == 0  # nothing was handed to the clustering
+    with pytest.raises(LpxError):
+        single(ctx, bad, SEG, CLU)
+    with pytest.raises(LpxError):
+        ctx.cluster(bad, ClusteringConfiguration(**CLU))
+    assert single(ctx, good, SEG, CLU)["n_clusters"] > 0  # the context is fine afterwards
+
+
 def test_batch_argument_errors(ctx):
     bctx = Context(0, batch=2)
     try:
