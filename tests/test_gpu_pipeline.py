@@ -74,6 +74,25 @@ def test_segment_seed_representatives(ctx, n_lpr):
                   number_of_lower_point_representatives=n_lpr)  # 35000-point segments: sort-based path
 
 
+@pytest.mark.parametrize("n_per", [24575, 24576, 24577])
+def test_segment_single_workgroup_limit(ctx, n_per):
+    """segments of exactly / just above 24576 points: the one-workgroup seed and plane kernels hand over to the
+    sort-based seed kernel and the launch-per-pass plane kernel"""
+    pts = np.concatenate([load_frame(FRAMES[0]), load_frame(FRAMES[1])])[:3 * n_per + 2]
+    check_segment(ctx, pts, number_of_planar_partitions=3, number_of_iterations=4)
+
+
+@pytest.mark.parametrize("kw", [dict(number_of_planar_partitions=256, number_of_iterations=2),
+                                dict(number_of_planar_partitions=1, number_of_iterations=64),
+                                dict(number_of_planar_partitions=5, number_of_iterations=1, sensor_height_m=2.5,
+                                     orthogonal_distance_threshold=0.05, initial_seed_threshold=0.1),
+                                dict(number_of_planar_partitions=4, number_of_iterations=7, sensor_height_m=1.0,
+                                     orthogonal_distance_threshold=1.0, initial_seed_threshold=2.0)])
+def test_segment_configuration_extremes(ctx, kw):
+    """most partitions / iterations the C-ABI accepts, and thresholds far from the defaults"""
+    check_segment(ctx, load_frame(FRAMES[2]), **kw)
+
+
 def test_segment_no_seed_quirk(ctx):
     """every z within initial_seed_threshold of the mean: the cut-off index stays 0 -> no seeds ->
     the whole segment is obstacle (src/segmentation.cpp:202-216, :251-259)"""
@@ -182,6 +201,14 @@ def test_cluster_quality_and_size_limits(ctx, q, mn, mx):
     centres = rng.random((150, 3)) * [60, 60, 2]
     obs[:, :3] = np.round(centres[rng.integers(0, 150, m)] + rng.normal(0, 0.25, (m, 3)), 3)
     check_cluster(ctx, obs, 0.18, q, mn, mx)
+
+
+@pytest.mark.parametrize("d2,q", [(1.0e-4, 0.5), (0.01, 0.0), (1.0, 0.25), (9.0, 0.5), (9.0, 0.999), (25.0, 1.0)])
+def test_cluster_radius_extremes(ctx, d2, q):
+    """radii from 1 cm (almost no neighbours) to 5 m (thousands per point, lists of many tiles)"""
+    pts = load_frame(FRAMES[1])
+    obs = pts[oracle.segment(pts)["obstacle_idx"]][::7][:6000]
+    check_cluster(ctx, obs, d2, q, 4)
 
 
 def test_cluster_edge_cases(ctx):
