@@ -227,8 +227,8 @@ void orc_jacobi_svd3(const float *a, float *v, float *sigma)
 /*   float 3x3 Jacobi SVD above; normal = V.col(2), d = normal . centroid.                     */
 /* ------------------------------------------------------------------------------------------ */
 
-#define FIX_SCALE 65536.0f /* 2^16: |q| < 2^27, products < 2^54 (fits the GPU's int64 lanes) */
-#define FIX_LIMIT 2048.0f
+#define FIX_SCALE 65536.0f    /* 2^16 */
+#define FIX_CLAMP 16777216.0f /* 2^24 m: |q| <= 2^40, products <= 2^80, sums over < 2^23 points fit 128 bits */
 
 typedef __int128 i128;
 
@@ -238,11 +238,18 @@ typedef struct
     i128 sx, sy, sz, sxx, sxy, sxz, syy, syz, szz;
 } moments;
 
+/* Any finite coordinate is accepted (the reference processes any finite float, src/segmentation.cpp:311-345).
+ * Beyond +-2^24 m (further than any Earth-fixed frame reaches) the MOMENTS use the clamped value so that the
+ * sums stay exact integers; the inlier test always uses the float coordinate itself. */
 static inline int to_fix(float v, int64_t *q)
 {
-    if (!(fabsf(v) < FIX_LIMIT))
+    if (!isfinite(v))
         return 1;
-    *q = (int64_t)llrintf(v * FIX_SCALE); /* round-half-even; v*2^20 is exact */
+    if (v > FIX_CLAMP)
+        v = FIX_CLAMP;
+    if (v < -FIX_CLAMP)
+        v = -FIX_CLAMP;
+    *q = (int64_t)llrintf(v * FIX_SCALE); /* round-half-even; the product by 2^16 is exact */
     return 0;
 }
 
@@ -335,11 +342,11 @@ int orc_segment(const void *pts, size_t stride, uint32_t n, const orc_seg_cfg *c
             seg_status[s] = ORC_SEG_TOO_FEW_POINTS;
     if (n == 0 || P == 0)
         return ORC_OK;
-    /* canonical arithmetic needs every coordinate finite and |v| < 2048 m */
+    /* non-finite coordinates are undefined behaviour upstream (comparators on NaN): rejected */
     for (uint32_t i = 0; i < n; ++i)
     {
         const float *p = pt_at(pts, stride, i);
-        if (!(fabsf(p[0]) < FIX_LIMIT) || !(fabsf(p[1]) < FIX_LIMIT) || !(fabsf(p[2]) < FIX_LIMIT))
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2]))
             return ORC_ERR_RANGE;
     }
 

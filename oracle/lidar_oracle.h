@@ -59,7 +59,7 @@ typedef struct
 #define ORC_SEG_ALL_OBSTACLE 2u   /* <3 ground points at some iteration, :251-259 */
 
 #define ORC_OK 0
-#define ORC_ERR_RANGE (-2) /* |coordinate| >= 2048 m: outside the fixed-point moment range */
+#define ORC_ERR_RANGE (-2) /* a coordinate is NaN or infinite */
 #define ORC_ERR_ARG (-1)
 
 /*

@@ -202,9 +202,34 @@ def test_plane_degenerate_inputs():
     assert oracle.plane_from_points(np.zeros((2, 3), np.float32))[1] == 1          # < 3 points
     plane, rc = oracle.plane_from_points(np.ones((10, 3), np.float32))             # identical points
     assert rc == 0 and tuple(plane[:3]) == (0.0, 0.0, 1.0)
-    big = np.zeros((4, 3), np.float32)
-    big[0, 0] = 5000.0
-    assert oracle.plane_from_points(big)[1] == oracle.ERR_RANGE
+    bad = np.zeros((4, 3), np.float32)
+    bad[0, 0] = np.inf
+    assert oracle.plane_from_points(bad)[1] == oracle.ERR_RANGE
+    bad[0, 0] = np.nan
+    assert oracle.plane_from_points(bad)[1] == oracle.ERR_RANGE
+
+
+def test_plane_far_coordinates_are_exact():
+    """any finite coordinate is accepted: the integer moments are exact up to 2^24 m (UTM / ECEF scale), so a
+    cloud shifted by a multiple of a large power of two keeps its normal (float64 cross-check)"""
+    rng = np.random.default_rng(11)
+    n = 5000
+    xyz = np.zeros((n, 3), np.float64)
+    xyz[:, 0] = np.round(rng.random(n) * 64, 0)
+    xyz[:, 1] = np.round(rng.random(n) * 64, 0)
+    xyz[:, 2] = np.round(0.25 * xyz[:, 0] - 0.5 * xyz[:, 1] + rng.normal(0, 1.0, n), 0)
+    for shift in (0.0, 4096.0, 500_000.0, 8_000_000.0):
+        p = (xyz + [shift, -shift, shift / 2]).astype(np.float32)
+        assert np.array_equal(p.astype(np.float64), xyz + [shift, -shift, shift / 2])  # exactly representable
+        plane, rc = oracle.plane_from_points(p)
+        assert rc == 0
+        w, v = np.linalg.eigh(np.cov(xyz.T))
+        nrm = v[:, 0] * np.sign(v[2, 0])
+        assert np.abs(plane[:3] * np.sign(plane[2]) - nrm).max() < 2e-5, (shift, plane, nrm)
+    # beyond 2^24 m the moments use the clamped coordinate: still a result, never an error
+    p = xyz.astype(np.float32)
+    p[0] = [3.0e38, -3.0e38, 1.0e30]
+    assert oracle.plane_from_points(p)[1] == 0
 
 
 def test_segment_edge_cases():

@@ -6,8 +6,18 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FRAMES = ["0000000000", "0000000077", "0000000153"]
 
+STREAM = os.path.join(GOLDEN, "stream")
+# the two configurations the 154-frame stream has goldens for: BASELINE configs[1]/[3] and the shipped defaults
+STREAM_CONFIGS = {
+    "p6i5_d025q05": (dict(number_of_planar_partitions=6, number_of_iterations=5),
+                     dict(distance_squared=0.25, cluster_quality=0.5)),
+    "p2i3_d018q05": (dict(number_of_planar_partitions=2, number_of_iterations=3),
+                     dict(distance_squared=0.18, cluster_quality=0.5)),
+}
+
 _frames = None
 _gold = None
+_stream_gold = None
 
 
 def load_frame(name):
@@ -21,6 +31,64 @@ def load_frame(name):
     for r, c in _frames[f"{name}_negzero"]:
         pts[r, c] = -0.0
     return pts
+
+
+def pack_frame(pts):
+    """lossless repack of an (n,4) float32 x y z intensity frame whose coordinates are exact 1 mm multiples and
+    intensities exact 0.01 multiples (every reference data/*.pcd frame): scan-order deltas of the integer
+    millimetres, zigzag, three byte planes per coordinate, intensity bytes, negative-zero list; xz"""
+    import lzma
+    q = np.rint(pts[:, :3].astype(np.float64) * 1000.0).astype(np.int32)
+    qi = np.rint(pts[:, 3].astype(np.float64) * 100.0).astype(np.int64)
+    rec = np.empty_like(pts)
+    rec[:, :3] = (q / 1000.0).astype(np.float32)
+    rec[:, 3] = (qi / 100.0).astype(np.float32)
+    assert np.array_equal(rec, pts), "frame is not 1 mm / 0.01 quantised"
+    assert qi.min() >= 0 and qi.max() < 256
+    d = np.diff(q, axis=0, prepend=np.zeros((1, 3), np.int32))
+    zz = ((d << 1) ^ (d >> 31)).astype(np.uint32)
+    assert zz.max() < (1 << 24)
+    planes = b"".join(np.ascontiguousarray(((zz >> (8 * k)) & 255).astype(np.uint8).T).tobytes() for k in range(3))
+    negzero = np.argwhere(np.signbit(pts) & (pts == 0)).astype(np.uint32)
+    head = np.array([pts.shape[0], negzero.shape[0]], np.uint32).tobytes()
+    return head + lzma.compress(planes + qi.astype(np.uint8).tobytes() + negzero.tobytes(),
+                                preset=9 | lzma.PRESET_EXTREME)
+
+
+def unpack_frame(blob):
+    import lzma
+    n, nz = (int(v) for v in np.frombuffer(blob[:8], np.uint32))
+    raw = np.frombuffer(lzma.decompress(blob[8:]), np.uint8)
+    zz = np.zeros((n, 3), np.uint32)
+    for k in range(3):
+        zz |= raw[3 * n * k:3 * n * (k + 1)].reshape(3, n).T.astype(np.uint32) << (8 * k)
+    d = (zz >> 1).astype(np.int32) ^ -(zz & 1).astype(np.int32)
+    q = np.cumsum(d, axis=0, dtype=np.int64)
+    pts = np.empty((n, 4), np.float32)
+    pts[:, :3] = (q / 1000.0).astype(np.float32)
+    pts[:, 3] = (raw[9 * n:10 * n].astype(np.float64) / 100.0).astype(np.float32)
+    for r, c in raw[10 * n:10 * n + 8 * nz].view(np.uint32).reshape(nz, 2):
+        pts[r, c] = -0.0
+    return pts
+
+
+def stream_names():
+    """the 154 frames of BASELINE configs[3] in filename order"""
+    return sorted(f[:-3] for f in os.listdir(STREAM) if f.endswith(".xz"))
+
+
+def load_stream_frame(name):
+    """(n,4) float32 frame of the committed 154-frame stream, bit-identical to the reference's data/<name>.pcd"""
+    with open(os.path.join(STREAM, name + ".xz"), "rb") as f:
+        return unpack_frame(f.read())
+
+
+def stream_gold():
+    global _stream_gold
+    if _stream_gold is None:
+        with np.load(os.path.join(GOLDEN, "stream_golden.npz")) as z:
+            _stream_gold = {k: z[k] for k in z.files}  # materialised: safe to use from forked workers
+    return _stream_gold
 
 
 def gold():
