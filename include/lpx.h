@@ -57,7 +57,7 @@ typedef struct
 
 #define LPX_OK 0
 #define LPX_ERR_ARG (-1)      /* bad argument */
-#define LPX_ERR_RANGE (-2)    /* a coordinate is non-finite or |v| >= 2048 m (fixed-point moment range) */
+#define LPX_ERR_RANGE (-2)    /* a coordinate is NaN or infinite (any finite cloud is processed) */
 #define LPX_ERR_HIP (-3)      /* HIP runtime error, see lpx_last_error() */
 #define LPX_ERR_CAPACITY (-4) /* workspace too small and could not be grown */
 #define LPX_ERR_NO_DEVICE (-5)
@@ -167,32 +167,6 @@ const char *lpx_profile_stage_name(int stage);
 /* Synchronises, then returns for each stage the accumulated milliseconds and number of launches
  * since the last reset; arrays of lpx_profile_stage_count() entries. */
 int lpx_profile_read(lpx_ctx *ctx, float *ms, uint32_t *launches, int reset);
-
-/* ---- stage-level entry points used by the parity tests (host pointers, synchronous) --------- */
-
-/* stable LSD radix sort of (key, value) pairs on the device; bits = number of low key bits used */
-int lpx_dbg_sort_pairs(lpx_ctx *ctx, uint32_t *keys, uint32_t *values, uint32_t n, uint32_t bits);
-int lpx_dbg_sort_keys64(lpx_ctx *ctx, uint64_t *keys, uint32_t n, uint32_t bits);
-/* exclusive scan of u32 -> u32, returns total in *total */
-int lpx_dbg_scan(lpx_ctx *ctx, uint32_t *data, uint32_t n, uint64_t *total);
-/* kd-tree array layout (reference KDTree::rebuild, src/kdtree.hpp:174-225): original index per node */
-int lpx_dbg_kd_layout(lpx_ctx *ctx, const float *xyz, uint32_t m, uint32_t *layout_idx);
-/* radius-neighbour lists of every point in kd-tree pre-order (src/kdtree.hpp:292-341) as CSR;
- * offsets[m+1]; idx/dist hold `capacity` entries.  Returns LPX_ERR_CAPACITY if too small
- * (offsets[m] still holds the required size).  The device keeps one word per neighbour (index | within-absorb-
- * radius bit); the distances handed back are recomputed on the host with the reference's expression. */
-int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint64_t *offsets, uint32_t *idx,
-                       float *dist, uint64_t capacity);
-/* connected-component root (smallest original index of the component) per point */
-int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint32_t *root);
-/* statistics of the last frame processed by this context (synchronises): out[12] =
- * {n_ground, n_obstacle, n_clusters, status, neighbour entries lo/hi, components, expansions,
- *  entries read by the replay lo/hi, words of list storage handed out lo/hi} */
-int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out12);
-/* the same for frame slot `slot` of a batch context */
-int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out12);
-/* plane from points through the device moment/Jacobi path */
-int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
 // lpx_api.hip -- C-ABI (include/lpx.h), context / workspace management, host staging, profiling.
 #include "lpx_internal.h"
+#include "lpx_debug.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -76,6 +77,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             {&ctx->frame, sizeof(FrameState)},
             {&ctx->seg_state, sizeof(SegState) * LPX_MAX_PARTITIONS},
             {&ctx->seg_acc, (sizeof(long long) * LPX_ACC_WORDS + 2 * sizeof(uint32_t)) * LPX_MAX_PARTITIONS},
+            {&ctx->seg_far, sizeof(long long) * LPX_FAR_WORDS * LPX_MAX_PARTITIONS},
             {&ctx->d_planes, sizeof(float) * 4 * LPX_MAX_PARTITIONS},
             {&ctx->d_counts, 64},
             {&ctx->hist, hist_bytes},
@@ -383,7 +385,7 @@ static int status_to_rc(lpx_ctx *ctx, uint32_t status)
         return LPX_OK;
     const int rc = -(int)status;
     if (rc == LPX_ERR_RANGE)
-        return lpx_fail(ctx, rc, "a coordinate is non-finite or |v| >= 2048 m");
+        return lpx_fail(ctx, rc, "a coordinate is NaN or infinite");
     if (rc == LPX_ERR_CAPACITY)
         return lpx_fail(ctx, rc, "neighbour workspace too small");
     return lpx_fail(ctx, rc, "device status %u", status);
@@ -497,13 +499,15 @@ static int upload(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n)
 static int reset_neighbour_state(lpx_ctx *ctx)
 {
     char *f = (char *)ctx->frame.p;
-    const size_t lo = offsetof(FrameState, status), nin = offsetof(FrameState, n_in), hi = sizeof(FrameState);
+    const size_t lo = offsetof(FrameState, status), nin = offsetof(FrameState, n_in);
+    const size_t nbe = offsetof(FrameState, nb_entries), hi = sizeof(FrameState);
     static_assert(offsetof(FrameState, nb_total) > offsetof(FrameState, status) &&
-                      offsetof(FrameState, n_obstacle) < offsetof(FrameState, status),
+                      offsetof(FrameState, n_obstacle) < offsetof(FrameState, status) &&
+                      offsetof(FrameState, nb_entries) > offsetof(FrameState, has_far),
                   "FrameState layout");
-    // n_in sits between the counters: clear around it
+    // n_in and has_far sit between the counters: clear around them
     LPX_HIP(ctx, hipMemsetAsync(f + lo, 0, nin - lo, ctx->stream));
-    LPX_HIP(ctx, hipMemsetAsync(f + nin + sizeof(uint32_t), 0, hi - nin - sizeof(uint32_t), ctx->stream));
+    LPX_HIP(ctx, hipMemsetAsync(f + nbe, 0, hi - nbe, ctx->stream));
     return LPX_OK;
 }
 

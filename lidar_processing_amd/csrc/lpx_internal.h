@@ -44,11 +44,14 @@ struct FrameState
     uint64_t replay_entries;  // neighbour entries read by the replay (lists of expanded points)
     uint32_t n_expansions;    // radius_search calls the reference would have made
     uint32_t n_in;            // points of the input cloud of this frame slot
+    uint32_t has_far;         // some coordinate has |v| >= 2048 m: the plane kernels take the wide-moment path for it
+    uint32_t pad0;
     uint64_t nb_entries;      // neighbour entries written (sum of the list lengths)
     uint64_t rs_total;        // words asked from the single-pass region [cap_nb, cap_nb + cap_rs)
 };
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
+#define LPX_FAR_WORDS 24  // moments of the points beyond +-2048 m: n, sx, sy, sz, 6 x (hh, hl, ll) limbs, 2 spare
 
 struct SegState  // per segment
 {
@@ -119,6 +122,7 @@ struct lpx_ctx
     Buf hist;                  // radix histograms / scan scratch
     Buf seg_state;             // SegState[LPX_MAX_PARTITIONS]
     Buf seg_acc;               // int64 [LPX_MAX_PARTITIONS][LPX_ACC_WORDS] + tickets
+    Buf seg_far;               // int64 [LPX_MAX_PARTITIONS][LPX_FAR_WORDS], zero between passes
     Buf blk_counts;            // per block ground / obstacle counts
     Buf d_labels, d_gidx, d_oidx, d_planes, d_counts;  // outputs for host API
     // ---- clustering buffers ----

@@ -1153,8 +1153,12 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                 blo[a] = fminf(blo[a], __shfl_xor(blo[a], o, 64));
                 bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], o, 64));
             }
+            // widened by the radius plus two ulps of the result: far from the origin (map / UTM frames) the
+            // rounding of this subtraction is larger than any fixed margin
             blo[a] -= rr;
             bhi[a] += rr;
+            blo[a] -= fabsf(blo[a]) * 2.4e-7f;
+            bhi[a] += fabsf(bhi[a]) * 2.4e-7f;
         }
         n_cur = nb_traverse(PR, M, D, blo, bhi, seqbuf, caps, pre, lane, &cur, &T);
         if (BLOCK && lane == 0)

@@ -24,7 +24,8 @@ constexpr int SEG_THREADS = 256;
 constexpr int SEG_WAVES = SEG_THREADS / WAVE;
 constexpr uint32_t SEG_CHUNK = 4096;  // points per block (16 per thread; bound for int64 lanes is 256)
 constexpr float FIX_SCALE = 65536.0f;
-constexpr float FIX_LIMIT = 2048.0f;
+constexpr float FIX_LIMIT = 2048.0f;       // below: |q| < 2^27, the int32 / int64 fast path
+constexpr float FIX_CLAMP = 16777216.0f;   // 2^24 m: |q| <= 2^40, the wide path of the rare far points
 
 struct SegParams
 {
@@ -67,6 +68,8 @@ __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacl
         f.replay_entries = 0;
         f.n_expansions = 0;
         f.n_in = n.v[blockIdx.z];
+        f.has_far = 0;
+        f.pad0 = 0;
         f.nb_entries = 0;
         f.rs_total = 0;
         *frame = f;
@@ -117,11 +120,18 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, float
     }
     if (nodes)
         nodes[i] = make_float4(x, y, z, __uint_as_float(i));
-    if (!(fabsf(x) < FIX_LIMIT) || !(fabsf(y) < FIX_LIMIT) || !(fabsf(z) < FIX_LIMIT))
+    // Any finite cloud is processed like the reference does (src/segmentation.cpp:311-345).  NaN / Inf are
+    // undefined behaviour upstream (comparators) and flag the frame.  Coordinates beyond +-2048 m leave the
+    // int32 fixed-point range of the moment fast path: the plane kernels give those points the wide path.
+    const float amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));  // fmaxf drops a NaN operand, hence:
+    const float nonfinite = (x - x) + (y - y) + (z - z);            // 0 for finite input, NaN for NaN / Inf
+    if (!(nonfinite == 0.0f))
     {
         frame->status = (uint32_t)(-LPX_ERR_RANGE);
-        frame->n_obstacle = 0;  // nothing downstream runs on non-finite or out-of-range coordinates
+        frame->n_obstacle = 0;  // nothing downstream runs on non-finite coordinates
     }
+    else if (!(amax < FIX_LIMIT))
+        frame->has_far = 1u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -731,16 +741,66 @@ __device__ double i128_to_double(i128 v)
     return neg ? -d : d;
 }
 
-// moments words: 0 n, 1 sx, 2 sy, 3 sz, 4.. (hi, lo) of xx, xy, xz, yy, yz, zz
-__device__ bool plane_from_moments(const long long *m, float *plane)
+// A member point with a coordinate beyond +-2048 m (rare: a spurious far return, or a cloud in a map / UTM
+// frame) does not fit the int32 lanes.  Its exact moments go straight to a per-segment global accumulator:
+// q = round(clamp(v, +-2^24 m) * 2^16) = h * 2^20 + l with 0 <= l < 2^20, and every product as the three
+// partial sums hh, hl + lh, ll (each below 2^41, so 64-bit atomics never carry).
+__device__ __forceinline__ long long far_fix(float v)
 {
-    const uint64_t cnt = (uint64_t)m[0];
-    if (cnt < 3)
-        return false;
-    const i128 sx = m[1], sy = m[2], sz = m[3];
+    v = fminf(fmaxf(v, -FIX_CLAMP), FIX_CLAMP);
+    return __float2ll_rn(v * FIX_SCALE);
+}
+
+__device__ __noinline__ void far_accumulate(long long *fa, float x, float y, float z)
+{
+    const long long q[3] = {far_fix(x), far_fix(y), far_fix(z)};
+    long long h[3], l[3];
+    for (int i = 0; i < 3; ++i)
+    {
+        h[i] = q[i] >> 20;
+        l[i] = q[i] & 0xfffffLL;
+    }
+    unsigned long long *f = (unsigned long long *)fa;
+    atomicAdd(f + 0, 1ull);
+    atomicAdd(f + 1, (unsigned long long)q[0]);
+    atomicAdd(f + 2, (unsigned long long)q[1]);
+    atomicAdd(f + 3, (unsigned long long)q[2]);
+    int w = 4;
+    for (int a = 0; a < 3; ++a)
+        for (int b = a; b < 3; ++b)
+        {
+            atomicAdd(f + w + 0, (unsigned long long)(h[a] * h[b]));
+            atomicAdd(f + w + 1, (unsigned long long)(h[a] * l[b] + l[a] * h[b]));
+            atomicAdd(f + w + 2, (unsigned long long)(l[a] * l[b]));
+            w += 3;
+        }
+}
+
+__device__ __forceinline__ bool is_near(float x, float y, float z)
+{
+    return fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) < FIX_LIMIT;
+}
+
+// moments words: 0 n, 1 sx, 2 sy, 3 sz, 4.. (hi, lo) of xx, xy, xz, yy, yz, zz; far (may be null): the
+// LPX_FAR_WORDS of far_accumulate
+__device__ bool plane_from_moments(const long long *m, const long long *far, float *plane)
+{
+    uint64_t cnt = (uint64_t)m[0];
+    i128 sx = m[1], sy = m[2], sz = m[3];
     i128 q[6];
     for (int i = 0; i < 6; ++i)
         q[i] = ((i128)m[4 + 2 * i] << 32) + (i128)m[5 + 2 * i];
+    if (far)
+    {
+        cnt += (uint64_t)far[0];
+        sx += far[1];
+        sy += far[2];
+        sz += far[3];
+        for (int i = 0; i < 6; ++i)
+            q[i] += ((i128)far[4 + 3 * i] << 40) + ((i128)far[5 + 3 * i] << 20) + (i128)far[6 + 3 * i];
+    }
+    if (cnt < 3)
+        return false;
     const double n = (double)cnt;
     const double den = n * (double)(cnt - 1);
     const double inv16 = 1.0 / 65536.0, inv32 = inv16 * inv16;
@@ -779,7 +839,8 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
                                                                   const float *__restrict__ YS,
                                                                   const float *__restrict__ ZS, SegParams prm,
                                                                   uint32_t t, SegState *st, long long *acc,
-                                                                  uint32_t *ticket, uint8_t *__restrict__ flags,
+                                                                  long long *facc, uint32_t *ticket,
+                                                                  uint8_t *__restrict__ flags,
                                                                   uint32_t *__restrict__ blk_counts,
                                                                   const FrameState *__restrict__ frame, size_t fs)
 {
@@ -790,15 +851,19 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     ZS = lpx_slot(ZS, fs);
     st = lpx_slot(st, fs);
     acc = lpx_slot(acc, fs);
+    facc = lpx_slot(facc, fs);
     ticket = lpx_slot(ticket, fs);
     flags = lpx_slot(flags, fs);
     blk_counts = lpx_slot(blk_counts, fs);
-    seg_bind(prm, lpx_slot(frame, fs));
+    frame = lpx_slot(frame, fs);
+    seg_bind(prm, frame);
+    const bool any_far = frame->has_far != 0;
     const uint32_t s = blockIdx.y, b = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     const uint32_t seg_lo = s * prm.n_per;
     const uint32_t lo = seg_lo + b * prm.chunk;
     const uint32_t hi = min(lo + prm.chunk, seg_lo + prm.n_per);
+    long long *fa = facc + (size_t)s * LPX_FAR_WORDS;
 
     const SegState sst = st[s];
     const bool skip = sst.failed == 2;       // < 3 points: nothing labelled
@@ -850,6 +915,8 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
                     cnt_o += (f == 2);
                 }
             }
+            else if (member && any_far && !is_near(x, y, z))
+                far_accumulate(fa, x, y, z);
             else if (member)
             {
                 const int qx = __float2int_rn(x * FIX_SCALE);
@@ -930,6 +997,8 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
         // have been performed before the barrier that precedes the ticket.  No L2 write-back fence.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (any_far)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the far points' atomics of every lane
     __syncthreads();
     if (tid == 0)
     {
@@ -947,6 +1016,10 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
         if (tid == 0)
             atomicExch(&ticket[s], 0u);
     }
+    long long *fred = &red[1][0];  // rows 1 and 2 hold the LPX_FAR_WORDS
+    static_assert(LPX_FAR_WORDS <= 2 * LPX_ACC_WORDS && SEG_WAVES >= 3, "far words fit two rows");
+    if (any_far && tid >= WAVE && tid < WAVE + LPX_FAR_WORDS)
+        fred[tid - WAVE] = (long long)atomicExch((unsigned long long *)&fa[tid - WAVE], 0ull);
     __syncthreads();
     if (tid == 0)
     {
@@ -958,7 +1031,7 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
         {
             float plane[4];
             // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
-            if (!plane_from_moments(m, plane))
+            if (!plane_from_moments(m, any_far ? fred : nullptr, plane))
                 o.failed = 1;
             else
             {
@@ -994,6 +1067,7 @@ __global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *
                                                                     const float *__restrict__ YS,
                                                                     const float *__restrict__ ZS, SegParams prm,
                                                                     SegState *__restrict__ st,
+                                                                    long long *facc,
                                                                     uint8_t *__restrict__ flags,
                                                                     uint32_t *__restrict__ blk_counts,
                                                                     const FrameState *__restrict__ frame, size_t fs)
@@ -1004,10 +1078,14 @@ __global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *
     YS = lpx_slot(YS, fs);
     ZS = lpx_slot(ZS, fs);
     st = lpx_slot(st, fs);
+    facc = lpx_slot(facc, fs);
     flags = lpx_slot(flags, fs);
     blk_counts = lpx_slot(blk_counts, fs);
-    seg_bind(prm, lpx_slot(frame, fs));
+    frame = lpx_slot(frame, fs);
+    seg_bind(prm, frame);
+    const bool any_far = frame->has_far != 0;
     const uint32_t s = blockIdx.x;
+    long long *fa = facc + (size_t)s * LPX_FAR_WORDS;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     const uint32_t lo = s * prm.n_per, hi = lo + prm.n_per;
     const SegState sst = st[s];  // written by seed_kernel in the previous launch
@@ -1063,6 +1141,8 @@ __global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *
                     cnt[u / ONE_U_PER_CHUNK] += (f == 1 ? 1u : 0u) + (f == 2 ? 0x10000u : 0u);
                 }
             }
+            else if (member && any_far && !is_near(x, y, z))
+                far_accumulate(fa, x, y, z);
             else if (member)
             {
                 const int qx = __float2int_rn(x * FIX_SCALE);
@@ -1128,6 +1208,8 @@ __global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *
             if (lane == 0)
                 red[w][i] = v[i];
         }
+        if (any_far)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the far points' atomics of every lane
         __syncthreads();
         if (tid < LPX_ACC_WORDS)
         {
@@ -1137,7 +1219,15 @@ __global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *
                 tot += red[i][tid];
             red[0][tid] = tot;  // only thread tid touches column tid of row 0 in this phase
         }
+        // fetch and clear the far accumulators (one lane each) while the columns above are summed
+        long long far_w = 0;
+        if (any_far && tid >= WAVE && tid < WAVE + LPX_FAR_WORDS)
+            far_w = (long long)atomicExch((unsigned long long *)&fa[tid - WAVE], 0ull);
         __syncthreads();
+        if (any_far && tid >= WAVE && tid < WAVE + LPX_FAR_WORDS)
+            (&red[1][0])[tid - WAVE] = far_w;  // rows 1 and 2 are free once the column sums are done
+        if (any_far)
+            __syncthreads();
         if (tid == 0)
         {
             long long m[LPX_ACC_WORDS];
@@ -1150,7 +1240,7 @@ __global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *
             if (!dead)
             {
                 // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
-                if (!plane_from_moments(m, plane))
+                if (!plane_from_moments(m, any_far ? &red[1][0] : nullptr, plane))
                     failed = 1;
                 else
                 {
@@ -1403,8 +1493,8 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
                            fv);
     hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, acc, ticket);
     hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
-                       0u, sst, acc, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr, (const FrameState *)frame,
-                       fv.fs);
+                       0u, sst, acc, (long long *)ctx->seg_far.p, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr,
+                       (const FrameState *)frame, fv.fs);
     hipLaunchKernelGGL(dbg_plane_out_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, d_out);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
@@ -1502,6 +1592,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     SegState *sst = (SegState *)ctx->seg_state.p;
     long long *acc = (long long *)ctx->seg_acc.p;
     uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
+    long long *facc = (long long *)ctx->seg_far.p;
     if (select_seeds)
     {
         StageTimer tm(ctx, ST_SEEDS);
@@ -1529,16 +1620,16 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     {
         StageTimer tm(ctx, ST_PLANE);
         if (prm.n_per <= ONE_MAX_POINTS)
-            hipLaunchKernelGGL(plane_single_kernel, dim3(P, 1, B), dim3(ONE_THREADS), 0, st, XS, YS, ZS, prm, sst,
+            hipLaunchKernelGGL(plane_single_kernel, dim3(P, 1, B), dim3(ONE_THREADS), 0, st, XS, YS, ZS, prm, sst, facc,
                                (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
         else
         {
             const dim3 g2(prm.bps, P, B);
             for (uint32_t t = 0; t < I; ++t)
                 hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, t, sst, acc,
-                                   ticket, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
+                                   facc, ticket, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
             hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, I, sst, acc,
-                               ticket, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
+                               facc, ticket, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
         }
     }
     {

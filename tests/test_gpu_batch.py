@@ -122,19 +122,26 @@ def test_batch_large_segments_take_the_pass_per_launch_path(ctx):
         check_frame(r, single(ctx, c, seg_kw, CLU))
 
 
-def test_batch_stride_and_range_error_are_per_frame(ctx):
+def test_batch_stride_and_far_returns_are_per_frame(ctx):
     good = load_frame(FRAMES[1])[:20_000]
+    far = good.copy()
+    far[123, 1] = 5000.0  # beyond the int32 fixed-point range: that frame takes the wide-moment path, alone
+    far[123, 2] = -1.7
     bad = good.copy()
-    bad[123, 1] = 5000.0  # outside the fixed-point range: that frame reports LPX_ERR_RANGE, the others are fine
-    bctx = Context(0, batch=3)
+    bad[5, 0] = np.nan
+    bctx = Context(0, batch=4)
     try:
-        res = run_batch(bctx, [good, bad, good], SEG, CLU, stride_floats=8)
+        res = run_batch(bctx, [good, far, bad, good], SEG, CLU, stride_floats=8)
     finally:
         bctx.close()
     ref = single(ctx, good, SEG, CLU)
     check_frame(res[0], ref)
-    check_frame(res[2], ref)
-    assert res[1]["status"] == 2  # -LPX_ERR_RANGE
+    check_frame(res[3], ref)
+    check_frame(res[1], single(ctx, far, SEG, CLU))
+    o = oracle.segment(far, oracle.SegCfg(**SEG))
+    assert o["rc"] == 0 and np.array_equal(res[1]["labels"], o["labels"])
+    assert np.array_equal(res[1]["planes"].view(np.uint32), o["planes"].view(np.uint32))
+    assert res[2]["status"] == 2  # -LPX_ERR_RANGE: NaN
 
 
 def test_batch_non_finite_frame_is_flagged_and_not_clustered(ctx):

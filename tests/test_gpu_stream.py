@@ -1,0 +1,155 @@
+"""GPU half of the 154-frame stream (BASELINE.json configs[3]) and the bench-shaped concurrency test.
+
+* every frame of the reference's data/*.pcd through the multi-frame launch chain, both configurations of
+  tests/golden/stream_golden.npz: counts and CRC-32 of the segmentation labels, the obstacle order, the plane
+  words and the cluster labels (the latter produced by the REFERENCE's own kd-tree build);
+* the shape bench.py runs (8 batch contexts x 32 frame slots, 2 enqueue threads, 3 rounds, 256 frames in
+  flight): every frame's five outputs equal the single-frame path and the goldens."""
+import concurrent.futures
+import zlib
+
+import numpy as np
+import pytest
+
+from lidar_processing_amd import ClusteringConfiguration, Context, SegmentationConfiguration
+from util import STREAM_CONFIGS, load_stream_frame, stream_gold, stream_names
+
+pytestmark = pytest.mark.gpu
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+@pytest.fixture(scope="module")
+def stream():
+    return [load_stream_frame(n) for n in stream_names()]
+
+
+class Pitched:
+    """F frames resident in HBM as pitched arrays, like bench.py keeps them"""
+
+    def __init__(self, frames, P):
+        import torch
+        self.torch = torch
+        dev = torch.device("cuda:0")
+        self.F = len(frames)
+        self.n = np.array([f.shape[0] for f in frames], np.uint32)
+        self.pitch = int(self.n.max())
+        host = np.zeros((self.F, self.pitch, 8), np.float32)  # 32-byte PointXYZI records
+        for j, f in enumerate(frames):
+            host[j, :f.shape[0], :4] = f
+        self.pts = torch.from_numpy(host).to(dev)
+        self.P = P
+        self.labels = torch.zeros((self.F, self.pitch), dtype=torch.int32, device=dev)
+        self.gidx = torch.zeros((self.F, self.pitch), dtype=torch.int32, device=dev)
+        self.oidx = torch.zeros((self.F, self.pitch), dtype=torch.int32, device=dev)
+        self.planes = torch.zeros((self.F, 4 * P), dtype=torch.float32, device=dev)
+        self.clab = torch.zeros((self.F, self.pitch), dtype=torch.int32, device=dev)
+        self.counts = torch.zeros((self.F, 4), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+    def clear(self):
+        for t in (self.labels, self.gidx, self.oidx, self.clab, self.counts):
+            t.fill_(-3)
+        self.planes.fill_(9.0)
+        self.torch.cuda.synchronize()
+
+    def enqueue(self, ctx, lo, hi, scfg, ccfg):
+        ctx.segment_cluster_batch_device(self.n[lo:hi], self.pts[lo].data_ptr(), 32, self.pitch, scfg, ccfg,
+                                         self.labels[lo].data_ptr(), self.gidx[lo].data_ptr(),
+                                         self.oidx[lo].data_ptr(), self.planes[lo].data_ptr(),
+                                         self.clab[lo].data_ptr(), self.counts[lo].data_ptr())
+
+    def frame(self, j):
+        ng, no, nc, status = (int(v) for v in self.counts[j].cpu().numpy().view(np.uint32))
+        n = int(self.n[j])
+        return dict(status=status, n_ground=ng, n_obstacle=no, n_clusters=nc,
+                    labels=self.labels[j, :n].cpu().numpy().view(np.uint32),
+                    ground_idx=self.gidx[j, :ng].cpu().numpy().view(np.uint32),
+                    obstacle_idx=self.oidx[j, :no].cpu().numpy().view(np.uint32),
+                    planes=self.planes[j].cpu().numpy().reshape(self.P, 4),
+                    cluster_labels=self.clab[j, :no].cpu().numpy())
+
+
+def golden_row(res):
+    return [res["n_ground"], res["n_obstacle"], res["n_clusters"], crc(res["labels"].astype(np.uint8)),
+            crc(res["obstacle_idx"]), crc(res["cluster_labels"]), crc(res["planes"])]
+
+
+@pytest.mark.parametrize("cname", list(STREAM_CONFIGS))
+def test_stream_154_frames_match_reference_goldens(stream, cname):
+    """BASELINE configs[3]: all 154 frames in filename order, 32 per launch chain"""
+    skw, ckw = STREAM_CONFIGS[cname]
+    scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
+    g = stream_gold()
+    buf = Pitched(stream, skw["number_of_planar_partitions"])
+    buf.clear()
+    bctx = Context(0, batch=32)
+    try:
+        bctx.reserve(buf.pitch)
+        for lo in range(0, buf.F, 32):
+            buf.enqueue(bctx, lo, min(lo + 32, buf.F), scfg, ccfg)
+        bctx.synchronize()
+    finally:
+        bctx.close()
+    bad = []
+    for j in range(buf.F):
+        res = buf.frame(j)
+        if res["status"] != 0 or golden_row(res) != [int(v) for v in g[cname][j]]:
+            bad.append((stream_names()[j], res["status"], golden_row(res), g[cname][j].tolist()))
+    assert not bad, bad[:3]
+
+
+def test_bench_shape_8_contexts_32_slots_2_threads(stream):
+    """the configuration bench.py times: 256 frames per step, 32 per chain, 8 contexts (streams) in flight, two
+    host threads enqueueing, three rounds back to back without a synchronisation in between; afterwards every
+    frame's labels, index lists, planes, cluster labels and counts equal the single-frame entry point's"""
+    cname = "p6i5_d025q05"
+    skw, ckw = STREAM_CONFIGS[cname]
+    scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
+    F, B, C, T, ROUNDS = 256, 32, 8, 2, 3
+    ids = [(5 * j) % len(stream) for j in range(F)]  # 154 distinct frames spread over the slots, some twice
+    buf = Pitched([stream[i] for i in ids], skw["number_of_planar_partitions"])
+    chains = [(k, min(k + B, F)) for k in range(0, F, B)]
+    ctxs = [Context(0, batch=B) for _ in range(C)]
+    try:
+        for c in ctxs:
+            c.reserve(buf.pitch)
+
+        def enqueue(tid):
+            buf.torch.cuda.set_device(0)
+            for k, (lo, hi) in enumerate(chains):
+                if (k % C) % T == tid:
+                    buf.enqueue(ctxs[k % C], lo, hi, scfg, ccfg)
+
+        with concurrent.futures.ThreadPoolExecutor(T) as pool:
+            for r in range(ROUNDS):
+                if r == ROUNDS - 1:
+                    for c in ctxs:
+                        c.synchronize()
+                    buf.clear()  # the last round has to produce everything again
+                list(pool.map(enqueue, range(T)))
+        for c in ctxs:
+            c.synchronize()
+    finally:
+        for c in ctxs:
+            c.close()
+    g = stream_gold()
+    one = Context(0)
+    try:
+        one.reserve(buf.pitch)
+        ref = {}
+        for j in range(F):
+            res = buf.frame(j)
+            assert res["status"] == 0
+            assert golden_row(res) == [int(v) for v in g[cname][ids[j]]], stream_names()[ids[j]]
+            if ids[j] not in ref:
+                ref[ids[j]] = one.segment_cluster(stream[ids[j]], scfg, ccfg)
+            want = ref[ids[j]]
+            for k in ("labels", "ground_idx", "obstacle_idx", "cluster_labels"):
+                assert np.array_equal(res[k], want[k]), (j, k)
+            assert np.array_equal(res["planes"].view(np.uint32), want["planes"].view(np.uint32))
+            assert res["n_clusters"] == want["n_clusters"]
+    finally:
+        one.close()
