@@ -579,7 +579,12 @@ static int cluster_resident(lpx_ctx *ctx, uint32_t m_bound, const lpx_clu_cfg *c
     {
         // the kd-tree of a first attempt stays valid (and must not be rebuilt from the permuted node array:
         // the layout depends on the input order, src/kdtree.hpp:174-225)
-        if ((rc = lpx_run_cluster(ctx, m_bound, cfg, (int32_t *)ctx->d_clabels.p, nullptr, attempt > 0)))
+        // A retry counts every list (no single-pass reservations): which groups win a reservation depends on
+        // scheduling, so only then is nb_total the exact requirement, and the attempt after it always fits.
+        ctx->exact_lists_only = attempt > 0;
+        rc = lpx_run_cluster(ctx, m_bound, cfg, (int32_t *)ctx->d_clabels.p, nullptr, attempt > 0);
+        ctx->exact_lists_only = false;
+        if (rc)
             return rc;
         if ((rc = read_frame(ctx, fs)))
             return rc;

@@ -147,6 +147,7 @@ struct lpx_ctx
     void *dbg_buf = nullptr;   // optional per-group statistics of the neighbour kernel (tools only)
     Buf dbg_store;
     bool attr_kd = false, attr_replay = false;  // hipFuncSetAttribute done for this context's device
+    bool exact_lists_only = false;  // capacity retry: count every list, so nb_total is the exact requirement
 
     // profiling
     bool profiling = false;

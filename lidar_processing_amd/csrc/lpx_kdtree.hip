@@ -1611,7 +1611,7 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
         const uint32_t nbk = groups / 2;
         hipLaunchKernelGGL(nb_group_kernel, dim3(nbk + (nbk + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b),
                            dim3(NB_THREADS), 0, ctx->stream, (const Node *)PR, frame, r2, rr, thr_f, len, off,
-                           (uint32_t *)ctx->nb_idx.p, ctx->cap_nb, ctx->cap_rs,
+                           (uint32_t *)ctx->nb_idx.p, ctx->cap_nb, ctx->exact_lists_only ? 0ull : ctx->cap_rs,
                            hook ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, (uint32_t *)ctx->dbg_buf,
                            lpx_fv(ctx));
     }

@@ -1,114 +1,106 @@
-// Drives the drop-in headers exactly like Processor::process does (reference src/processor.cpp:135-200):
-// segment -> recolour into PointXYZRGBL clouds -> cluster -> regroup.  Reads a raw float32 x y z i
-// file, writes labels so that the Python test can compare them with the oracle.
+// Test harness for the drop-in headers: makes the two hot-path calls the reference's processor node makes
+// (Segmenter::segment on a PointXYZI cloud, then Clusterer::cluster on the obstacle cloud recoloured as
+// PointXYZRGBL; reference src/processor.cpp:150 and :178) and dumps what the Python test compares with the
+// oracle.  It also checks Clusterer::regroup against a per-label bucket count computed here.
+//
+// in : raw float32 records x y z intensity
+// out: u32 n, n_ground, n_obstacle, n_clusters | u32 seg labels[n] | i32 cluster labels[n_obstacle] |
+//      f32 obstacle xyz[n_obstacle * 3]
 #include "clustering.hpp"
 #include "segmentation.hpp"
 
-#include <algorithm>
+#include <cstdint>
 #include <cstdio>
-#include <memory>
-#include <stdexcept>
+#include <cstdlib>
 #include <vector>
 
-using namespace lidar_processing;
+namespace lp = lidar_processing;
+
+static int fail(const char *what)
+{
+    std::fprintf(stderr, "dropin_main: %s\n", what);
+    return 1;
+}
 
 int main(int argc, char **argv)
 {
     if (argc < 3)
-    {
-        std::fprintf(stderr, "usage: dropin_main in.f32 out.bin\n");
-        return 2;
-    }
-    std::FILE *f = std::fopen(argv[1], "rb");
-    if (!f)
-        return 2;
-    pcl::PointCloud<pcl::PointXYZI> cloud_in_;
-    float rec[4];
-    while (std::fread(rec, sizeof rec, 1, f) == 1)
+        return fail("usage: dropin_main in.f32 out.bin");
+    std::FILE *in = std::fopen(argv[1], "rb");
+    if (!in)
+        return fail("cannot open the input");
+    pcl::PointCloud<pcl::PointXYZI> cloud;
+    for (float r[4]; std::fread(r, sizeof r, 1, in) == 1;)
     {
         pcl::PointXYZI p;
-        p.x = rec[0];
-        p.y = rec[1];
-        p.z = rec[2];
-        p.intensity = rec[3];
-        cloud_in_.push_back(p);
+        p.x = r[0], p.y = r[1], p.z = r[2], p.intensity = r[3];
+        cloud.push_back(p);
     }
-    std::fclose(f);
+    std::fclose(in);
 
-    Segmenter segmenter_;
-    Clusterer clusterer_;
-    pcl::PointCloud<pcl::PointXYZI> ground_points_;
-    pcl::PointCloud<pcl::PointXYZI> obstacle_points_;
-    std::vector<SegmentationLabel> segmentation_labels_;
+    lp::Segmenter segmenter;
+    lp::Clusterer clusterer;
+    std::vector<lp::SegmentationLabel> seg_labels;
+    pcl::PointCloud<pcl::PointXYZI> ground, obstacles;
+    segmenter.segment(cloud, seg_labels, ground, obstacles);  // call 1
 
-    segmenter_.segment(cloud_in_, segmentation_labels_, ground_points_, obstacle_points_);
+    pcl::PointCloud<pcl::PointXYZRGBL> coloured;  // the point type the node hands to the clusterer
+    coloured.reserve(obstacles.size());
+    for (std::size_t i = 0; i < obstacles.size(); ++i)
+        coloured.emplace_back(obstacles[i].x, obstacles[i].y, obstacles[i].z, 0, 255, 0, 1);
 
-    auto obstacle_cloud = std::make_unique<pcl::PointCloud<pcl::PointXYZRGBL>>();
-    obstacle_cloud->reserve(obstacle_points_.size());
-    for (const auto &obstacle_point : obstacle_points_)
+    std::vector<lp::ClusteringLabel> clu_labels;
+    clusterer.cluster(coloured, clu_labels);  // call 2
+    if (clu_labels.size() != coloured.size())
+        return fail("one cluster label per obstacle point expected");
+
+    // bucket sizes per label, and the running position of every point inside its bucket
+    std::int64_t top = -1;
+    for (const lp::ClusteringLabel l : clu_labels)
     {
-        obstacle_cloud->emplace_back(obstacle_point.x, obstacle_point.y, obstacle_point.z, 0, 255, 0, 1);
+        if (l == lp::Clusterer::UNDEFINED)
+            return fail("a point was left UNDEFINED");
+        if (l > top)
+            top = l;
+    }
+    std::vector<std::uint32_t> bucket(static_cast<std::size_t>(top + 1), 0U);
+    std::vector<std::uint32_t> slot(clu_labels.size(), 0U);
+    for (std::size_t i = 0; i < clu_labels.size(); ++i)
+        if (clu_labels[i] != lp::Clusterer::INVALID)
+            slot[i] = bucket[static_cast<std::size_t>(clu_labels[i])]++;
+
+    // the device-side regrouping must put point i of label l at position slot[i] of cloud l
+    std::vector<pcl::PointCloud<pcl::PointXYZ>> groups;
+    clusterer.regroup(coloured, groups);
+    if (groups.size() != bucket.size())
+        return fail("regroup: number of clusters");
+    for (std::size_t c = 0; c < groups.size(); ++c)
+        if (groups[c].size() != bucket[c] || bucket[c] == 0U)
+            return fail("regroup: cluster size (or an empty cluster)");
+    for (std::size_t i = 0; i < clu_labels.size(); ++i)
+    {
+        if (clu_labels[i] == lp::Clusterer::INVALID)
+            continue;
+        const pcl::PointXYZ &g = groups[static_cast<std::size_t>(clu_labels[i])][slot[i]];
+        if (g.x != coloured[i].x || g.y != coloured[i].y || g.z != coloured[i].z)
+            return fail("regroup: a point is out of place");
     }
 
-    std::vector<pcl::PointCloud<pcl::PointXYZ>> clustered_obstacle_cloud;
-    std::vector<ClusteringLabel> cluster_labels;
-    clusterer_.cluster(*obstacle_cloud, cluster_labels);
-
-    const auto max_label = *std::max_element(cluster_labels.cbegin(), cluster_labels.cend());
-    clustered_obstacle_cloud.resize(max_label + 1);
-    for (std::size_t i = 0; i < obstacle_cloud->size(); ++i)
+    std::FILE *out = std::fopen(argv[2], "wb");
+    if (!out)
+        return fail("cannot open the output");
+    const std::uint32_t head[4] = {static_cast<std::uint32_t>(cloud.size()), static_cast<std::uint32_t>(ground.size()),
+                                   static_cast<std::uint32_t>(obstacles.size()),
+                                   static_cast<std::uint32_t>(bucket.size())};
+    std::fwrite(head, sizeof head, 1, out);
+    std::fwrite(seg_labels.data(), sizeof(std::uint32_t), seg_labels.size(), out);
+    std::fwrite(clu_labels.data(), sizeof(std::int32_t), clu_labels.size(), out);
+    for (std::size_t i = 0; i < obstacles.size(); ++i)
     {
-        auto label = cluster_labels[i];
-        if (label == Clusterer::UNDEFINED)
-        {
-            throw std::runtime_error("Undefined label found (clustering)");
-        }
-        if (label != Clusterer::INVALID)
-        {
-            const auto &point = obstacle_cloud->points[i];
-            clustered_obstacle_cloud[label].emplace_back(point.x, point.y, point.z);
-        }
+        const float xyz[3] = {obstacles[i].x, obstacles[i].y, obstacles[i].z};
+        std::fwrite(xyz, sizeof xyz, 1, out);
     }
-
-    // optional device-side regrouping must equal the caller's own loop above
-    std::vector<pcl::PointCloud<pcl::PointXYZ>> regrouped;
-    clusterer_.regroup(*obstacle_cloud, regrouped);
-    if (regrouped.size() != clustered_obstacle_cloud.size())
-    {
-        throw std::runtime_error("regroup: cluster count differs");
-    }
-    for (std::size_t c = 0; c < regrouped.size(); ++c)
-    {
-        if (regrouped[c].size() != clustered_obstacle_cloud[c].size())
-        {
-            throw std::runtime_error("regroup: cluster size differs");
-        }
-        for (std::size_t p = 0; p < regrouped[c].size(); ++p)
-        {
-            if (regrouped[c][p].x != clustered_obstacle_cloud[c][p].x || regrouped[c][p].y != clustered_obstacle_cloud[c][p].y ||
-                regrouped[c][p].z != clustered_obstacle_cloud[c][p].z)
-            {
-                throw std::runtime_error("regroup: point differs");
-            }
-        }
-    }
-
-    std::FILE *o = std::fopen(argv[2], "wb");
-    const std::uint32_t n = static_cast<std::uint32_t>(cloud_in_.size());
-    const std::uint32_t ng = static_cast<std::uint32_t>(ground_points_.size());
-    const std::uint32_t no = static_cast<std::uint32_t>(obstacle_points_.size());
-    const std::uint32_t nc = static_cast<std::uint32_t>(clustered_obstacle_cloud.size());
-    std::fwrite(&n, 4, 1, o);
-    std::fwrite(&ng, 4, 1, o);
-    std::fwrite(&no, 4, 1, o);
-    std::fwrite(&nc, 4, 1, o);
-    std::fwrite(segmentation_labels_.data(), 4, n, o);
-    std::fwrite(cluster_labels.data(), 4, no, o);
-    for (const auto &p : obstacle_points_)
-    {
-        std::fwrite(&p.x, 4, 3, o);
-    }
-    std::fclose(o);
-    std::printf("points %u ground %u obstacle %u clusters %u\n", n, ng, no, nc);
+    std::fclose(out);
+    std::printf("points %u ground %u obstacle %u clusters %u\n", head[0], head[1], head[2], head[3]);
     return 0;
 }

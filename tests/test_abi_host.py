@@ -103,6 +103,39 @@ def test_dropin_headers_compile_like_processor(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_binding_recipe_survives_quoted_include_resolution(tmp_path):
+    """src/processor.cpp includes "segmentation.hpp" / "clustering.hpp" with quotes, and a quoted include searches
+    the including file's own directory before any -I path.  A caller that sits NEXT TO same-named CPU headers (as
+    processor.cpp does in the reference's src/) therefore never sees the drop-in headers through an include path
+    alone; integration/apply_to_reference.sh replaces the two headers by forwarding shims.  Decoy headers that
+    refuse to compile stand in for the reference's."""
+    from lidar_processing_amd import _lib
+    _lib.build()
+    ref = tmp_path / "reference"
+    (ref / "src").mkdir(parents=True)
+    for h in ("segmentation", "clustering"):
+        (ref / "src" / f"{h}.hpp").write_text('#error "the CPU header of the reference was picked"\n')
+        (ref / "src" / f"{h}.cpp").write_text("// cpu implementation\n")
+    tu = ref / "src" / "processor_like.cpp"
+    tu.write_text(open(os.path.join(ROOT, "tests", "cxx", "dropin_main.cpp")).read())
+
+    def compile_tu():
+        return subprocess.run(["g++", "-std=c++17", "-O0", "-fsyntax-only", f"-I{ROOT}/include/lidar_processing",
+                               f"-I{ROOT}/include", f"-I{ROOT}/tests/cxx", str(tu)], capture_output=True, text=True)
+
+    r = compile_tu()
+    assert r.returncode != 0 and "CPU header of the reference was picked" in r.stderr  # the pitfall is real
+    r = subprocess.run([os.path.join(ROOT, "integration", "apply_to_reference.sh"), str(ref), ROOT],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (ref / "src" / "segmentation_cpu.hpp").exists() and (ref / "src" / "clustering_cpu.cpp").exists()
+    r = compile_tu()
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([os.path.join(ROOT, "integration", "apply_to_reference.sh"), str(ref), ROOT],
+                       capture_output=True, text=True)  # idempotent: the originals are not overwritten by a shim
+    assert r.returncode == 0 and "#error" in (ref / "src" / "segmentation_cpu.hpp").read_text()
+
+
 def test_config_structs_mirror_reference_defaults():
     from lidar_processing_amd import ClusteringConfiguration, Clusterer, SegmentationConfiguration, SegmentationLabel
     s = SegmentationConfiguration()
