@@ -120,9 +120,51 @@ class Clusterer final
         }
     }
 
+    // Optional fast path for the convex branch of findOrderedConcaveOutlines (src/polygon_simplification.cpp:96-115):
+    // one counter-clockwise outline per valid cluster with fewer than `max_points` points (20 in the reference),
+    // clusters in label order, computed on the device for the labels of the last cluster() call.  Larger
+    // clusters are skipped here (the reference sends them to its concave-hull submodule).  PointOutT needs
+    // public x and y members and a (x, y) constructor, like geom::Point<float>.
+    template <typename PointOutT>
+    void convex_outlines(std::vector<std::vector<PointOutT>> &outlines, std::uint32_t max_points = 20U)
+    {
+        outlines.clear();
+        if (last_clusters_ == 0U)
+        {
+            return;
+        }
+        hull_offsets_.resize(last_clusters_ + 1U);
+        hull_indices_.resize(last_size_);
+        hull_xy_.resize(2U * static_cast<std::size_t>(last_size_));
+        std::uint32_t number_of_hull_points = 0U;
+        const int rc = lpx_cluster_hulls(context_->get(), last_size_, last_clusters_, max_points, hull_offsets_.data(),
+                                         hull_indices_.data(), hull_xy_.data(), &number_of_hull_points);
+        if (rc != LPX_OK)
+        {
+            throw std::runtime_error(std::string("convex outlines failed: ") + lpx_last_error(context_->get()));
+        }
+        for (std::uint32_t c = 0U; c < last_clusters_; ++c)
+        {
+            if (hull_offsets_[c + 1U] == hull_offsets_[c])
+            {
+                continue;
+            }
+            std::vector<PointOutT> outline;
+            outline.reserve(hull_offsets_[c + 1U] - hull_offsets_[c]);
+            for (std::uint32_t p = hull_offsets_[c]; p < hull_offsets_[c + 1U]; ++p)
+            {
+                outline.emplace_back(hull_xy_[2U * p], hull_xy_[2U * p + 1U]);
+            }
+            outlines.push_back(std::move(outline));
+        }
+    }
+
   private:
     std::shared_ptr<detail::LpxContext> context_;
     ClusteringConfiguration configuration_;
+    std::vector<std::uint32_t> hull_offsets_;
+    std::vector<std::uint32_t> hull_indices_;
+    std::vector<float> hull_xy_;
     std::uint32_t last_size_{0U};
     std::uint32_t last_clusters_{0U};
     std::vector<std::uint32_t> group_offsets_;

@@ -84,6 +84,8 @@ class Segmenter final
         obstacle_cloud.clear();
 
         const std::uint32_t number_of_points = static_cast<std::uint32_t>(cloud_in.points.size());
+        last_ground_ = 0U;
+        last_obstacle_ = 0U;
         if (number_of_points == 0)
         {
             return;
@@ -120,6 +122,8 @@ class Segmenter final
             return;
         }
 
+        last_ground_ = number_of_ground;
+        last_obstacle_ = number_of_obstacle;
         ground_cloud.reserve(number_of_ground);
         obstacle_cloud.reserve(number_of_obstacle);
         for (std::uint32_t i = 0U; i < number_of_ground; ++i)
@@ -132,9 +136,34 @@ class Segmenter final
         }
     }
 
+    // Optional fast path for what the reference's caller does right after segment() (src/processor.cpp:152-163):
+    // the ground cloud recoloured as PointXYZRGBL(x, y, z, 220, 220, 220, label 0) and the obstacle cloud as
+    // (x, y, z, 0, 255, 0, label 1), whose records the node then memcpy's into the published PointCloud2 messages
+    // (src/conversions.cpp:164-193).  The records are written on the device from the points that are still
+    // resident there; valid after segment() and before the next segment() on this object.
+    template <typename PointOutT>
+    void coloured_clouds(pcl::PointCloud<PointOutT> &ground_cloud, pcl::PointCloud<PointOutT> &obstacle_cloud)
+    {
+        static_assert(sizeof(PointOutT) == 32U, "pcl::PointXYZRGBL records are 32 bytes");
+        ground_cloud.points.resize(last_ground_);
+        obstacle_cloud.points.resize(last_obstacle_);
+        std::uint32_t number_of_ground = 0U;
+        std::uint32_t number_of_obstacle = 0U;
+        PointOutT scratch{};  // a null destination is an argument error; an empty cloud has no data()
+        const int rc = lpx_coloured_clouds(context_->get(), last_ground_ ? static_cast<void *>(ground_cloud.points.data()) : &scratch,
+                                           last_obstacle_ ? static_cast<void *>(obstacle_cloud.points.data()) : &scratch,
+                                           &number_of_ground, &number_of_obstacle);
+        if (rc != LPX_OK || number_of_ground != last_ground_ || number_of_obstacle != last_obstacle_)
+        {
+            throw std::runtime_error(std::string("coloured clouds failed: ") + lpx_last_error(context_->get()));
+        }
+    }
+
   private:
     std::shared_ptr<detail::LpxContext> context_;
     SegmentationConfiguration configuration_;
+    std::uint32_t last_ground_{0U};
+    std::uint32_t last_obstacle_{0U};
     std::vector<std::uint32_t> ground_indices_;
     std::vector<std::uint32_t> obstacle_indices_;
     std::vector<float> planes_;

@@ -115,6 +115,30 @@ int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint
                         uint32_t *obstacle_idx, uint32_t *n_obstacle, float *planes, int32_t *cluster_labels,
                         uint32_t *n_clusters);
 
+/* ---- PointCloud2 wire format (N4) ------------------------------------------------------------ */
+
+/* The reference's node decodes the incoming sensor_msgs/PointCloud2 on the host into a PointXYZI cloud with four
+ * field iterators (src/conversions.cpp:62-85) before it calls segment().  These entry points take the message's
+ * data[] buffer as it is: n = width * height records of point_step bytes, float32 x / y / z at the byte offsets
+ * of the message's "x" / "y" / "z" PointField entries (little-endian, like the reference assumes; offsets and
+ * point_step need not be multiples of 4).  Everything else is lpx_segment / lpx_segment_cluster. */
+int lpx_segment_fields(lpx_ctx *ctx, const void *data, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                       uint32_t off_z, uint32_t n, const lpx_seg_cfg *cfg, uint32_t *labels, uint32_t *ground_idx,
+                       uint32_t *n_ground, uint32_t *obstacle_idx, uint32_t *n_obstacle, float *planes);
+int lpx_segment_cluster_fields(lpx_ctx *ctx, const void *data, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                               uint32_t off_z, uint32_t n, const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
+                               uint32_t *labels, uint32_t *ground_idx, uint32_t *n_ground, uint32_t *obstacle_idx,
+                               uint32_t *n_obstacle, float *planes, int32_t *cluster_labels, uint32_t *n_clusters);
+
+/* The two clouds the node publishes after segment(): ground points as pcl::PointXYZRGBL(x, y, z, 220, 220, 220,
+ * label 0), obstacle points as (x, y, z, 0, 255, 0, label 1) (src/processor.cpp:152-163), whose 32-byte records
+ * are memcpy'd into the data[] of the outgoing PointCloud2 messages (src/conversions.cpp:164-193).  Record layout
+ * (PCL 1.12 point_types): float x, y, z, 1.0f | uint8 b, g, r, a = 255 | uint32 label | 8 zero bytes.  Records
+ * of the LAST host segmentation call of this context, in output-cloud order; each array needs room for 32 bytes
+ * per point of that cloud (n_ground / n_obstacle as returned by that call). */
+int lpx_coloured_clouds(lpx_ctx *ctx, void *ground_records, void *obstacle_records, uint32_t *n_ground,
+                        uint32_t *n_obstacle);
+
 /* Cluster regrouping done by the caller right after cluster() (reference src/processor.cpp:180-200):
  * the points of every valid cluster, clusters in label order, points in ascending index order,
  * INVALID dropped.  Works on the labels of the LAST lpx_cluster / lpx_segment_cluster call of this
@@ -122,6 +146,17 @@ int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint
  * clustered cloud), *n_valid = offsets[n_clusters]. */
 int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t *offsets, uint32_t *indices,
                        uint32_t *n_valid);
+
+/* Per-cluster 2-D convex hulls (N3): what findOrderedConcaveOutlines computes for clusters with fewer than 20
+ * points (reference src/polygon_simplification.cpp:96-115; max_points = 20) and findOrderedConvexOutlines for all
+ * of them (:32-80; max_points = UINT32_MAX) -- Andrew's monotone chain on (x, y), counter-clockwise from the
+ * lowest (x, y) point, collinear points and duplicates are not vertices.  The reference takes the algorithm from
+ * its Convex-Hull git submodule, which its checkout does not vendor: the published algorithm is restated, see
+ * DESIGN.md.  Clusters with max_points or more points get an empty hull (the reference's concave branch is out
+ * of scope).  Works on the labels of the LAST clustering call of this context: hull_offsets[n_clusters + 1],
+ * hull_indices (indices into the clustered cloud) and hull_xy (x, y pairs; may be NULL) hold up to m entries. */
+int lpx_cluster_hulls(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t max_points, uint32_t *hull_offsets,
+                      uint32_t *hull_indices, float *hull_xy, uint32_t *n_hull_points);
 
 /* ---- device-resident entry points (asynchronous on the context stream) ---------------------- */
 
@@ -145,6 +180,19 @@ int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames, const void
                                      const lpx_clu_cfg *clu_cfg, uint32_t *d_labels, uint32_t *d_ground_idx,
                                      uint32_t *d_obstacle_idx, float *d_planes, int32_t *d_cluster_labels,
                                      uint32_t *d_counts);
+/* device forms of the PointCloud2 entry points above.  d_ground_idx / d_obstacle_idx are the index lists the
+ * segmentation of the same frame(s) wrote; the batch form takes arrays pitched like the batch entry point's
+ * (records pitched by frame_pitch * 32 bytes).  Counts stay on the device. */
+int lpx_segment_cluster_fields_device(lpx_ctx *ctx, const void *d_data, uint32_t point_step, uint32_t off_x,
+                                      uint32_t off_y, uint32_t off_z, uint32_t n, const lpx_seg_cfg *seg_cfg,
+                                      const lpx_clu_cfg *clu_cfg, uint32_t *d_labels, uint32_t *d_ground_idx,
+                                      uint32_t *d_obstacle_idx, float *d_planes, int32_t *d_cluster_labels,
+                                      uint32_t *d_counts);
+int lpx_coloured_clouds_device(lpx_ctx *ctx, const uint32_t *d_ground_idx, const uint32_t *d_obstacle_idx,
+                               void *d_ground_records, void *d_obstacle_records);
+int lpx_coloured_clouds_batch_device(lpx_ctx *ctx, uint32_t n_frames, uint32_t frame_pitch,
+                                     const uint32_t *d_ground_idx, const uint32_t *d_obstacle_idx,
+                                     void *d_ground_records, void *d_obstacle_records);
 int lpx_segment_device(lpx_ctx *ctx, const void *d_pts, size_t stride_bytes, uint32_t n, const lpx_seg_cfg *cfg,
                        uint32_t *d_labels, uint32_t *d_ground_idx, uint32_t *d_obstacle_idx, float *d_planes,
                        uint32_t *d_counts);
@@ -154,6 +202,11 @@ int lpx_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride_bytes, uin
 /* device form of lpx_cluster_groups: d_offsets needs n_clusters + 1 (at most m + 1) entries, d_indices m */
 int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets,
                               uint32_t *d_indices);
+
+/* device form of lpx_cluster_hulls on the CSR lpx_cluster_groups_device wrote (same labels, same cloud) */
+int lpx_cluster_hulls_device(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, const uint32_t *d_offsets,
+                             const uint32_t *d_indices, uint32_t max_points, uint32_t *d_hull_offsets,
+                             uint32_t *d_hull_indices, float *d_hull_xy);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 

@@ -62,6 +62,17 @@ def lib():
                                       vp, vp, pu32]
     L.lpx_segment_cluster_device.argtypes = [vp, vp, sz, u32, C.POINTER(SegCfg), C.POINTER(CluCfg), vp, vp, vp, vp,
                                              vp, vp]
+    L.lpx_segment_fields.argtypes = [vp, vp, u32, u32, u32, u32, u32, C.POINTER(SegCfg), vp, vp, pu32, vp, pu32, vp]
+    L.lpx_segment_cluster_fields.argtypes = [vp, vp, u32, u32, u32, u32, u32, C.POINTER(SegCfg), C.POINTER(CluCfg), vp, vp,
+                                             pu32, vp, pu32, vp, vp, pu32]
+    L.lpx_segment_cluster_fields_device.argtypes = [vp, vp, u32, u32, u32, u32, u32, C.POINTER(SegCfg), C.POINTER(CluCfg),
+                                                    vp, vp, vp, vp, vp, vp]
+    L.lpx_coloured_clouds.argtypes = [vp, vp, vp, pu32, pu32]
+    L.lpx_coloured_clouds_device.argtypes = [vp, vp, vp, vp, vp]
+    L.lpx_coloured_clouds_batch_device.argtypes = [vp, u32, u32, vp, vp, vp, vp]
+    L.lpx_cluster_hulls.argtypes = [vp, u32, u32, u32, vp, vp, vp, pu32]
+    L.lpx_cluster_hulls_device.argtypes = [vp, vp, u32, vp, vp, u32, vp, vp, vp]
+    L.lpx_cluster_groups_device.argtypes = [vp, vp, u32, vp, vp]
     L.lpx_create_batch.argtypes = [C.c_int, u32, C.POINTER(vp)]
     L.lpx_segment_cluster_batch_device.argtypes = [vp, u32, vp, sz, u32, vp, C.POINTER(SegCfg), C.POINTER(CluCfg), vp,
                                                    vp, vp, vp, vp, vp]

@@ -170,6 +170,44 @@ class Context:
         return dict(labels=labels, ground_idx=gi[:ng.value].copy(), obstacle_idx=oi[:no.value].copy(),
                     planes=planes[:P], cluster_labels=cl[:no.value].copy(), n_clusters=nc.value)
 
+    # ---- PointCloud2 wire format ----
+    def segment_cluster_fields(self, data, point_step, offsets, n, seg_cfg, clu_cfg=None):
+        """lpx_segment_fields / lpx_segment_cluster_fields: `data` is the byte buffer of a sensor_msgs/PointCloud2
+        message (n records of point_step bytes), offsets = byte offsets of its float32 x, y, z fields"""
+        buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray)
+                                   else data.view(np.uint8).reshape(-1))
+        assert buf.size >= n * point_step
+        P = seg_cfg.number_of_planar_partitions
+        labels = np.zeros(n, np.uint32)
+        gi = np.zeros(max(n, 1), np.uint32)
+        oi = np.zeros(max(n, 1), np.uint32)
+        cl = np.full(max(n, 1), UNDEFINED, np.int32)
+        planes = np.zeros((max(P, 1), 4), np.float32)
+        ng, no, nc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        sc = seg_cfg._c()
+        ox, oy, oz = (int(o) for o in offsets)
+        if clu_cfg is None:
+            self.check(self._L.lpx_segment_fields(self._h, _vp(buf), int(point_step), ox, oy, oz, int(n), C.byref(sc),
+                                                  _vp(labels), _vp(gi), C.byref(ng), _vp(oi), C.byref(no),
+                                                  _vp(planes)))
+        else:
+            cc = clu_cfg._c()
+            self.check(self._L.lpx_segment_cluster_fields(self._h, _vp(buf), int(point_step), ox, oy, oz, int(n),
+                                                          C.byref(sc), C.byref(cc), _vp(labels), _vp(gi), C.byref(ng),
+                                                          _vp(oi), C.byref(no), _vp(planes), _vp(cl), C.byref(nc)))
+        return dict(labels=labels, ground_idx=gi[:ng.value].copy(), obstacle_idx=oi[:no.value].copy(),
+                    planes=planes[:P], cluster_labels=cl[:no.value].copy(), n_clusters=nc.value)
+
+    def coloured_clouds(self, n_ground, n_obstacle):
+        """lpx_coloured_clouds: the 32-byte PointXYZRGBL records of the ground and obstacle clouds of the last host
+        segmentation call (reference src/processor.cpp:152-163), as two uint8 arrays of shape (count, 32)"""
+        g = np.zeros((max(n_ground, 1), 32), np.uint8)
+        o = np.zeros((max(n_obstacle, 1), 32), np.uint8)
+        ng, no = C.c_uint32(0), C.c_uint32(0)
+        self.check(self._L.lpx_coloured_clouds(self._h, _vp(g), _vp(o), C.byref(ng), C.byref(no)))
+        assert ng.value == n_ground and no.value == n_obstacle
+        return g[:n_ground], o[:n_obstacle]
+
     def cluster_groups(self, m, n_clusters):
         """offsets[n_clusters + 1], indices: the regrouping of reference src/processor.cpp:180-200 for the
         labels of the last cluster call of this context"""
@@ -180,6 +218,18 @@ class Context:
                                                C.POINTER(C.c_uint32)]
         self.check(self._L.lpx_cluster_groups(self._h, int(m), int(n_clusters), _vp(off), _vp(idx), C.byref(nv)))
         return off, idx[:nv.value].copy()
+
+    def cluster_hulls(self, m, n_clusters, max_points=20):
+        """lpx_cluster_hulls: (hull_offsets[n_clusters + 1], hull_indices, hull_xy) -- counter-clockwise convex
+        hulls of the clusters with fewer than max_points points (reference src/polygon_simplification.cpp:96-115)
+        for the labels of the last cluster call of this context"""
+        off = np.zeros(n_clusters + 1, np.uint32)
+        idx = np.zeros(max(m, 1), np.uint32)
+        xy = np.zeros((max(m, 1), 2), np.float32)
+        nh = C.c_uint32(0)
+        self.check(self._L.lpx_cluster_hulls(self._h, int(m), int(n_clusters), int(max_points), _vp(off), _vp(idx),
+                                             _vp(xy), C.byref(nh)))
+        return off, idx[:nh.value].copy(), xy[:nh.value].copy()
 
     # ---- device-resident entry point (asynchronous on the context stream) ----
     def segment_cluster_device(self, d_pts, stride_bytes, n, seg_cfg, clu_cfg, d_labels, d_ground_idx, d_obstacle_idx,
@@ -322,6 +372,13 @@ class Clusterer:
         labels, self._n_clusters = self._ctx.cluster(a, self.configuration)
         self._m = a.shape[0]
         return labels
+
+    def convex_outlines(self, cloud_in, max_points=20):
+        """findOrderedConcaveOutlines' convex branch (src/polygon_simplification.cpp:96-115): list of (k, 2) xy
+        arrays, one per cluster with fewer than max_points points (counter-clockwise), clusters in label order;
+        larger clusters are skipped (concave branch: out of scope)"""
+        off, idx, xy = self._ctx.cluster_hulls(self._m, self._n_clusters, max_points)
+        return [xy[off[c]:off[c + 1]] for c in range(self._n_clusters) if off[c + 1] > off[c]]
 
     def grouped(self, cloud_in):
         """The regrouping the reference's caller does right after cluster() (src/processor.cpp:180-200):

@@ -149,6 +149,22 @@ static int begin_call(lpx_ctx *ctx, uint32_t frames, uint32_t upitch)
         return lpx_fail(ctx, LPX_ERR_ARG, "%u frames in a call, the context has %u frame slots", frames, ctx->batch);
     ctx->cur_b = frames;
     ctx->upitch = upitch;
+    ctx->in_off[0] = 0;  // PCL records: x, y, z lead the record; the *_fields entry points overwrite this
+    ctx->in_off[1] = 4;
+    ctx->in_off[2] = 8;
+    return LPX_OK;
+}
+
+// PointCloud2 layout of the call being enqueued (after begin_call)
+static int set_fields(lpx_ctx *ctx, size_t point_step, uint32_t off_x, uint32_t off_y, uint32_t off_z)
+{
+    const uint32_t o[3] = {off_x, off_y, off_z};
+    for (int a = 0; a < 3; ++a)
+    {
+        if (point_step < 4 || o[a] > point_step - 4)
+            return lpx_fail(ctx, LPX_ERR_ARG, "field offset %u does not fit a point_step of %zu bytes", o[a], point_step);
+        ctx->in_off[a] = o[a];
+    }
     return LPX_OK;
 }
 
@@ -316,6 +332,8 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
         hipFree(ctx->nb_arena);
     if (ctx->in_aos.p)
         hipFree(ctx->in_aos.p);
+    if (ctx->rec_out.p)
+        hipFree(ctx->rec_out.p);
     if (ctx->dbg_store.p)
         hipFree(ctx->dbg_store.p);
     for (int i = 0; i < ctx->n_pending; ++i)
@@ -359,9 +377,9 @@ extern "C" int lpx_synchronize(lpx_ctx *ctx)
 // ------------------------------------------------------------------------------------------------
 // argument checks
 // ------------------------------------------------------------------------------------------------
-static int check_seg(lpx_ctx *ctx, const lpx_seg_cfg *c, size_t stride)
+static int check_seg(lpx_ctx *ctx, const lpx_seg_cfg *c, size_t stride, bool pcl_records = true)
 {
-    if (!c || stride < 12 || (stride & 3))
+    if (!c || (pcl_records && (stride < 12 || (stride & 3))))
         return lpx_fail(ctx, LPX_ERR_ARG, "stride must be a multiple of 4 and at least 12 bytes");
     if (c->number_of_planar_partitions == 0 || c->number_of_planar_partitions > LPX_MAX_PARTITIONS ||
         c->number_of_iterations > LPX_MAX_ITERATIONS)
@@ -370,9 +388,9 @@ static int check_seg(lpx_ctx *ctx, const lpx_seg_cfg *c, size_t stride)
     return LPX_OK;
 }
 
-static int check_clu(lpx_ctx *ctx, const lpx_clu_cfg *c, size_t stride)
+static int check_clu(lpx_ctx *ctx, const lpx_clu_cfg *c, size_t stride, bool pcl_records = true)
 {
-    if (!c || stride < 12 || (stride & 3))
+    if (!c || (pcl_records && (stride < 12 || (stride & 3))))
         return lpx_fail(ctx, LPX_ERR_ARG, "stride must be a multiple of 4 and at least 12 bytes");
     if (!(c->distance_squared >= 0.0f) || !(c->distance_squared < 3.0e38f))
         return lpx_fail(ctx, LPX_ERR_ARG, "distance_squared must be finite and >= 0");
@@ -406,6 +424,7 @@ extern "C" int lpx_segment_device(lpx_ctx *ctx, const void *d_pts, size_t stride
     LPX_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)))
         return rc;
+    ctx->last_n = n;
     if ((rc = lpx_run_segment(ctx, d_pts, stride, &n, cfg, d_labels, d_gidx, d_oidx, d_planes)))
         return rc;
     return d_counts ? lpx_write_counts(ctx, d_counts) : LPX_OK;
@@ -427,24 +446,49 @@ extern "C" int lpx_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride
     return lpx_run_cluster(ctx, m, cfg, d_labels, d_counts, false);
 }
 
-extern "C" int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n,
-                                          const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, uint32_t *d_labels,
-                                          uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes, int32_t *d_clabels,
-                                          uint32_t *d_counts)
+// offs: byte offsets of x, y, z in a record (PointCloud2 fields), or null for PCL records (0, 4, 8)
+static int segment_cluster_device_impl(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32_t *offs, uint32_t n,
+                                       const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, uint32_t *d_labels,
+                                       uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes, int32_t *d_clabels,
+                                       uint32_t *d_counts)
 {
     if (!ctx)
         return LPX_ERR_ARG;
-    int rc = check_seg(ctx, seg_cfg, stride);
-    if (rc || (rc = check_clu(ctx, clu_cfg, stride)))
+    int rc = check_seg(ctx, seg_cfg, stride, !offs);
+    if (rc || (rc = check_clu(ctx, clu_cfg, stride, !offs)))
         return rc;
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)))
+    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)) ||
+        (offs && (rc = set_fields(ctx, stride, offs[0], offs[1], offs[2]))))
         return rc;
+    ctx->last_n = n;
     if ((rc = lpx_run_segment(ctx, d_pts, stride, &n, seg_cfg, d_labels, d_gidx, d_oidx, d_planes)))
         return rc;
     if (!d_clabels)
         d_clabels = (int32_t *)ctx->d_clabels.p;
     return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts, false);  // n bounds the obstacle count
+}
+
+extern "C" int lpx_segment_cluster_device(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t n,
+                                          const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, uint32_t *d_labels,
+                                          uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes, int32_t *d_clabels,
+                                          uint32_t *d_counts)
+{
+    return segment_cluster_device_impl(ctx, d_pts, stride, nullptr, n, seg_cfg, clu_cfg, d_labels, d_gidx, d_oidx,
+                                       d_planes, d_clabels, d_counts);
+}
+
+// The data[] buffer of a sensor_msgs/PointCloud2 message ingested as it is: point_step and the offsets of its
+// float32 x / y / z fields replace the host-side decode of reference src/conversions.cpp:62-85.
+extern "C" int lpx_segment_cluster_fields_device(lpx_ctx *ctx, const void *d_data, uint32_t point_step, uint32_t off_x,
+                                                 uint32_t off_y, uint32_t off_z, uint32_t n, const lpx_seg_cfg *seg_cfg,
+                                                 const lpx_clu_cfg *clu_cfg, uint32_t *d_labels, uint32_t *d_gidx,
+                                                 uint32_t *d_oidx, float *d_planes, int32_t *d_clabels,
+                                                 uint32_t *d_counts)
+{
+    const uint32_t offs[3] = {off_x, off_y, off_z};
+    return segment_cluster_device_impl(ctx, d_data, point_step, offs, n, seg_cfg, clu_cfg, d_labels, d_gidx, d_oidx,
+                                       d_planes, d_clabels, d_counts);
 }
 
 // B frames per launch chain: every kernel covers all frames (gridDim.z), so the launch count of the chain
@@ -544,9 +588,9 @@ static int download_segment(lpx_ctx *ctx, uint32_t n, uint32_t P, uint32_t *labe
     return LPX_OK;
 }
 
-extern "C" int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
-                           uint32_t *labels, uint32_t *gidx, uint32_t *n_ground, uint32_t *oidx, uint32_t *n_obstacle,
-                           float *planes)
+static int segment_impl(lpx_ctx *ctx, const void *pts, size_t stride, const uint32_t *offs, uint32_t n,
+                        const lpx_seg_cfg *cfg, uint32_t *labels, uint32_t *gidx, uint32_t *n_ground, uint32_t *oidx,
+                        uint32_t *n_obstacle, float *planes)
 {
     if (!ctx)
         return LPX_ERR_ARG;
@@ -554,20 +598,37 @@ extern "C" int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
         *n_ground = 0;
     if (n_obstacle)
         *n_obstacle = 0;
-    int rc = check_seg(ctx, cfg, stride);
+    int rc = check_seg(ctx, cfg, stride, !offs);
     if (rc)
         return rc;
     if (n && !pts)
         return lpx_fail(ctx, LPX_ERR_ARG, "null points");
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)) || (rc = upload(ctx, pts, stride, n)))
+    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)) ||
+        (offs && (rc = set_fields(ctx, stride, offs[0], offs[1], offs[2]))) || (rc = upload(ctx, pts, stride, n)))
         return rc;
+    ctx->last_n = n;
     if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, &n, cfg, (uint32_t *)ctx->d_labels.p,
                               (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
         return rc;
     FrameState fs;
     return download_segment(ctx, n, cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle, planes,
                             &fs);
+}
+
+extern "C" int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
+                           uint32_t *labels, uint32_t *gidx, uint32_t *n_ground, uint32_t *oidx, uint32_t *n_obstacle,
+                           float *planes)
+{
+    return segment_impl(ctx, pts, stride, nullptr, n, cfg, labels, gidx, n_ground, oidx, n_obstacle, planes);
+}
+
+extern "C" int lpx_segment_fields(lpx_ctx *ctx, const void *data, uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                                  uint32_t off_z, uint32_t n, const lpx_seg_cfg *cfg, uint32_t *labels, uint32_t *gidx,
+                                  uint32_t *n_ground, uint32_t *oidx, uint32_t *n_obstacle, float *planes)
+{
+    const uint32_t offs[3] = {off_x, off_y, off_z};
+    return segment_impl(ctx, data, point_step, offs, n, cfg, labels, gidx, n_ground, oidx, n_obstacle, planes);
 }
 
 // Runs the clustering of the obstacle SoA resident in ctx (count on the device, at most m_bound points) and
@@ -640,10 +701,10 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
     return download_clusters(ctx, fs, labels, n_clusters);
 }
 
-extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *seg_cfg,
-                                   const lpx_clu_cfg *clu_cfg, uint32_t *labels, uint32_t *gidx, uint32_t *n_ground,
-                                   uint32_t *oidx, uint32_t *n_obstacle, float *planes, int32_t *cluster_labels,
-                                   uint32_t *n_clusters)
+static int segment_cluster_impl(lpx_ctx *ctx, const void *pts, size_t stride, const uint32_t *offs, uint32_t n,
+                                const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, uint32_t *labels, uint32_t *gidx,
+                                uint32_t *n_ground, uint32_t *oidx, uint32_t *n_obstacle, float *planes,
+                                int32_t *cluster_labels, uint32_t *n_clusters)
 {
     if (!ctx)
         return LPX_ERR_ARG;
@@ -653,14 +714,16 @@ extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride,
         *n_obstacle = 0;
     if (n_clusters)
         *n_clusters = 0;
-    int rc = check_seg(ctx, seg_cfg, stride);
-    if (rc || (rc = check_clu(ctx, clu_cfg, stride)))
+    int rc = check_seg(ctx, seg_cfg, stride, !offs);
+    if (rc || (rc = check_clu(ctx, clu_cfg, stride, !offs)))
         return rc;
     if (n && !pts)
         return lpx_fail(ctx, LPX_ERR_ARG, "null points");
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)) || (rc = upload(ctx, pts, stride, n)))
+    if ((rc = ensure_for(ctx, n)) || (rc = begin_call(ctx, 1, 0)) ||
+        (offs && (rc = set_fields(ctx, stride, offs[0], offs[1], offs[2]))) || (rc = upload(ctx, pts, stride, n)))
         return rc;
+    ctx->last_n = n;
     if ((rc = lpx_run_segment(ctx, ctx->in_aos.p, stride, &n, seg_cfg, (uint32_t *)ctx->d_labels.p,
                               (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
         return rc;
@@ -688,6 +751,92 @@ extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride,
     return download_clusters(ctx, fs, cluster_labels, n_clusters);  // one synchronisation for all copies
 }
 
+extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *seg_cfg,
+                                   const lpx_clu_cfg *clu_cfg, uint32_t *labels, uint32_t *gidx, uint32_t *n_ground,
+                                   uint32_t *oidx, uint32_t *n_obstacle, float *planes, int32_t *cluster_labels,
+                                   uint32_t *n_clusters)
+{
+    return segment_cluster_impl(ctx, pts, stride, nullptr, n, seg_cfg, clu_cfg, labels, gidx, n_ground, oidx, n_obstacle,
+                                planes, cluster_labels, n_clusters);
+}
+
+extern "C" int lpx_segment_cluster_fields(lpx_ctx *ctx, const void *data, uint32_t point_step, uint32_t off_x,
+                                          uint32_t off_y, uint32_t off_z, uint32_t n, const lpx_seg_cfg *seg_cfg,
+                                          const lpx_clu_cfg *clu_cfg, uint32_t *labels, uint32_t *gidx,
+                                          uint32_t *n_ground, uint32_t *oidx, uint32_t *n_obstacle, float *planes,
+                                          int32_t *cluster_labels, uint32_t *n_clusters)
+{
+    const uint32_t offs[3] = {off_x, off_y, off_z};
+    return segment_cluster_impl(ctx, data, point_step, offs, n, seg_cfg, clu_cfg, labels, gidx, n_ground, oidx,
+                                n_obstacle, planes, cluster_labels, n_clusters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// egress: the PointXYZRGBL clouds of reference src/processor.cpp:152-163 / src/conversions.cpp:164-193
+// ------------------------------------------------------------------------------------------------
+extern "C" int lpx_coloured_clouds_device(lpx_ctx *ctx, const uint32_t *d_gidx, const uint32_t *d_oidx,
+                                          void *d_ground_records, void *d_obstacle_records)
+{
+    if (!ctx || !d_gidx || !d_oidx || !d_ground_records || !d_obstacle_records)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->cur_b = 1;
+    ctx->upitch = 0;
+    return lpx_run_colour(ctx, ctx->last_n, d_gidx, d_oidx, d_ground_records, d_obstacle_records);
+}
+
+extern "C" int lpx_coloured_clouds_batch_device(lpx_ctx *ctx, uint32_t n_frames, uint32_t frame_pitch,
+                                                const uint32_t *d_gidx, const uint32_t *d_oidx, void *d_ground_records,
+                                                void *d_obstacle_records)
+{
+    if (!ctx || !d_gidx || !d_oidx || !d_ground_records || !d_obstacle_records)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_frames == 0 || n_frames > ctx->batch)
+        return lpx_fail(ctx, LPX_ERR_ARG, "%u frames, the context has %u frame slots", n_frames, ctx->batch);
+    ctx->cur_b = n_frames;
+    ctx->upitch = frame_pitch;
+    return lpx_run_colour(ctx, frame_pitch, d_gidx, d_oidx, d_ground_records, d_obstacle_records);
+}
+
+// host form: records of the LAST lpx_segment* / lpx_segment_cluster* HOST call of this context
+extern "C" int lpx_coloured_clouds(lpx_ctx *ctx, void *ground_records, void *obstacle_records, uint32_t *n_ground,
+                                   uint32_t *n_obstacle)
+{
+    if (!ctx || !ground_records || !obstacle_records)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->last_n;
+    if (n_ground)
+        *n_ground = 0;
+    if (n_obstacle)
+        *n_obstacle = 0;
+    if (n == 0)
+        return LPX_OK;
+    int rc = lpx_ensure(ctx, ctx->rec_out, 64 * (size_t)n + 64);
+    if (rc)
+        return rc;
+    char *grec = (char *)ctx->rec_out.p, *orec = grec + 32 * (size_t)n;
+    ctx->cur_b = 1;
+    ctx->upitch = 0;
+    if ((rc = lpx_run_colour(ctx, n, (const uint32_t *)ctx->d_gidx.p, (const uint32_t *)ctx->d_oidx.p, grec, orec)))
+        return rc;
+    FrameState fs;
+    if ((rc = read_frame(ctx, &fs)))
+        return rc;
+    if (fs.n_ground)
+        LPX_HIP(ctx, hipMemcpyAsync(ground_records, grec, 32 * (size_t)fs.n_ground, hipMemcpyDeviceToHost, ctx->stream));
+    if (fs.n_obstacle)
+        LPX_HIP(ctx, hipMemcpyAsync(obstacle_records, orec, 32 * (size_t)fs.n_obstacle, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_ground)
+        *n_ground = fs.n_ground;
+    if (n_obstacle)
+        *n_obstacle = fs.n_obstacle;
+    return LPX_OK;
+}
+
 // Cluster regrouping (reference src/processor.cpp:180-200) of the labels of the LAST clustering call on
 // this context, which are still resident on the device.
 extern "C" int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t *offsets, uint32_t *indices,
@@ -705,21 +854,82 @@ extern "C" int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters,
         return LPX_OK;
     }
     LPX_HIP(ctx, hipSetDevice(ctx->device));
+    // offsets / indices go to kd-build scratch (free once the clustering is done): the index lists of the
+    // segmentation stay resident for lpx_coloured_clouds
+    uint32_t *d_off = (uint32_t *)ctx->lpos.p, *d_ind = (uint32_t *)ctx->rpos.p;
     int rc = begin_call(ctx, 1, 0);
-    if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, (uint32_t *)ctx->d_gidx.p,
-                                   (uint32_t *)ctx->d_oidx.p)))
+    if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)))
         return rc;
-    LPX_HIP(ctx, hipMemcpyAsync(offsets, ctx->d_gidx.p, sizeof(uint32_t) * ((size_t)n_clusters + 1),
+    LPX_HIP(ctx, hipMemcpyAsync(offsets, d_off, sizeof(uint32_t) * ((size_t)n_clusters + 1),
                                 hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t nv = offsets[n_clusters];
     if (nv > m)
         return lpx_fail(ctx, LPX_ERR_INTERNAL, "group offsets out of range");
     if (indices && nv)
-        LPX_HIP(ctx, hipMemcpy(indices, ctx->d_oidx.p, sizeof(uint32_t) * nv, hipMemcpyDeviceToHost));
+        LPX_HIP(ctx, hipMemcpy(indices, d_ind, sizeof(uint32_t) * nv, hipMemcpyDeviceToHost));
     if (n_valid)
         *n_valid = nv;
     return LPX_OK;
+}
+
+// N3: convex hulls (Andrew monotone chain, counter-clockwise) of the valid clusters with fewer than max_points
+// points -- the convex branch of reference src/polygon_simplification.cpp:96-115 (max_points = 20) -- for the
+// labels of the LAST clustering call of this context.
+extern "C" int lpx_cluster_hulls(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t max_points,
+                                 uint32_t *hull_offsets, uint32_t *hull_indices, float *hull_xy,
+                                 uint32_t *n_hull_points)
+{
+    if (!ctx || !hull_offsets)
+        return LPX_ERR_ARG;
+    if (n_hull_points)
+        *n_hull_points = 0;
+    for (uint32_t c = 0; c <= n_clusters; ++c)
+        hull_offsets[c] = 0;
+    if (m == 0 || n_clusters == 0)
+        return LPX_OK;
+    if (m > ctx->cap_n || n_clusters > m)
+        return lpx_fail(ctx, LPX_ERR_ARG, "%u points / %u clusters do not match the last clustering call", m, n_clusters);
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t *d_off = (uint32_t *)ctx->lpos.p, *d_ind = (uint32_t *)ctx->rpos.p;
+    uint32_t *d_hoff = (uint32_t *)ctx->nb_off.p, *d_hidx = (uint32_t *)ctx->nb_len.p;
+    float *d_hxy = (float *)ctx->key64_a.p;
+    int rc = begin_call(ctx, 1, 0);
+    if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)) ||
+        (rc = lpx_run_hulls(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind, max_points, d_hoff, d_hidx, d_hxy)))
+        return rc;
+    LPX_HIP(ctx, hipMemcpyAsync(hull_offsets, d_hoff, sizeof(uint32_t) * ((size_t)n_clusters + 1), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t total = hull_offsets[n_clusters];
+    if (total > m)
+        return lpx_fail(ctx, LPX_ERR_INTERNAL, "hull offsets out of range");
+    if (hull_indices && total)
+        LPX_HIP(ctx, hipMemcpyAsync(hull_indices, d_hidx, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, ctx->stream));
+    if (hull_xy && total)
+        LPX_HIP(ctx, hipMemcpyAsync(hull_xy, d_hxy, sizeof(float) * 2 * total, hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_hull_points)
+        *n_hull_points = total;
+    return LPX_OK;
+}
+
+// device form: d_offsets / d_indices are the CSR lpx_cluster_groups_device wrote for d_labels (m points, the cloud
+// of the last clustering call of this context); d_hull_offsets needs n_clusters + 1 (at most m + 1) entries,
+// d_hull_indices m, d_hull_xy 2 * m floats.
+extern "C" int lpx_cluster_hulls_device(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, const uint32_t *d_offsets,
+                                        const uint32_t *d_indices, uint32_t max_points, uint32_t *d_hull_offsets,
+                                        uint32_t *d_hull_indices, float *d_hull_xy)
+{
+    if (!ctx || !d_labels || !d_offsets || !d_indices || !d_hull_offsets || !d_hull_indices || !d_hull_xy)
+        return LPX_ERR_ARG;
+    if (m > ctx->cap_n)
+        return lpx_fail(ctx, LPX_ERR_ARG, "%u points do not match the last clustering call", m);
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = begin_call(ctx, 1, 0);
+    if (rc)
+        return rc;
+    return lpx_run_hulls(ctx, d_labels, m, d_offsets, d_indices, max_points, d_hull_offsets, d_hull_indices, d_hull_xy);
 }
 
 extern "C" int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets,

@@ -545,6 +545,217 @@ __global__ void group_offsets_kernel(const uint32_t *__restrict__ skey, const ui
         offsets[p ? prev + 1 : 0] = p;  // first rejected point: end of the last valid cluster
 }
 
+// ------------------------------------------------------------------------------------------------
+// N3: per-cluster 2-D convex hull -- the convex branch of findOrderedConcaveOutlines (reference
+// src/polygon_simplification.cpp:96-115: clusters with fewer than 20 points) and findOrderedConvexOutlines
+// (:32-80).  The reference delegates to geom::constructConvexHull(ANDREW_MONOTONE_CHAIN, COUNTERCLOCKWISE) of
+// its Convex-Hull submodule, which is not vendored; the published algorithm is restated with the conventions
+// stated in DESIGN.md (points sorted by (x, y, index), duplicates skipped, collinear points are
+// not vertices, float32 cross product without contraction, CCW from the lowest (x, y) point).  The concave
+// branch (:116-131, Concave-Hull submodule) is out of scope: larger clusters get an empty hull.
+//
+// Input: the CSR of lpx_run_groups (clusters in label order).  Three stable radix sorts of the CSR's point list
+// -- by y key, by x key, by label -- leave every cluster's points in (x, y, index) order inside the cluster's
+// own CSR range; then one LANE per cluster runs the monotone chain with its stack in global scratch (the two
+// top entries stay in registers, so only a pop loads), and a second kernel packs the hulls.
+// ------------------------------------------------------------------------------------------------
+__global__ void hull_key_kernel(const uint32_t *__restrict__ vals, const float *__restrict__ coord,
+                                const int32_t *__restrict__ labels, const uint32_t *__restrict__ d_n,
+                                uint32_t *__restrict__ key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *d_n)
+        return;
+    const uint32_t v = vals[i];
+    key[i] = labels ? (uint32_t)labels[v] : lpx_float_key(coord[v]);  // lpx_float_key maps -0 to +0
+}
+
+__device__ __forceinline__ float hull_cross(float ax, float ay, float bx, float by, float cx, float cy)
+{
+    const float l = (bx - ax) * (cy - ay);
+    const float r = (by - ay) * (cx - ax);
+    return l - r;
+}
+
+__global__ void hull_chain_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ sorted,
+                                  const float *__restrict__ OX, const float *__restrict__ OY,
+                                  const FrameState *__restrict__ frame, uint32_t max_points,
+                                  uint32_t *__restrict__ st_idx, float2 *__restrict__ st_xy,
+                                  uint32_t *__restrict__ hull_len)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nc = frame->n_clusters;
+    if (c > nc)
+        return;
+    if (c == nc)
+    {
+        hull_len[c] = 0;  // sentinel: the exclusive scan leaves the total here
+        return;
+    }
+    const uint32_t b = off[c], n = off[c + 1] - b;
+    if (n == 0 || n >= max_points)
+    {
+        hull_len[c] = 0;
+        return;
+    }
+    const uint32_t *sp = sorted + b;
+    // the stack holds the lower hull plus the upper chain of the points seen so far from the end: at most 2 n
+    // entries (a lower-hull vertex can sit on the upper hull of a suffix), so cluster c owns [2 b, 2 b + 2 n)
+    uint32_t *S = st_idx + 2 * (size_t)b;
+    float2 *SXY = st_xy + 2 * (size_t)b;
+    // -0 and +0 are one value (the sort keys say so too): compare and compute on x + 0
+#define HP_LOAD(i, id, x, y)                                                                                          \
+    const uint32_t id = sp[i];                                                                                        \
+    const float x = OX[id] + 0.0f, y = OY[id] + 0.0f;
+    // distinct points (duplicates are consecutive in sorted order)
+    uint32_t u = 0;
+    {
+        float px = 0.0f, py = 0.0f;
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            HP_LOAD(i, id, x, y)
+            if (i == 0 || x != px || y != py)
+            {
+                if (u < 2)
+                {
+                    S[u] = id;
+                    SXY[u] = make_float2(x, y);
+                }
+                ++u;
+            }
+            px = x;
+            py = y;
+        }
+    }
+    if (u <= 2)
+    {
+        hull_len[c] = u;
+        return;
+    }
+    uint32_t k = 0;
+    float ax = 0.0f, ay = 0.0f, bx = 0.0f, by = 0.0f;  // S[k-2], S[k-1]
+#define HP_POP_WHILE(limit)                                                                                           \
+    while (k >= (limit) && hull_cross(ax, ay, bx, by, x, y) <= 0.0f)                                                  \
+    {                                                                                                                 \
+        --k;                                                                                                          \
+        bx = ax;                                                                                                      \
+        by = ay;                                                                                                      \
+        if (k >= 2)                                                                                                   \
+        {                                                                                                             \
+            const float2 t = SXY[k - 2];                                                                              \
+            ax = t.x;                                                                                                 \
+            ay = t.y;                                                                                                 \
+        }                                                                                                             \
+    }
+#define HP_PUSH()                                                                                                     \
+    S[k] = id;                                                                                                        \
+    SXY[k] = make_float2(x, y);                                                                                       \
+    ++k;                                                                                                              \
+    ax = bx;                                                                                                          \
+    ay = by;                                                                                                          \
+    bx = x;                                                                                                           \
+    by = y;
+    {
+        float px = 0.0f, py = 0.0f;
+        for (uint32_t i = 0; i < n; ++i)  // lower hull
+        {
+            HP_LOAD(i, id, x, y)
+            const bool dup = i > 0 && x == px && y == py;
+            px = x;
+            py = y;
+            if (dup)
+                continue;
+            HP_POP_WHILE(2u)
+            HP_PUSH()
+        }
+    }
+    const uint32_t lower = k + 1;
+    {
+        bool skipped_last = false;
+        for (uint32_t i = n; i-- > 0;)  // upper hull
+        {
+            HP_LOAD(i, id, x, y)
+            if (i > 0)
+            {
+                const uint32_t pid = sp[i - 1];
+                if (x == OX[pid] + 0.0f && y == OY[pid] + 0.0f)
+                    continue;  // not the first of its run of duplicates
+            }
+            if (!skipped_last)
+            {
+                skipped_last = true;  // the last distinct point is the top of the stack already
+                continue;
+            }
+            HP_POP_WHILE(lower)
+            if (i == 0)
+                break;  // the first point would close the polygon: it is not stored twice
+            HP_PUSH()
+        }
+    }
+    hull_len[c] = k;
+#undef HP_LOAD
+#undef HP_POP_WHILE
+#undef HP_PUSH
+}
+
+__global__ void hull_count_kernel(const uint32_t *__restrict__ off, const FrameState *__restrict__ frame,
+                                  uint32_t *__restrict__ d_nv)
+{
+    if (threadIdx.x == 0)
+        *d_nv = off[frame->n_clusters];  // points in valid clusters (0 clusters: offsets[0] = 0)
+}
+
+// exclusive scan of hull_len[0 .. n_clusters] (the sentinel entry receives the total) by one workgroup
+__global__ __launch_bounds__(1024) void hull_scan_kernel(const uint32_t *__restrict__ len,
+                                                         const FrameState *__restrict__ frame,
+                                                         uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t n = frame->n_clusters + 1;
+    const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
+    if (tid == 0)
+        s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024)
+    {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n ? len[i] : 0u;
+        const uint32_t incl = lpx_wave_incl_scan_u32(v);
+        if (lane == WAVE - 1)
+            s_wave[w] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (uint32_t k = 0; k < w; ++k)
+            before += s_wave[k];
+        if (i < n)
+            out[i] = before + incl - v;
+        __syncthreads();
+        if (tid == 1023)
+            s_carry = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ void hull_pack_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ slabel,
+                                 const uint32_t *__restrict__ d_n, const uint32_t *__restrict__ st_idx,
+                                 const float2 *__restrict__ st_xy, const uint32_t *__restrict__ hull_len,
+                                 const uint32_t *__restrict__ hull_off, uint32_t *__restrict__ out_idx,
+                                 float2 *__restrict__ out_xy)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= *d_n)
+        return;
+    const uint32_t c = slabel[p];  // position p of the sorted point list belongs to cluster c
+    const uint32_t j = p - off[c];
+    if (j < hull_len[c])
+    {
+        const size_t q = 2 * (size_t)off[c] + j;  // stack entry j of cluster c
+        out_idx[hull_off[c] + j] = st_idx[q];
+        out_xy[hull_off[c] + j] = st_xy[q];
+    }
+}
+
 static uint32_t bits_for_count(uint32_t n)  // bits to hold values 0..n-1
 {
     uint32_t b = 1;
@@ -629,6 +840,58 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         hipLaunchKernelGGL(relabel_kernel, grd, blk, 0, st, frame, (const int32_t *)ctx->seed_of.p, valid, dense,
                            d_labels, ctx->cap_nb, (const uint64_t *)total, d_counts, fv);
     }
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+// Hulls of the clusters (labels d_labels over the m points resident in OX / OY) with fewer than max_points points.
+// d_offsets / d_indices: the CSR of lpx_run_groups for the same labels (already computed).  Results:
+// d_hull_off[n_clusters + 1], d_hull_idx / d_hull_xy[<= m].
+int lpx_run_hulls(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, const uint32_t *d_offsets,
+                  const uint32_t *d_indices, uint32_t max_points, uint32_t *d_hull_off, uint32_t *d_hull_idx,
+                  float *d_hull_xy)
+{
+    if (m == 0)
+    {
+        LPX_HIP(ctx, hipMemsetAsync(d_hull_off, 0, sizeof(uint32_t), ctx->stream));
+        return LPX_OK;
+    }
+    StageTimer tm(ctx, ST_GROUPS);
+    hipStream_t st = ctx->stream;
+    const FrameState *frame = (const FrameState *)ctx->frame.p;
+    const dim3 blk(256), grd((m + 255) / 256);
+    uint32_t *ka = (uint32_t *)ctx->key_a.p, *kb = (uint32_t *)ctx->key_b.p;
+    uint32_t *va = (uint32_t *)ctx->val_a.p, *vb = (uint32_t *)ctx->val_b.p;
+    // number of points in valid clusters = offsets[n_clusters]; as a device count for the sorts it is read from a
+    // one-word copy (n_clusters is only known on the device here)
+    uint32_t *d_nv = (uint32_t *)((char *)ctx->d_counts.p + 32);
+    hipLaunchKernelGGL(hull_count_kernel, dim3(1), dim3(64), 0, st, d_offsets, frame, d_nv);
+    LPX_HIP(ctx, hipMemcpyAsync(va, d_indices, sizeof(uint32_t) * m, hipMemcpyDeviceToDevice, st));
+    const float *coords[2] = {(const float *)ctx->OY.p, (const float *)ctx->OX.p};
+    uint32_t *ko = ka, *vo = va;
+    int rc;
+    for (int pass = 0; pass < 3; ++pass)
+    {
+        uint32_t *kin = (vo == va) ? ka : kb;  // keys travel with the buffer pair the values are in
+        hipLaunchKernelGGL(hull_key_kernel, grd, blk, 0, st, (const uint32_t *)vo, pass < 2 ? coords[pass] : nullptr,
+                           pass == 2 ? d_labels : (const int32_t *)nullptr, (const uint32_t *)d_nv, kin);
+        const uint32_t bits = pass == 2 ? bits_for_count(m + 1) : 32;
+        if (vo == va)
+            rc = lpx_sort_pairs(ctx, ka, kb, va, vb, m, d_nv, bits, &ko, &vo);
+        else
+            rc = lpx_sort_pairs(ctx, kb, ka, vb, va, m, d_nv, bits, &ko, &vo);
+        if (rc)
+            return rc;
+    }
+    // scratch that is free once the clustering is done: 2 stack words and 2 float2 per point, one length per cluster
+    uint32_t *st_idx = (uint32_t *)ctx->key64_b.p, *hull_len = (uint32_t *)ctx->cc_hi.p;
+    float2 *st_xy = (float2 *)ctx->nodes_pre.p;
+    hipLaunchKernelGGL(hull_chain_kernel, dim3((m + 1 + 63) / 64), dim3(64), 0, st, d_offsets, (const uint32_t *)vo,
+                       (const float *)ctx->OX.p, (const float *)ctx->OY.p, frame, max_points, st_idx, st_xy, hull_len);
+    hipLaunchKernelGGL(hull_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)hull_len, frame, d_hull_off);
+    hipLaunchKernelGGL(hull_pack_kernel, grd, blk, 0, st, d_offsets, (const uint32_t *)ko, (const uint32_t *)d_nv,
+                       (const uint32_t *)st_idx, (const float2 *)st_xy, (const uint32_t *)hull_len,
+                       (const uint32_t *)d_hull_off, d_hull_idx, (float2 *)d_hull_xy);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

@@ -107,12 +107,15 @@ struct lpx_ctx
     uint32_t rs_per_point = 512;
     uint32_t batch = 1;        // frame slots
     uint32_t cur_b = 1;        // frames of the call being enqueued (gridDim.z)
+    uint32_t in_off[3] = {0, 4, 8};  // byte offsets of x, y, z inside a record of the call being enqueued
     uint32_t upitch = 0;       // pitch of the caller arrays of that call
     void *arena = nullptr, *nb_arena = nullptr;
     size_t fstride = 0, nb_fstride = 0;
 
     // ---- segmentation buffers (cap_n) ----
     Buf in_aos;                // staging for host input
+    Buf rec_out;               // staging for the coloured-cloud records handed to the host
+    uint32_t last_n = 0;       // points of the last single-frame segmentation (bounds n_ground + n_obstacle)
     Buf X, Y, Z;               // original order SoA
     Buf key_a, key_b;          // u32 keys ping-pong
     Buf val_a, val_b;          // u32 values ping-pong
@@ -216,6 +219,9 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
 // kd_ready: the tree of a previous attempt on the same cloud is kept
 int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_t *d_labels, uint32_t *d_counts,
                     bool kd_ready);
+// PointXYZRGBL records of the ground / obstacle clouds of the frames last segmented (X/Y/Z still resident)
+int lpx_run_colour(lpx_ctx *ctx, uint32_t n_max, const uint32_t *d_gidx, const uint32_t *d_oidx, void *d_grec,
+                   void *d_orec);
 // AoS (device) -> ctx->OX/OY/OZ, sets frame->n_obstacle = m
 int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_t m);
 // resets the FrameState of every slot of the call and stores the per-frame input sizes
@@ -225,6 +231,11 @@ int lpx_write_counts(lpx_ctx *ctx, uint32_t *d_counts);
 
 // CSR of the valid clusters from d_labels (m entries): d_offsets[n_clusters + 1], d_indices[n_valid]
 int lpx_run_groups(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets, uint32_t *d_indices);
+
+// N3: convex hulls of the small clusters from that CSR (results: hull offsets / point indices / xy)
+int lpx_run_hulls(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, const uint32_t *d_offsets,
+                  const uint32_t *d_indices, uint32_t max_points, uint32_t *d_hull_off, uint32_t *d_hull_idx,
+                  float *d_hull_xy);
 
 int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max);
 // thr_f: absorb threshold of the clustering (largest float <= (1-q)^2 d^2), stored as bit 31 of every list

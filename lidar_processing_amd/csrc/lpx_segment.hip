@@ -92,7 +92,26 @@ __global__ void counts_kernel(const FrameState *frame, uint32_t *counts, size_t 
 // ------------------------------------------------------------------------------------------------
 // K0 ingest: strided AoS -> SoA, x keys, iota; range check
 // ------------------------------------------------------------------------------------------------
-__global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, float *__restrict__ X,
+// Record layout: float32 x, y, z at byte offsets off.x, off.y, off.z of every `stride`-byte record -- a PCL point
+// array (offsets 0, 4, 8; 16- or 32-byte records) or the data[] buffer of a sensor_msgs/PointCloud2 message with
+// its point_step and field offsets (what the reference decodes on the host at src/conversions.cpp:62-85).
+// ALIGNED: base, stride and offsets are multiples of 4 (every PCL type, every sane message); otherwise bytes.
+struct XyzOff
+{
+    uint32_t x, y, z;
+};
+
+template <bool ALIGNED>
+__device__ __forceinline__ float ld_f32(const char *p)
+{
+    if (ALIGNED)
+        return *(const float *)p;
+    const unsigned char *b = (const unsigned char *)p;
+    return __uint_as_float((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24));
+}
+
+template <bool ALIGNED>
+__global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOff off, float *__restrict__ X,
                               float *__restrict__ Y, float *__restrict__ Z, uint32_t *__restrict__ key,
                               uint32_t *__restrict__ val, FrameState *__restrict__ frame,
                               float4 *__restrict__ nodes, FV fv)
@@ -108,8 +127,8 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, float
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= frame->n_in)
         return;
-    const float *p = (const float *)(pts + (size_t)i * stride);
-    const float x = p[0], y = p[1], z = p[2];
+    const char *p = pts + (size_t)i * stride;
+    const float x = ld_f32<ALIGNED>(p + off.x), y = ld_f32<ALIGNED>(p + off.y), z = ld_f32<ALIGNED>(p + off.z);
     X[i] = x;
     Y[i] = y;
     Z[i] = z;
@@ -1398,6 +1417,39 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// egress: the two clouds Processor::process builds right after segment() (reference src/processor.cpp:152-163:
+// ground -> PointXYZRGBL(x, y, z, 220, 220, 220, label 0), obstacle -> PointXYZRGBL(x, y, z, 0, 255, 0, label 1))
+// and then memcpy's into the data[] of the two published PointCloud2 messages (src/conversions.cpp:164-193).
+// Record = 32 bytes as pcl::PointXYZRGBL lays them out (PCL 1.12 point_types: float x, y, z, 1.0f | b, g, r, a = 255
+// | uint32 label | 8 bytes of padding, written as zero).  One thread per record, two 16-byte stores.
+// ------------------------------------------------------------------------------------------------
+__global__ void colour_kernel(const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+                              const uint32_t *__restrict__ gidx, const uint32_t *__restrict__ oidx,
+                              const FrameState *__restrict__ frame, float4 *__restrict__ grec,
+                              float4 *__restrict__ orec, FV fv)
+{
+    X = lpx_slot(X, fv.fs);
+    Y = lpx_slot(Y, fv.fs);
+    Z = lpx_slot(Z, fv.fs);
+    frame = lpx_slot(frame, fv.fs);
+    gidx = lpx_user(gidx, fv.upitch);
+    oidx = lpx_user(oidx, fv.upitch);
+    grec = lpx_user(grec, 2u * fv.upitch);
+    orec = lpx_user(orec, 2u * fv.upitch);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ng = frame->n_ground, no = frame->n_obstacle;
+    if (i >= ng + no)
+        return;
+    const bool g = i < ng;
+    const uint32_t j = g ? i : i - ng;
+    const uint32_t k = g ? gidx[j] : oidx[j];
+    float4 *dst = (g ? grec : orec) + 2 * (size_t)j;
+    dst[0] = make_float4(X[k], Y[k], Z[k], 1.0f);
+    const uint32_t rgba = g ? 0xffdcdcdcu : 0xff00ff00u;  // a r g b from the top byte down: bytes b, g, r, a in memory
+    dst[1] = make_float4(__uint_as_float(rgba), __uint_as_float(g ? 0u : 1u), 0.0f, 0.0f);
+}
+
 __global__ void dbg_all_seed_kernel(SegState *st, long long *acc, uint32_t *ticket)
 {
     if (threadIdx.x < LPX_ACC_WORDS)
@@ -1445,6 +1497,31 @@ static uint32_t bits_for(uint32_t v)  // number of bits needed to represent valu
     return b ? b : 1;
 }
 
+static void launch_ingest(lpx_ctx *ctx, dim3 grid, const void *d_pts, size_t stride, float *X, float *Y, float *Z,
+                          uint32_t *key, uint32_t *val, FrameState *frame, float4 *nodes)
+{
+    const XyzOff off = {ctx->in_off[0], ctx->in_off[1], ctx->in_off[2]};
+    const bool aligned = (((uintptr_t)d_pts | stride | off.x | off.y | off.z) & 3u) == 0;
+    if (aligned)
+        hipLaunchKernelGGL(ingest_kernel<true>, grid, dim3(256), 0, ctx->stream, (const char *)d_pts, stride, off, X, Y,
+                           Z, key, val, frame, nodes, lpx_fv(ctx));
+    else
+        hipLaunchKernelGGL(ingest_kernel<false>, grid, dim3(256), 0, ctx->stream, (const char *)d_pts, stride, off, X, Y,
+                           Z, key, val, frame, nodes, lpx_fv(ctx));
+}
+
+int lpx_run_colour(lpx_ctx *ctx, uint32_t n_max, const uint32_t *d_gidx, const uint32_t *d_oidx, void *d_grec,
+                   void *d_orec)
+{
+    if (n_max == 0)
+        return LPX_OK;
+    hipLaunchKernelGGL(colour_kernel, dim3((n_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream,
+                       (const float *)ctx->X.p, (const float *)ctx->Y.p, (const float *)ctx->Z.p, d_gidx, d_oidx,
+                       (const FrameState *)ctx->frame.p, (float4 *)d_grec, (float4 *)d_orec, lpx_fv(ctx));
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
 int lpx_frame_init(lpx_ctx *ctx, const uint32_t *n_points, bool as_obstacles)
 {
     NArr na;
@@ -1488,9 +1565,7 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
     if (rc)
         return rc;
     if (n)
-        hipLaunchKernelGGL(ingest_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const char *)d_pts,
-                           (size_t)12, XS, YS, ZS, (uint32_t *)nullptr, (uint32_t *)nullptr, frame, (float4 *)nullptr,
-                           fv);
+        launch_ingest(ctx, dim3((n + 255) / 256), d_pts, 12, XS, YS, ZS, nullptr, nullptr, frame, nullptr);
     hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, acc, ticket);
     hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
                        0u, sst, acc, (long long *)ctx->seg_far.p, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr,
@@ -1508,9 +1583,8 @@ int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_
         return rc;
     if (m)
     {
-        hipLaunchKernelGGL(ingest_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, (const char *)d_pts,
-                           stride, (float *)ctx->OX.p, (float *)ctx->OY.p, (float *)ctx->OZ.p, (uint32_t *)nullptr,
-                           (uint32_t *)nullptr, frame, (float4 *)ctx->nodes.p, lpx_fv(ctx));
+        launch_ingest(ctx, dim3((m + 255) / 256), d_pts, stride, (float *)ctx->OX.p, (float *)ctx->OY.p,
+                      (float *)ctx->OZ.p, nullptr, nullptr, frame, (float4 *)ctx->nodes.p);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
@@ -1562,8 +1636,8 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
 
     {
         StageTimer tm(ctx, ST_INGEST);
-        hipLaunchKernelGGL(ingest_kernel, grd, blk, 0, st, (const char *)d_pts, stride, X, Y, Z,
-                           (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->val_a.p, frame, (float4 *)nullptr, fv);
+        launch_ingest(ctx, grd, d_pts, stride, X, Y, Z, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->val_a.p, frame,
+                      nullptr);
     }
     uint32_t *skeys = nullptr, *sidx = nullptr;
     {

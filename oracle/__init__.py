@@ -185,6 +185,44 @@ def jacobi_svd3(mat):
     return v.reshape(3, 3), s
 
 
+def convex_hull(xy):
+    """Andrew monotone chain, CCW, collinear points excluded: indices into xy (restated published algorithm;
+    reference: geom::constructConvexHull of the absent Convex-Hull submodule, src/polygon_simplification.cpp:109-110)"""
+    a = np.ascontiguousarray(np.asarray(xy, dtype=np.float32)[:, :2])
+    out = np.zeros(max(a.shape[0], 1), np.uint32)
+    cnt = C.c_uint32(0)
+    assert lib().orc_convex_hull(_p(a), C.c_uint32(a.shape[0]), _p(out), C.byref(cnt)) == 0
+    return out[:cnt.value].copy()
+
+
+def cluster_hulls(points, labels, n_clusters, max_points=20):
+    """(hull_offsets[n_clusters + 1], hull_indices) of the clusters with fewer than max_points points"""
+    a, stride = _as_points(points)
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    off = np.zeros(n_clusters + 1, np.uint32)
+    idx = np.zeros(max(a.shape[0], 1), np.uint32)
+    assert lib().orc_cluster_hulls(_p(a), C.c_size_t(stride), C.c_uint32(a.shape[0]), _p(lab), C.c_uint32(n_clusters),
+                                   C.c_uint32(max_points), _p(off), _p(idx)) == 0
+    return off, idx[:int(off[n_clusters])].copy()
+
+
+def coloured_records(points, idx, ground):
+    """The recolour copy of reference src/processor.cpp:152-163 restated: cloud_in[idx] as 32-byte pcl::PointXYZRGBL
+    records -- (x, y, z, 220, 220, 220, label 0) for the ground cloud, (x, y, z, 0, 255, 0, label 1) for the
+    obstacle cloud -- i.e. the bytes convertPCLToPointCloud2 memcpy's into the message (src/conversions.cpp:164-193).
+    Layout per PCL 1.12 point_types (PCL is absent from this image; third-party, version unpinned by the
+    reference): float x, y, z, data[3] = 1.0f | uint8 b, g, r, a = 255 | uint32 label | 8 bytes padding (zero)."""
+    a = np.ascontiguousarray(points, dtype=np.float32)
+    idx = np.asarray(idx, dtype=np.int64)
+    rec = np.zeros(idx.shape[0], dtype=np.dtype([("xyz", "<f4", 3), ("w", "<f4"), ("bgra", "u1", 4), ("label", "<u4"),
+                                                 ("pad", "u1", 8)]))
+    rec["xyz"] = a[idx, :3]
+    rec["w"] = 1.0
+    rec["bgra"] = (220, 220, 220, 255) if ground else (0, 255, 0, 255)
+    rec["label"] = 0 if ground else 1
+    return rec.view(np.uint8).reshape(idx.shape[0], 32)
+
+
 # ---- compiled reference (kdtree.hpp / queue.hpp) -------------------------------------------------
 
 def ref_kd_preorder(points):

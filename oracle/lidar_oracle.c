@@ -930,3 +930,142 @@ int orc_cluster(const void *pts, size_t stride, uint32_t m, const orc_clu_cfg *c
 {
     return orc_cluster_stats(pts, stride, m, cfg, labels, n_clusters, NULL, NULL);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* N3: 2-D convex hull of a cluster (the convex branch of findOrderedConcaveOutlines,           */
+/* src/polygon_simplification.cpp:96-115, and findOrderedConvexOutlines :32-80).                */
+/*                                                                                              */
+/* PARITY UNPINNED: the reference calls geom::constructConvexHull(points, ANDREW_MONOTONE_CHAIN, */
+/* COUNTERCLOCKWISE) from the git submodule Convex-Hull (github.com/YevgeniyEngineer/Convex-Hull, */
+/* .gitmodules:1-3), which is NOT vendored in the reference checkout (empty directory, no pinned */
+/* commit available here).  What follows is the published algorithm (A. M. Andrew, "Another      */
+/* efficient algorithm for convex hulls in two dimensions", 1979) with these conventions:        */
+/*   - points (x, y) = first two coordinates as float32 (:104-107), sorted by (x, y, index);     */
+/*   - exact duplicates of the previous sorted point are skipped;                                */
+/*   - lower hull then upper hull, a point is popped while cross(h[-2], h[-1], p) <= 0, so       */
+/*     collinear boundary points are NOT hull vertices; cross is evaluated in float32,           */
+/*     (bx-ax)*(cy-ay) - (by-ay)*(cx-ax), no contraction;                                        */
+/*   - result counter-clockwise starting at the lowest (x, y) point, no repeated closing vertex; */
+/*     one distinct point -> 1 vertex, two -> 2 vertices.                                        */
+/* out_idx receives indices into the input array.                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct
+{
+    float x, y;
+    uint32_t idx;
+} hpt;
+
+static int cmp_hpt(const void *a, const void *b)
+{
+    const hpt *p = (const hpt *)a, *q = (const hpt *)b;
+    if (p->x != q->x)
+        return p->x < q->x ? -1 : 1;
+    if (p->y != q->y)
+        return p->y < q->y ? -1 : 1;
+    return p->idx < q->idx ? -1 : (p->idx > q->idx);
+}
+
+static inline float hcross(const hpt *a, const hpt *b, const hpt *c)
+{
+    const float l = (b->x - a->x) * (c->y - a->y);
+    const float r = (b->y - a->y) * (c->x - a->x);
+    return l - r;
+}
+
+int orc_convex_hull(const float *xy, uint32_t n, uint32_t *out_idx, uint32_t *count)
+{
+    *count = 0;
+    if (n == 0)
+        return ORC_OK;
+    hpt *p = (hpt *)malloc(sizeof(hpt) * n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        p[i].x = xy[2 * (size_t)i] + 0.0f; /* -0 -> +0 so that the order is the value order */
+        p[i].y = xy[2 * (size_t)i + 1] + 0.0f;
+        p[i].idx = i;
+    }
+    qsort(p, n, sizeof(hpt), cmp_hpt);
+    uint32_t u = 0; /* distinct points */
+    for (uint32_t i = 0; i < n; ++i)
+        if (u == 0 || p[i].x != p[u - 1].x || p[i].y != p[u - 1].y)
+            p[u++] = p[i];
+    if (u <= 2)
+    {
+        for (uint32_t i = 0; i < u; ++i)
+            out_idx[i] = p[i].idx;
+        *count = u;
+        free(p);
+        return ORC_OK;
+    }
+    hpt *h = (hpt *)malloc(sizeof(hpt) * 2 * (size_t)u);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < u; ++i) /* lower hull */
+    {
+        while (k >= 2 && hcross(&h[k - 2], &h[k - 1], &p[i]) <= 0.0f)
+            --k;
+        h[k++] = p[i];
+    }
+    const uint32_t lower = k + 1;
+    for (uint32_t i = u - 1; i-- > 0;) /* upper hull */
+    {
+        while (k >= lower && hcross(&h[k - 2], &h[k - 1], &p[i]) <= 0.0f)
+            --k;
+        h[k++] = p[i];
+    }
+    --k; /* the last point repeats the first */
+    for (uint32_t i = 0; i < k; ++i)
+        out_idx[i] = h[i].idx;
+    *count = k;
+    free(h);
+    free(p);
+    return ORC_OK;
+}
+
+/* Hulls of every valid cluster with fewer than max_points points (20 in the reference, :97), clusters in label
+ * order: hull_offsets[n_clusters + 1], hull_indices = indices into the clustered cloud.  Larger clusters get an
+ * empty hull here (the reference sends them to the concave-hull submodule, absent -- out of scope). */
+int orc_cluster_hulls(const void *pts, size_t stride, uint32_t m, const int32_t *labels, uint32_t n_clusters,
+                      uint32_t max_points, uint32_t *hull_offsets, uint32_t *hull_indices)
+{
+    uint32_t *cnt = (uint32_t *)calloc((size_t)n_clusters + 1, sizeof(uint32_t));
+    for (uint32_t i = 0; i < m; ++i)
+        if (labels[i] >= 0 && (uint32_t)labels[i] < n_clusters)
+            ++cnt[labels[i] + 1];
+    for (uint32_t c = 0; c < n_clusters; ++c)
+        cnt[c + 1] += cnt[c];
+    uint32_t *members = (uint32_t *)malloc(sizeof(uint32_t) * (m ? m : 1));
+    uint32_t *fill = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)n_clusters + 1));
+    memcpy(fill, cnt, sizeof(uint32_t) * ((size_t)n_clusters + 1));
+    for (uint32_t i = 0; i < m; ++i) /* src/processor.cpp:183-197: members in index order */
+        if (labels[i] >= 0 && (uint32_t)labels[i] < n_clusters)
+            members[fill[labels[i]]++] = i;
+    uint32_t total = 0;
+    float *xy = (float *)malloc(sizeof(float) * 2 * (m ? m : 1));
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (m ? m : 1));
+    for (uint32_t c = 0; c < n_clusters; ++c)
+    {
+        hull_offsets[c] = total;
+        const uint32_t b = cnt[c], n = cnt[c + 1] - cnt[c];
+        if (n == 0 || n >= max_points)
+            continue;
+        for (uint32_t t = 0; t < n; ++t)
+        {
+            const float *p = pt_at(pts, stride, members[b + t]);
+            xy[2 * t] = p[0];
+            xy[2 * t + 1] = p[1];
+        }
+        uint32_t k = 0;
+        orc_convex_hull(xy, n, tmp, &k);
+        for (uint32_t t = 0; t < k; ++t)
+            hull_indices[total + t] = members[b + tmp[t]];
+        total += k;
+    }
+    hull_offsets[n_clusters] = total;
+    free(tmp);
+    free(xy);
+    free(fill);
+    free(members);
+    free(cnt);
+    return ORC_OK;
+}

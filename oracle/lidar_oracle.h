@@ -99,6 +99,14 @@ int orc_plane_from_points(const float *xyz, uint32_t n, float *plane);
 /* Eigen 3.4 JacobiSVD<Matrix3f> restated: V of a 3x3 float matrix (row-major in/out) */
 void orc_jacobi_svd3(const float *a, float *v, float *sigma);
 
+/* N3: Andrew monotone chain, counter-clockwise, collinear points excluded (restated published algorithm; the
+ * reference's own implementation lives in the un-vendored Convex-Hull submodule: PARITY UNPINNED).
+ * xy: n (x, y) float pairs; out_idx: hull vertices as indices into xy. */
+int orc_convex_hull(const float *xy, uint32_t n, uint32_t *out_idx, uint32_t *count);
+/* hulls of the valid clusters with fewer than max_points points (src/polygon_simplification.cpp:96-115) */
+int orc_cluster_hulls(const void *pts, size_t stride_bytes, uint32_t m, const int32_t *labels, uint32_t n_clusters,
+                      uint32_t max_points, uint32_t *hull_offsets, uint32_t *hull_indices);
+
 #ifdef __cplusplus
 }
 #endif

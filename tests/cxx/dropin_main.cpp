@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace lp = lidar_processing;
@@ -48,6 +49,21 @@ int main(int argc, char **argv)
     coloured.reserve(obstacles.size());
     for (std::size_t i = 0; i < obstacles.size(); ++i)
         coloured.emplace_back(obstacles[i].x, obstacles[i].y, obstacles[i].z, 0, 255, 0, 1);
+
+    // optional device-side recolouring: same records as the copy above (and the ground cloud's counterpart)
+    pcl::PointCloud<pcl::PointXYZRGBL> ground_rgbl, obstacle_rgbl;
+    segmenter.coloured_clouds(ground_rgbl, obstacle_rgbl);
+    if (ground_rgbl.size() != ground.size() || obstacle_rgbl.size() != coloured.size())
+        return fail("coloured_clouds: sizes");
+    for (std::size_t i = 0; i < coloured.size(); ++i)
+        if (std::memcmp(&obstacle_rgbl[i], &coloured[i], 24) != 0)  // x y z 1 | b g r a | label
+            return fail("coloured_clouds: an obstacle record differs");
+    for (std::size_t i = 0; i < ground.size(); ++i)
+    {
+        const pcl::PointXYZRGBL want(ground[i].x, ground[i].y, ground[i].z, 220, 220, 220, 0);
+        if (std::memcmp(&ground_rgbl[i], &want, 24) != 0)
+            return fail("coloured_clouds: a ground record differs");
+    }
 
     std::vector<lp::ClusteringLabel> clu_labels;
     clusterer.cluster(coloured, clu_labels);  // call 2

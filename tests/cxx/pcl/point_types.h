@@ -37,7 +37,7 @@ struct alignas(16) PointXYZRGBL
     float pad2[2]{};
     PointXYZRGBL() = default;
     PointXYZRGBL(float x_, float y_, float z_, std::uint8_t r, std::uint8_t g, std::uint8_t b, std::uint32_t l)
-        : x(x_), y(y_), z(z_), rgba((std::uint32_t(r) << 16) | (std::uint32_t(g) << 8) | b), label(l)
+        : x(x_), y(y_), z(z_), rgba((255U << 24) | (std::uint32_t(r) << 16) | (std::uint32_t(g) << 8) | b), label(l)
     {
     }
 };

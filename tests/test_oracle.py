@@ -295,3 +295,43 @@ def test_synthetic_scene_is_deterministic():
     b = synthetic_scene(6000, 20, 200, 20240601)
     assert a.shape == (10000, 4) and np.array_equal(a, b)
     assert np.array_equal(a[:, :3], np.round(a[:, :3].astype(np.float64), 3).astype(np.float32))
+
+
+# ---- N3: convex hull restatement (Andrew monotone chain; the reference's Convex-Hull submodule is absent) ----
+
+def test_convex_hull_known_answers():
+    sq = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5], [0.5, 0], [1, 0.5], [0, 0], [1, 1]], np.float32)
+    assert oracle.convex_hull(sq).tolist() == [0, 1, 2, 3]                      # corners, CCW, first duplicate kept
+    assert oracle.convex_hull(np.array([[0, 0], [1, 1], [2, 2], [3, 3]], np.float32)).tolist() == [0, 3]  # collinear
+    assert oracle.convex_hull(np.array([[1, 1], [1, 1]], np.float32)).tolist() == [0]
+    assert oracle.convex_hull(np.zeros((0, 2), np.float32)).tolist() == []
+    assert oracle.convex_hull(np.array([[3, 4]], np.float32)).tolist() == [0]
+    assert oracle.convex_hull(np.array([[0, 0], [4, 0], [2, -3]], np.float32)).tolist() == [0, 2, 1]  # CCW
+    assert oracle.convex_hull(np.array([[-0.0, 0.0], [0.0, -0.0], [1, 0], [0, 1]], np.float32)).tolist() == [0, 2, 3]
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_convex_hull_against_scipy(seed):
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(seed)
+    for _ in range(60):
+        n = int(rng.integers(3, 200))
+        p = rng.normal(size=(n, 2)).astype(np.float32)
+        h = oracle.convex_hull(p)
+        assert set(h.tolist()) == set(ConvexHull(p.astype(np.float64)).vertices.tolist())
+        x, y = p[h, 0].astype(np.float64), p[h, 1].astype(np.float64)
+        assert 0.5 * np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y) > 0          # counter-clockwise
+        assert h[0] == np.lexsort((p[:, 1], p[:, 0]))[0]                           # starts at the lowest (x, y)
+
+
+def test_cluster_hulls_follow_the_reference_size_rule():
+    """src/polygon_simplification.cpp:97: only clusters with fewer than 20 points take the convex branch"""
+    pts = load_frame(FRAMES[0])
+    obs = pts[oracle.segment(pts)["obstacle_idx"]]
+    lab, nc = oracle.cluster(obs)
+    off, idx = oracle.cluster_hulls(obs, lab, nc, 20)
+    sizes = np.bincount(lab[lab >= 0], minlength=nc)
+    assert ((np.diff(off) > 0) == (sizes < 20)).all() and len(idx) == off[-1]
+    c = int(np.nonzero(sizes < 20)[0][0])
+    mem = np.nonzero(lab == c)[0]
+    assert np.array_equal(idx[off[c]:off[c + 1]], mem[oracle.convex_hull(obs[mem, :2])])
