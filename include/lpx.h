@@ -188,6 +188,12 @@ int lpx_segment_cluster_fields_device(lpx_ctx *ctx, const void *d_data, uint32_t
                                       const lpx_clu_cfg *clu_cfg, uint32_t *d_labels, uint32_t *d_ground_idx,
                                       uint32_t *d_obstacle_idx, float *d_planes, int32_t *d_cluster_labels,
                                       uint32_t *d_counts);
+int lpx_segment_cluster_batch_fields_device(lpx_ctx *ctx, uint32_t n_frames, const void *d_data, uint32_t point_step,
+                                            uint32_t off_x, uint32_t off_y, uint32_t off_z, uint32_t frame_pitch,
+                                            const uint32_t *n_points, const lpx_seg_cfg *seg_cfg,
+                                            const lpx_clu_cfg *clu_cfg, uint32_t *d_labels, uint32_t *d_ground_idx,
+                                            uint32_t *d_obstacle_idx, float *d_planes, int32_t *d_cluster_labels,
+                                            uint32_t *d_counts);
 int lpx_coloured_clouds_device(lpx_ctx *ctx, const uint32_t *d_ground_idx, const uint32_t *d_obstacle_idx,
                                void *d_ground_records, void *d_obstacle_records);
 int lpx_coloured_clouds_batch_device(lpx_ctx *ctx, uint32_t n_frames, uint32_t frame_pitch,
@@ -207,6 +213,52 @@ int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m,
 int lpx_cluster_hulls_device(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, const uint32_t *d_offsets,
                              const uint32_t *d_indices, uint32_t max_points, uint32_t *d_hull_offsets,
                              uint32_t *d_hull_indices, float *d_hull_xy);
+
+/* ---- N1: frames from binary PCD files, pinned memory, double-buffered stream ------------------ */
+
+/* Counterpart of the reference's input harness (Dataloader::preload_point_clouds, src/dataloader.cpp:128-153, which
+ * loads every .pcd file of data/ with pcl::io::loadPCDFile): binary PCD v0.7, header as in data/0000000000.pcd:1-11.  The
+ * payload is used AS STORED (records of point_step bytes, float32 x / y / z at off_x/y/z) through the *_fields
+ * entry points, so a file goes disk -> pinned host memory -> device without a decode or a copy in between. */
+typedef struct
+{
+    uint32_t n_points;   /* POINTS (or WIDTH * HEIGHT) */
+    uint32_t point_step; /* bytes per record = sum of SIZE * COUNT */
+    uint32_t off_x, off_y, off_z;
+    uint32_t n_fields;
+} lpx_pcd_info;
+
+/* page-locked host memory (hipHostMalloc) for lpx_pcd_load destinations and result arrays */
+int lpx_host_alloc(void **out, size_t bytes);
+void lpx_host_free(void *p);
+/* header only / header + exactly POINTS records into dst (trailing bytes of the file are ignored, as PCL does).
+ * LPX_ERR_ARG: unreadable, not `DATA binary`, or x / y / z are not float32 scalars; LPX_ERR_CAPACITY: dst too small */
+int lpx_pcd_info_read(const char *path, lpx_pcd_info *info);
+int lpx_pcd_load(const char *path, void *dst, size_t dst_capacity_bytes, lpx_pcd_info *info);
+
+/* A feeder preloads a list of files into ONE pinned arena (like the reference preloads all clouds) ... */
+typedef struct lpx_feeder lpx_feeder;
+int lpx_feeder_create(int device, const char *const *paths, uint32_t n_files, lpx_feeder **out);
+void lpx_feeder_destroy(lpx_feeder *f);
+uint32_t lpx_feeder_frames(const lpx_feeder *f);
+const void *lpx_feeder_frame(const lpx_feeder *f, uint32_t i, lpx_pcd_info *info); /* pinned records of frame i */
+const char *lpx_feeder_last_error(const lpx_feeder *f);
+
+/* ... and runs frames through a batch context with two device buffer sets: while chain k computes, the records
+ * of chain k + 1 travel H2D on a copy stream and the results of chain k - 1 travel D2H (exact sizes) on another,
+ * so PCIe in both directions overlaps the kernels.  Host result arrays (ordinary or pinned memory) are pitched by
+ * frame_pitch elements per frame; planes (may be NULL) by 4 * number_of_planar_partitions floats, counts by 4
+ * words {n_ground, n_obstacle, n_clusters, status}.  Per frame the results equal lpx_segment_cluster's. */
+typedef struct
+{
+    uint32_t *labels, *ground_idx, *obstacle_idx;
+    int32_t *cluster_labels;
+    float *planes;
+    uint32_t *counts;
+    uint32_t frame_pitch;
+} lpx_stream_out;
+int lpx_feeder_run(lpx_feeder *f, lpx_ctx *batch_ctx, const uint32_t *frame_ids, uint32_t n_frames,
+                   const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, const lpx_stream_out *out);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 

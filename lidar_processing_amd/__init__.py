@@ -5,9 +5,10 @@ Host-side mirror of the reference's operator interface for the hot path
 the C-ABI library `liblpx.so` (include/lpx.h).  There is no CPU fallback: without the HIP library
 or without a GPU every compute call raises.
 """
-from .api import (ClusteringConfiguration, Clusterer, LpxError, SegmentationConfiguration, SegmentationLabel,
-                  Segmenter, Context, INVALID, UNDEFINED)
+from .api import (ClusteringConfiguration, Clusterer, Feeder, LpxError, PinnedArray, SegmentationConfiguration,
+                  SegmentationLabel, Segmenter, Context, INVALID, UNDEFINED, load_pcd, pcd_info)
 from .pcd import read_pcd, write_pcd
 
 __all__ = ["ClusteringConfiguration", "Clusterer", "LpxError", "SegmentationConfiguration", "SegmentationLabel",
-           "Segmenter", "Context", "INVALID", "UNDEFINED", "read_pcd", "write_pcd"]
+           "Segmenter", "Context", "INVALID", "UNDEFINED", "read_pcd", "write_pcd", "Feeder", "PinnedArray", "load_pcd",
+           "pcd_info"]

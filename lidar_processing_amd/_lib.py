@@ -14,6 +14,17 @@ class SegCfg(C.Structure):
                 ("number_of_planar_partitions", C.c_uint32), ("number_of_lower_point_representatives", C.c_uint32)]
 
 
+class PcdInfo(C.Structure):
+    _fields_ = [("n_points", C.c_uint32), ("point_step", C.c_uint32), ("off_x", C.c_uint32), ("off_y", C.c_uint32),
+                ("off_z", C.c_uint32), ("n_fields", C.c_uint32)]
+
+
+class StreamOut(C.Structure):
+    _fields_ = [("labels", C.c_void_p), ("ground_idx", C.c_void_p), ("obstacle_idx", C.c_void_p),
+                ("cluster_labels", C.c_void_p), ("planes", C.c_void_p), ("counts", C.c_void_p),
+                ("frame_pitch", C.c_uint32)]
+
+
 class CluCfg(C.Structure):
     _fields_ = [("distance_squared", C.c_float), ("cluster_quality", C.c_float), ("min_cluster_size", C.c_uint32),
                 ("max_cluster_size", C.c_uint32)]
@@ -73,6 +84,23 @@ def lib():
     L.lpx_cluster_hulls.argtypes = [vp, u32, u32, u32, vp, vp, vp, pu32]
     L.lpx_cluster_hulls_device.argtypes = [vp, vp, u32, vp, vp, u32, vp, vp, vp]
     L.lpx_cluster_groups_device.argtypes = [vp, vp, u32, vp, vp]
+    L.lpx_host_alloc.argtypes = [C.POINTER(vp), sz]
+    L.lpx_host_free.argtypes = [vp]
+    L.lpx_host_free.restype = None
+    L.lpx_pcd_info_read.argtypes = [C.c_char_p, C.POINTER(PcdInfo)]
+    L.lpx_pcd_load.argtypes = [C.c_char_p, vp, sz, C.POINTER(PcdInfo)]
+    L.lpx_feeder_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), u32, C.POINTER(vp)]
+    L.lpx_feeder_destroy.argtypes = [vp]
+    L.lpx_feeder_destroy.restype = None
+    L.lpx_feeder_frames.argtypes = [vp]
+    L.lpx_feeder_frames.restype = u32
+    L.lpx_feeder_frame.argtypes = [vp, u32, C.POINTER(PcdInfo)]
+    L.lpx_feeder_frame.restype = vp
+    L.lpx_feeder_last_error.argtypes = [vp]
+    L.lpx_feeder_last_error.restype = C.c_char_p
+    L.lpx_feeder_run.argtypes = [vp, vp, vp, u32, C.POINTER(SegCfg), C.POINTER(CluCfg), C.POINTER(StreamOut)]
+    L.lpx_segment_cluster_batch_fields_device.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, vp, C.POINTER(SegCfg),
+                                                          C.POINTER(CluCfg), vp, vp, vp, vp, vp, vp]
     L.lpx_create_batch.argtypes = [C.c_int, u32, C.POINTER(vp)]
     L.lpx_segment_cluster_batch_device.argtypes = [vp, u32, vp, sz, u32, vp, C.POINTER(SegCfg), C.POINTER(CluCfg), vp,
                                                    vp, vp, vp, vp, vp]

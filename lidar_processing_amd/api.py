@@ -312,6 +312,128 @@ class Context:
         return plane, rc
 
 
+class PinnedArray:
+    """numpy view of page-locked host memory (lpx_host_alloc); free() or garbage collection releases it"""
+
+    def __init__(self, shape, dtype):
+        self._L = _lib.lib()
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        rc = self._L.lpx_host_alloc(C.byref(p), max(nbytes, 1))
+        if rc != 0:
+            raise LpxError(rc, "lpx_host_alloc")
+        self._p = p
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def free(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._L.lpx_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pcd_info(path):
+    """lpx_pcd_info_read: dict(n_points, point_step, offsets=(x, y, z), n_fields) of a binary PCD v0.7 file"""
+    inf = _lib.PcdInfo()
+    rc = _lib.lib().lpx_pcd_info_read(str(path).encode(), C.byref(inf))
+    if rc != 0:
+        raise LpxError(rc, f"{path}: not a binary PCD file with float32 x, y, z")
+    return dict(n_points=inf.n_points, point_step=inf.point_step, offsets=(inf.off_x, inf.off_y, inf.off_z),
+                n_fields=inf.n_fields)
+
+
+def load_pcd(path, pinned=True):
+    """lpx_pcd_load: the records of the file as an (n, point_step / 4) float32 array (a view of pinned memory when
+    pinned=True, kept alive by the array's .base chain) and the info dict.  Counterpart of pcl::io::loadPCDFile as
+    the reference uses it (src/dataloader.cpp:139)."""
+    info = pcd_info(path)
+    n, step = info["n_points"], info["point_step"]
+    if step % 4:
+        raise LpxError(-1, "records are not a whole number of floats")
+    if pinned:
+        holder = PinnedArray((n, step // 4), np.float32)
+        dst = holder.array
+    else:
+        holder, dst = None, np.zeros((n, step // 4), np.float32)
+    inf = _lib.PcdInfo()
+    rc = _lib.lib().lpx_pcd_load(str(path).encode(), _vp(dst) if n else None, dst.nbytes, C.byref(inf))
+    if rc != 0:
+        raise LpxError(rc, f"{path}: load failed")
+    info["_pinned"] = holder
+    return dst, info
+
+
+class Feeder:
+    """lpx_feeder: a list of PCD files preloaded into pinned memory (the reference preloads all clouds too,
+    src/dataloader.cpp:128-153) and the double-buffered H2D -> launch chain -> D2H pipeline over them"""
+
+    def __init__(self, paths, device=0):
+        self._L = _lib.lib()
+        arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+        h = C.c_void_p()
+        rc = self._L.lpx_feeder_create(int(device), arr, len(paths), C.byref(h))
+        if rc != 0:
+            raise LpxError(rc, "lpx_feeder_create")
+        self._h = h
+        self.n_frames = self._L.lpx_feeder_frames(h)
+        self.info = []
+        for i in range(self.n_frames):
+            inf = _lib.PcdInfo()
+            self._L.lpx_feeder_frame(h, i, C.byref(inf))
+            self.info.append(dict(n_points=inf.n_points, point_step=inf.point_step,
+                                  offsets=(inf.off_x, inf.off_y, inf.off_z)))
+
+    def frame(self, i):
+        """(n, point_step / 4) float32 view of the pinned records of frame i"""
+        inf = _lib.PcdInfo()
+        p = self._L.lpx_feeder_frame(self._h, i, C.byref(inf))
+        buf = (C.c_char * max(inf.n_points * inf.point_step, 1)).from_address(p)
+        return np.frombuffer(buf, dtype=np.float32, count=inf.n_points * inf.point_step // 4).reshape(
+            inf.n_points, inf.point_step // 4)
+
+    def run(self, ctx, frame_ids, seg_cfg, clu_cfg, out=None):
+        """lpx_feeder_run through the batch context `ctx`; returns the dict of pinned, pitched result arrays
+        (labels, ground_idx, obstacle_idx, cluster_labels (F, pitch); planes (F, 4P); counts (F, 4))"""
+        ids = np.ascontiguousarray(frame_ids, dtype=np.uint32)
+        F = ids.shape[0]
+        P = seg_cfg.number_of_planar_partitions
+        if F and int(ids.max()) >= self.n_frames:
+            raise LpxError(-1, f"frame id {int(ids.max())} out of range: the feeder holds {self.n_frames} frames")
+        if out is None:
+            pitch = max([self.info[i]["n_points"] for i in ids.tolist()] + [1])
+            out = dict(pitch=pitch,
+                       labels=PinnedArray((F, pitch), np.uint32), ground_idx=PinnedArray((F, pitch), np.uint32),
+                       obstacle_idx=PinnedArray((F, pitch), np.uint32), cluster_labels=PinnedArray((F, pitch), np.int32),
+                       planes=PinnedArray((F, 4 * P), np.float32), counts=PinnedArray((F, 4), np.uint32))
+        so = _lib.StreamOut(*[out[k].array.ctypes.data for k in ("labels", "ground_idx", "obstacle_idx", "cluster_labels",
+                                                                 "planes", "counts")], out["pitch"])
+        sc, cc = seg_cfg._c(), clu_cfg._c()
+        rc = self._L.lpx_feeder_run(self._h, ctx._h, _vp(ids), F, C.byref(sc), C.byref(cc), C.byref(so))
+        if rc != 0:
+            raise LpxError(rc, self._L.lpx_feeder_last_error(self._h).decode())
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lpx_feeder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _default_ctx = {}
 
 

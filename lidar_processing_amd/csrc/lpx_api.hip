@@ -493,20 +493,19 @@ extern "C" int lpx_segment_cluster_fields_device(lpx_ctx *ctx, const void *d_dat
 
 // B frames per launch chain: every kernel covers all frames (gridDim.z), so the launch count of the chain
 // is paid once per batch and each launch has B times the workgroups of a single frame.
-extern "C" int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames, const void *d_pts, size_t stride,
-                                                uint32_t frame_pitch, const uint32_t *n_points,
-                                                const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
-                                                uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes,
-                                                int32_t *d_clabels, uint32_t *d_counts)
+int lpx_batch_impl(lpx_ctx *ctx, uint32_t n_frames, const void *d_pts, size_t stride, const uint32_t *offs,
+                   uint32_t frame_pitch, const uint32_t *n_points, const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
+                   uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes, int32_t *d_clabels,
+                   uint32_t *d_counts)
 {
     if (!ctx || !n_points)
         return LPX_ERR_ARG;
-    int rc = check_seg(ctx, seg_cfg, stride);
-    if (rc || (rc = check_clu(ctx, clu_cfg, stride)))
+    int rc = check_seg(ctx, seg_cfg, stride, !offs);
+    if (rc || (rc = check_clu(ctx, clu_cfg, stride, !offs)))
         return rc;
     if (!d_labels || !d_gidx || !d_oidx || !d_clabels || !d_counts)
         return lpx_fail(ctx, LPX_ERR_ARG, "the batch entry point needs every output array except planes");
-    if ((rc = begin_call(ctx, n_frames, frame_pitch)))
+    if ((rc = begin_call(ctx, n_frames, frame_pitch)) || (offs && (rc = set_fields(ctx, stride, offs[0], offs[1], offs[2]))))
         return rc;
     uint32_t n = 0;
     for (uint32_t b = 0; b < n_frames; ++b)
@@ -523,6 +522,29 @@ extern "C" int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames,
     if ((rc = lpx_run_segment(ctx, d_pts, stride, n_points, seg_cfg, d_labels, d_gidx, d_oidx, d_planes)))
         return rc;
     return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts, false);
+}
+
+extern "C" int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames, const void *d_pts, size_t stride,
+                                                uint32_t frame_pitch, const uint32_t *n_points,
+                                                const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
+                                                uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes,
+                                                int32_t *d_clabels, uint32_t *d_counts)
+{
+    return lpx_batch_impl(ctx, n_frames, d_pts, stride, nullptr, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels, d_gidx,
+                          d_oidx, d_planes, d_clabels, d_counts);
+}
+
+// the same for n_frames PointCloud2-style buffers (records of point_step bytes, x / y / z at the given offsets)
+extern "C" int lpx_segment_cluster_batch_fields_device(lpx_ctx *ctx, uint32_t n_frames, const void *d_data,
+                                                       uint32_t point_step, uint32_t off_x, uint32_t off_y,
+                                                       uint32_t off_z, uint32_t frame_pitch, const uint32_t *n_points,
+                                                       const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
+                                                       uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx,
+                                                       float *d_planes, int32_t *d_clabels, uint32_t *d_counts)
+{
+    const uint32_t offs[3] = {off_x, off_y, off_z};
+    return lpx_batch_impl(ctx, n_frames, d_data, point_step, offs, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels,
+                          d_gidx, d_oidx, d_planes, d_clabels, d_counts);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,472 @@
+// lpx_feeder.hip -- N1: frames from binary PCD files into pinned host memory, and a double-buffered
+// prefetch -> H2D -> launch chain -> D2H pipeline over them.
+//
+// Counterpart of the reference's input harness: Dataloader::preload_point_clouds (src/dataloader.cpp:128-153)
+// loads every data/*.pcd with pcl::io::loadPCDFile into a PointXYZI cloud, re-packs it into a PointCloud2
+// (:87-126) and the processor decodes that again (src/conversions.cpp:62-85) before it calls segment().  Here the
+// file payload -- float32 records exactly as stored, header fields as in data/0000000000.pcd:1-11 -- is read
+// straight into hipHostMalloc memory and handed to the device with its own record layout (the *_fields entry
+// points): no intermediate copy, no decode on the host.
+//
+// Pipeline of lpx_feeder_run (B = frame slots of the batch context, two device buffer sets):
+//   chain k    : H2D of its frames' records on a copy stream into set k % 2   (after chain k-2 has computed)
+//                launch chain on the context stream                            (after that H2D, and after
+//                                                                               chain k-2's results left set k % 2)
+//   chain k - 1: the host waits for it WHILE chain k runs, reads its 4-word counts and issues exact-size D2H
+//                copies of labels / index lists / cluster labels / planes on a second copy stream.
+// PCIe moves in both directions next to the compute; the device never waits for the host between chains.
+#include "lpx_internal.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+struct lpx_feeder
+{
+    int device = 0;
+    std::vector<lpx_pcd_info> info;
+    std::vector<size_t> offset;  // byte offset of every frame in the pinned arena
+    char *pinned = nullptr;      // all frames, hipHostMalloc
+    size_t pinned_bytes = 0;
+    uint32_t max_points = 0, max_step = 0;
+    char err[512] = {0};
+    // device side of lpx_feeder_run (sized on first use)
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_compute[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+    void *d_in[2] = {nullptr, nullptr};
+    void *d_out[2] = {nullptr, nullptr};
+    size_t in_bytes = 0, out_bytes = 0;
+    uint32_t *h_counts = nullptr;  // pinned, 2 sets x B x 4
+    uint32_t cap_b = 0, cap_pitch = 0, cap_P = 0;
+};
+
+static int ffail(lpx_feeder *f, int code, const char *fmt, const char *a, const char *b = "")
+{
+    if (f)
+        snprintf(f->err, sizeof f->err, fmt, a, b);
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pinned host memory
+// ------------------------------------------------------------------------------------------------
+extern "C" int lpx_host_alloc(void **out, size_t bytes)
+{
+    if (!out)
+        return LPX_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return LPX_ERR_NO_DEVICE;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? LPX_OK : LPX_ERR_HIP;
+}
+
+extern "C" void lpx_host_free(void *p)
+{
+    if (p)
+        hipHostFree(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// binary PCD v0.7
+// ------------------------------------------------------------------------------------------------
+static int parse_header(FILE *fp, lpx_pcd_info *info, long *data_pos)
+{
+    char line[1024];
+    std::vector<std::string> fields;
+    std::vector<uint32_t> sizes, counts;
+    std::vector<char> types;
+    uint64_t width = 0, height = 1, points = 0;
+    bool have_points = false, have_data = false;
+    while (fgets(line, sizeof line, fp))
+    {
+        if (line[0] == '#')
+            continue;
+        char *save = nullptr;
+        char *key = strtok_r(line, " \t\r\n", &save);
+        if (!key)
+            continue;
+        std::vector<std::string> v;
+        for (char *t = strtok_r(nullptr, " \t\r\n", &save); t; t = strtok_r(nullptr, " \t\r\n", &save))
+            v.push_back(t);
+        if (!strcmp(key, "FIELDS"))
+            fields = v;
+        else if (!strcmp(key, "SIZE"))
+            for (auto &s : v)
+                sizes.push_back((uint32_t)strtoul(s.c_str(), nullptr, 10));
+        else if (!strcmp(key, "TYPE"))
+            for (auto &s : v)
+                types.push_back(s.empty() ? '?' : s[0]);
+        else if (!strcmp(key, "COUNT"))
+            for (auto &s : v)
+                counts.push_back((uint32_t)strtoul(s.c_str(), nullptr, 10));
+        else if (!strcmp(key, "WIDTH") && !v.empty())
+            width = strtoull(v[0].c_str(), nullptr, 10);
+        else if (!strcmp(key, "HEIGHT") && !v.empty())
+            height = strtoull(v[0].c_str(), nullptr, 10);
+        else if (!strcmp(key, "POINTS") && !v.empty())
+        {
+            points = strtoull(v[0].c_str(), nullptr, 10);
+            have_points = true;
+        }
+        else if (!strcmp(key, "DATA"))
+        {
+            if (v.empty() || v[0] != "binary")
+                return LPX_ERR_ARG;  // ascii / binary_compressed: not what the reference's data uses
+            have_data = true;
+            break;
+        }
+    }
+    if (!have_data || fields.empty() || sizes.size() != fields.size() || types.size() != fields.size())
+        return LPX_ERR_ARG;
+    if (counts.empty())
+        counts.assign(fields.size(), 1u);
+    if (counts.size() != fields.size())
+        return LPX_ERR_ARG;
+    if (!have_points)
+        points = width * height;
+    if (points > 0xfffffff0ull)
+        return LPX_ERR_ARG;
+    uint32_t step = 0, off[3] = {0, 0, 0};
+    bool found[3] = {false, false, false};
+    for (size_t i = 0; i < fields.size(); ++i)
+    {
+        for (int a = 0; a < 3; ++a)
+            if (fields[i] == (a == 0 ? "x" : a == 1 ? "y" : "z"))
+            {
+                if (sizes[i] != 4 || types[i] != 'F' || counts[i] != 1)
+                    return LPX_ERR_ARG;  // the path computes on float32 coordinates
+                off[a] = step;
+                found[a] = true;
+            }
+        step += sizes[i] * counts[i];
+    }
+    if (!found[0] || !found[1] || !found[2] || step == 0)
+        return LPX_ERR_ARG;
+    info->n_points = (uint32_t)points;
+    info->point_step = step;
+    info->off_x = off[0];
+    info->off_y = off[1];
+    info->off_z = off[2];
+    info->n_fields = (uint32_t)fields.size();
+    *data_pos = ftell(fp);
+    return LPX_OK;
+}
+
+extern "C" int lpx_pcd_info_read(const char *path, lpx_pcd_info *info)
+{
+    if (!path || !info)
+        return LPX_ERR_ARG;
+    FILE *fp = fopen(path, "rb");
+    if (!fp)
+        return LPX_ERR_ARG;
+    long pos = 0;
+    const int rc = parse_header(fp, info, &pos);
+    fclose(fp);
+    return rc;
+}
+
+// Reads exactly POINTS records into dst (the reference's files carry ~3.9 KB of trailing bytes after the payload,
+// which are ignored).  dst may be pinned (lpx_host_alloc) or ordinary memory.
+extern "C" int lpx_pcd_load(const char *path, void *dst, size_t dst_capacity_bytes, lpx_pcd_info *info)
+{
+    if (!path || !info || (!dst && dst_capacity_bytes))
+        return LPX_ERR_ARG;
+    FILE *fp = fopen(path, "rb");
+    if (!fp)
+        return LPX_ERR_ARG;
+    long pos = 0;
+    int rc = parse_header(fp, info, &pos);
+    if (rc == LPX_OK)
+    {
+        const size_t need = (size_t)info->n_points * info->point_step;
+        if (need > dst_capacity_bytes)
+            rc = LPX_ERR_CAPACITY;
+        else if (need && fread(dst, 1, need, fp) != need)
+            rc = LPX_ERR_ARG;  // truncated payload
+    }
+    fclose(fp);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// feeder: every file preloaded into ONE pinned arena (src/dataloader.cpp:128-153 preloads all clouds too)
+// ------------------------------------------------------------------------------------------------
+extern "C" int lpx_feeder_create(int device, const char *const *paths, uint32_t n_files, lpx_feeder **out)
+{
+    if (!out || (!paths && n_files))
+        return LPX_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return LPX_ERR_NO_DEVICE;
+    if (device < 0 || device >= count || hipSetDevice(device) != hipSuccess)
+        return LPX_ERR_ARG;
+    lpx_feeder *f = new (std::nothrow) lpx_feeder();
+    if (!f)
+        return LPX_ERR_INTERNAL;
+    f->device = device;
+    size_t total = 0;
+    for (uint32_t i = 0; i < n_files; ++i)
+    {
+        lpx_pcd_info inf;
+        const int rc = lpx_pcd_info_read(paths[i], &inf);
+        if (rc)
+        {
+            delete f;
+            return rc;
+        }
+        f->info.push_back(inf);
+        f->offset.push_back(total);
+        total += ((size_t)inf.n_points * inf.point_step + 255) & ~(size_t)255;
+        f->max_points = inf.n_points > f->max_points ? inf.n_points : f->max_points;
+        f->max_step = inf.point_step > f->max_step ? inf.point_step : f->max_step;
+    }
+    if (hipHostMalloc((void **)&f->pinned, total ? total : 1, hipHostMallocDefault) != hipSuccess)
+    {
+        delete f;
+        return LPX_ERR_HIP;
+    }
+    f->pinned_bytes = total;
+    for (uint32_t i = 0; i < n_files; ++i)
+    {
+        lpx_pcd_info inf;
+        const size_t cap = (i + 1 < n_files ? f->offset[i + 1] : total) - f->offset[i];
+        const int rc = lpx_pcd_load(paths[i], f->pinned + f->offset[i], cap, &inf);  // file -> pinned, no staging copy
+        if (rc || inf.n_points != f->info[i].n_points || inf.point_step != f->info[i].point_step)
+        {
+            hipHostFree(f->pinned);
+            delete f;
+            return rc ? rc : LPX_ERR_ARG;
+        }
+    }
+    *out = f;
+    return LPX_OK;
+}
+
+static void feeder_release_device(lpx_feeder *f)
+{
+    for (int s = 0; s < 2; ++s)
+    {
+        if (f->d_in[s])
+            hipFree(f->d_in[s]);
+        if (f->d_out[s])
+            hipFree(f->d_out[s]);
+        f->d_in[s] = f->d_out[s] = nullptr;
+        if (f->ev_h2d[s])
+            hipEventDestroy(f->ev_h2d[s]);
+        if (f->ev_compute[s])
+            hipEventDestroy(f->ev_compute[s]);
+        if (f->ev_d2h[s])
+            hipEventDestroy(f->ev_d2h[s]);
+        f->ev_h2d[s] = f->ev_compute[s] = f->ev_d2h[s] = nullptr;
+    }
+    if (f->h_counts)
+        hipHostFree(f->h_counts);
+    f->h_counts = nullptr;
+    if (f->h2d)
+        hipStreamDestroy(f->h2d);
+    if (f->d2h)
+        hipStreamDestroy(f->d2h);
+    f->h2d = f->d2h = nullptr;
+    f->cap_b = f->cap_pitch = f->cap_P = 0;
+}
+
+extern "C" void lpx_feeder_destroy(lpx_feeder *f)
+{
+    if (!f)
+        return;
+    hipSetDevice(f->device);
+    hipDeviceSynchronize();
+    feeder_release_device(f);
+    if (f->pinned)
+        hipHostFree(f->pinned);
+    delete f;
+}
+
+extern "C" uint32_t lpx_feeder_frames(const lpx_feeder *f)
+{
+    return f ? (uint32_t)f->info.size() : 0u;
+}
+
+extern "C" const void *lpx_feeder_frame(const lpx_feeder *f, uint32_t i, lpx_pcd_info *info)
+{
+    if (!f || i >= f->info.size())
+        return nullptr;
+    if (info)
+        *info = f->info[i];
+    return f->pinned + f->offset[i];
+}
+
+extern "C" const char *lpx_feeder_last_error(const lpx_feeder *f)
+{
+    return f ? f->err : "no feeder";
+}
+
+// per-set device output layout: [labels | gidx | oidx | clabels] B x pitch words each, planes B x 4P, counts B x 4
+struct OutSet
+{
+    uint32_t *labels, *gidx, *oidx;
+    int32_t *clabels;
+    float *planes;
+    uint32_t *counts;
+};
+
+static OutSet out_set(void *base, uint32_t B, uint32_t pitch, uint32_t P)
+{
+    OutSet o;
+    uint32_t *w = (uint32_t *)base;
+    const size_t a = (size_t)B * pitch;
+    o.labels = w;
+    o.gidx = w + a;
+    o.oidx = w + 2 * a;
+    o.clabels = (int32_t *)(w + 3 * a);
+    o.planes = (float *)(w + 4 * a);
+    o.counts = w + 4 * a + (size_t)B * 4 * P;
+    return o;
+}
+
+#define FHIP(f, call)                                                                                                \
+    do                                                                                                               \
+    {                                                                                                                \
+        hipError_t e_ = (call);                                                                                      \
+        if (e_ != hipSuccess)                                                                                        \
+            return ffail((f), LPX_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                           \
+    } while (0)
+
+static int feeder_prepare(lpx_feeder *f, uint32_t B, uint32_t pitch, uint32_t P)
+{
+    if (f->cap_b >= B && f->cap_pitch >= pitch && f->cap_P >= P && f->d_in[0])
+        return LPX_OK;
+    hipDeviceSynchronize();
+    feeder_release_device(f);
+    FHIP(f, hipStreamCreateWithFlags(&f->h2d, hipStreamNonBlocking));
+    FHIP(f, hipStreamCreateWithFlags(&f->d2h, hipStreamNonBlocking));
+    f->in_bytes = (size_t)B * pitch * f->max_step;
+    f->out_bytes = sizeof(uint32_t) * ((size_t)B * pitch * 4 + (size_t)B * 4 * P + (size_t)B * 4) + 256;
+    for (int s = 0; s < 2; ++s)
+    {
+        FHIP(f, hipMalloc(&f->d_in[s], f->in_bytes ? f->in_bytes : 1));
+        FHIP(f, hipMalloc(&f->d_out[s], f->out_bytes));
+        FHIP(f, hipEventCreateWithFlags(&f->ev_h2d[s], hipEventDisableTiming));
+        FHIP(f, hipEventCreateWithFlags(&f->ev_compute[s], hipEventDisableTiming));
+        FHIP(f, hipEventCreateWithFlags(&f->ev_d2h[s], hipEventDisableTiming));
+    }
+    FHIP(f, hipHostMalloc((void **)&f->h_counts, sizeof(uint32_t) * 2 * (size_t)B * 4, hipHostMallocDefault));
+    f->cap_b = B;
+    f->cap_pitch = pitch;
+    f->cap_P = P;
+    return LPX_OK;
+}
+
+// Frames frame_ids[0 .. n_frames) of the feeder through `ctx` (a batch context; its slot count is the chain
+// length), results to host arrays pitched by out->frame_pitch elements per frame (planes: 4 P floats, counts: 4
+// words {n_ground, n_obstacle, n_clusters, status}).  Synchronous at return.
+extern "C" int lpx_feeder_run(lpx_feeder *f, lpx_ctx *ctx, const uint32_t *frame_ids, uint32_t n_frames,
+                              const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, const lpx_stream_out *out)
+{
+    if (!f || !ctx || !seg_cfg || !clu_cfg || !out || (!frame_ids && n_frames))
+        return LPX_ERR_ARG;
+    if (!out->labels || !out->ground_idx || !out->obstacle_idx || !out->cluster_labels || !out->counts)
+        return ffail(f, LPX_ERR_ARG, "%s", "every output array except planes is required");
+    if (n_frames == 0)
+        return LPX_OK;
+    if (ctx->device != f->device)
+        return ffail(f, LPX_ERR_ARG, "%s", "feeder and context live on different devices");
+    const uint32_t B = ctx->batch, P = seg_cfg->number_of_planar_partitions;
+    uint32_t pitch = 0, step = 0;
+    for (uint32_t j = 0; j < n_frames; ++j)
+    {
+        if (frame_ids[j] >= f->info.size())
+            return ffail(f, LPX_ERR_ARG, "%s", "frame id out of range");
+        const lpx_pcd_info &inf = f->info[frame_ids[j]];
+        pitch = inf.n_points > pitch ? inf.n_points : pitch;
+        if (j == 0)
+            step = inf.point_step;
+        const lpx_pcd_info &i0 = f->info[frame_ids[0]];
+        if (inf.point_step != step || inf.off_x != i0.off_x || inf.off_y != i0.off_y || inf.off_z != i0.off_z)
+            return ffail(f, LPX_ERR_ARG, "%s", "the frames of one run must share a record layout");
+    }
+    if (pitch > out->frame_pitch)
+        return ffail(f, LPX_ERR_ARG, "%s", "a frame holds more points than out->frame_pitch");
+    FHIP(f, hipSetDevice(f->device));
+    int rc = feeder_prepare(f, B, pitch, P);
+    if (rc)
+        return rc;
+    if ((rc = lpx_reserve(ctx, pitch, 0)))
+        return ffail(f, rc, "%s", lpx_last_error(ctx));
+    const lpx_pcd_info lay = f->info[frame_ids[0]];
+    const uint32_t offs[3] = {lay.off_x, lay.off_y, lay.off_z};
+    const uint32_t n_chains = (n_frames + B - 1) / B;
+    const size_t up = out->frame_pitch;
+
+    // exact-size D2H of chain k's results once it has computed (the host waits for it while chain k + 1 runs)
+    auto drain = [&](uint32_t k) -> int {
+        const int s = (int)(k & 1u);
+        const uint32_t lo = k * B, nb = (n_frames - lo < B) ? n_frames - lo : B;
+        const OutSet o = out_set(f->d_out[s], B, f->cap_pitch, f->cap_P);
+        uint32_t *hc = f->h_counts + (size_t)s * B * 4;
+        FHIP(f, hipEventSynchronize(f->ev_compute[s]));
+        FHIP(f, hipMemcpyAsync(hc, o.counts, sizeof(uint32_t) * 4 * nb, hipMemcpyDeviceToHost, f->d2h));
+        FHIP(f, hipStreamSynchronize(f->d2h));
+        for (uint32_t b = 0; b < nb; ++b)
+        {
+            const uint32_t fid = frame_ids[lo + b], n = f->info[fid].n_points;
+            const uint32_t ng = hc[4 * b], no = hc[4 * b + 1];
+            const size_t dst = (size_t)(lo + b) * up, src = (size_t)b * f->cap_pitch;
+            memcpy(out->counts + 4 * (size_t)(lo + b), hc + 4 * b, 16);
+            if (n)
+                FHIP(f, hipMemcpyAsync(out->labels + dst, o.labels + src, 4 * (size_t)n, hipMemcpyDeviceToHost, f->d2h));
+            if (ng)
+                FHIP(f, hipMemcpyAsync(out->ground_idx + dst, o.gidx + src, 4 * (size_t)ng, hipMemcpyDeviceToHost, f->d2h));
+            if (no)
+            {
+                FHIP(f, hipMemcpyAsync(out->obstacle_idx + dst, o.oidx + src, 4 * (size_t)no, hipMemcpyDeviceToHost, f->d2h));
+                FHIP(f, hipMemcpyAsync(out->cluster_labels + dst, o.clabels + src, 4 * (size_t)no, hipMemcpyDeviceToHost,
+                                       f->d2h));
+            }
+        }
+        if (out->planes)
+            FHIP(f, hipMemcpyAsync(out->planes + (size_t)lo * 4 * P, o.planes, sizeof(float) * 4 * P * nb,
+                                   hipMemcpyDeviceToHost, f->d2h));
+        FHIP(f, hipEventRecord(f->ev_d2h[s], f->d2h));
+        return LPX_OK;
+    };
+
+    uint32_t n_pts[LPX_MAX_BATCH];
+    for (uint32_t k = 0; k < n_chains; ++k)
+    {
+        const int s = (int)(k & 1u);
+        const uint32_t lo = k * B, nb = (n_frames - lo < B) ? n_frames - lo : B;
+        // inputs of set s are free once chain k - 2 has computed
+        if (k >= 2)
+            FHIP(f, hipStreamWaitEvent(f->h2d, f->ev_compute[s], 0));
+        for (uint32_t b = 0; b < nb; ++b)
+        {
+            const uint32_t fid = frame_ids[lo + b];
+            n_pts[b] = f->info[fid].n_points;
+            if (n_pts[b])
+                FHIP(f, hipMemcpyAsync((char *)f->d_in[s] + (size_t)b * f->cap_pitch * step, f->pinned + f->offset[fid],
+                                       (size_t)n_pts[b] * step, hipMemcpyHostToDevice, f->h2d));
+        }
+        FHIP(f, hipEventRecord(f->ev_h2d[s], f->h2d));
+        FHIP(f, hipStreamWaitEvent(ctx->stream, f->ev_h2d[s], 0));
+        if (k >= 2)
+            FHIP(f, hipStreamWaitEvent(ctx->stream, f->ev_d2h[s], 0));  // chain k - 2's results have left set s
+        const OutSet o = out_set(f->d_out[s], B, f->cap_pitch, f->cap_P);
+        rc = lpx_batch_impl(ctx, nb, f->d_in[s], step, offs, f->cap_pitch, n_pts, seg_cfg, clu_cfg, o.labels, o.gidx, o.oidx,
+                            o.planes, o.clabels, o.counts);
+        if (rc)
+            return ffail(f, rc, "%s", lpx_last_error(ctx));
+        FHIP(f, hipEventRecord(f->ev_compute[s], ctx->stream));
+        if (k >= 1 && (rc = drain(k - 1)))
+            return rc;
+    }
+    if ((rc = drain(n_chains - 1)))
+        return rc;
+    FHIP(f, hipStreamSynchronize(f->d2h));
+    return LPX_OK;
+}

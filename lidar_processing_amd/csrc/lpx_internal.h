@@ -232,6 +232,11 @@ int lpx_write_counts(lpx_ctx *ctx, uint32_t *d_counts);
 // CSR of the valid clusters from d_labels (m entries): d_offsets[n_clusters + 1], d_indices[n_valid]
 int lpx_run_groups(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, uint32_t *d_offsets, uint32_t *d_indices);
 
+// batch launch chain; offs = byte offsets of x, y, z in a record, or null for PCL records
+int lpx_batch_impl(lpx_ctx *ctx, uint32_t n_frames, const void *d_pts, size_t stride, const uint32_t *offs,
+                   uint32_t frame_pitch, const uint32_t *n_points, const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
+                   uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes, int32_t *d_clabels,
+                   uint32_t *d_counts);
 // N3: convex hulls of the small clusters from that CSR (results: hull offsets / point indices / xy)
 int lpx_run_hulls(lpx_ctx *ctx, const int32_t *d_labels, uint32_t m, const uint32_t *d_offsets,
                   const uint32_t *d_indices, uint32_t max_points, uint32_t *d_hull_off, uint32_t *d_hull_idx,

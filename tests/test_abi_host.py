@@ -163,6 +163,28 @@ def test_pcd_roundtrip(tmp_path):
     assert fields == ["x", "y", "z", "intensity"] and np.array_equal(back, pts)
 
 
+def test_c_pcd_loader_on_host_memory(tmp_path):
+    """lpx_pcd_info_read / lpx_pcd_load are plain file I/O: they run without a GPU into ordinary memory"""
+    from lidar_processing_amd import load_pcd, pcd_info, write_pcd, LpxError
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(4321, 4)).astype(np.float32)
+    p = tmp_path / "a.pcd"
+    write_pcd(p, pts)
+    with open(p, "ab") as f:
+        f.write(b"\0" * 3900)
+    assert pcd_info(p) == dict(n_points=4321, point_step=16, offsets=(0, 4, 8), n_fields=4)
+    got, _ = load_pcd(p, pinned=False)
+    assert np.array_equal(got.view(np.uint32), pts.view(np.uint32))
+    with pytest.raises(LpxError):
+        pcd_info(tmp_path / "missing.pcd")
+    ref = "/root/reference/data/0000000077.pcd"
+    if os.path.exists(ref):  # build container: the reference's own file, against the committed fixture
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from util import load_frame
+        got, info = load_pcd(ref, pinned=False)
+        assert info["n_points"] == 124049 and np.array_equal(got.view(np.uint32), load_frame("0000000077").view(np.uint32))
+
+
 def test_frame_sharding_is_round_robin():
     sys.path.insert(0, ROOT)
     import bench

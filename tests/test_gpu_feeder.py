@@ -1,0 +1,115 @@
+"""N1: binary PCD files -> pinned host memory -> double-buffered H2D / launch chain / D2H (lpx_pcd_load,
+lpx_feeder_*).  The GPU box has no reference checkout, so the .pcd files are written here from the committed
+stream fixture (bit-identical payloads, with the trailing bytes the reference's files carry)."""
+import numpy as np
+import pytest
+
+from lidar_processing_amd import (ClusteringConfiguration, Context, Feeder, LpxError, SegmentationConfiguration, load_pcd,
+                                  pcd_info, write_pcd)
+from test_gpu_stream import crc, golden_row
+from util import STREAM_CONFIGS, load_stream_frame, stream_gold, stream_names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pcd_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("pcd")
+    for name in stream_names():
+        path = d / f"{name}.pcd"
+        write_pcd(path, load_stream_frame(name))
+        with open(path, "ab") as f:
+            f.write(b"\x00" * 3900)  # the reference's files carry trailing bytes after the POINTS records
+    return d
+
+
+def test_pcd_loader_reads_exactly_the_records_into_pinned_memory(pcd_dir):
+    for name in stream_names()[::31]:
+        want = load_stream_frame(name)
+        info = pcd_info(pcd_dir / f"{name}.pcd")
+        assert info == dict(n_points=want.shape[0], point_step=16, offsets=(0, 4, 8), n_fields=4)
+        got, info2 = load_pcd(pcd_dir / f"{name}.pcd")
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        got2, _ = load_pcd(pcd_dir / f"{name}.pcd", pinned=False)
+        assert np.array_equal(got2.view(np.uint32), want.view(np.uint32))
+
+
+def test_pcd_loader_field_layouts_and_errors(tmp_path):
+    rng = np.random.default_rng(1)
+    pts = rng.normal(size=(777, 5)).astype(np.float32)
+    p = tmp_path / "five.pcd"
+    write_pcd(p, pts, fields=("intensity", "x", "ring", "y", "z"))
+    info = pcd_info(p)
+    assert info["point_step"] == 20 and info["offsets"] == (4, 12, 16)
+    got, _ = load_pcd(p, pinned=False)
+    assert np.array_equal(got, pts)
+    (tmp_path / "ascii.pcd").write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\n"
+                                        "HEIGHT 1\nPOINTS 1\nDATA ascii\n0 0 0\n")
+    with pytest.raises(LpxError):
+        pcd_info(tmp_path / "ascii.pcd")
+    (tmp_path / "noz.pcd").write_bytes(b"VERSION 0.7\nFIELDS x y\nSIZE 4 4\nTYPE F F\nCOUNT 1 1\nWIDTH 1\nHEIGHT 1\n"
+                                       b"POINTS 1\nDATA binary\n" + b"\0" * 8)
+    with pytest.raises(LpxError):
+        pcd_info(tmp_path / "noz.pcd")
+    trunc = tmp_path / "trunc.pcd"
+    write_pcd(trunc, pts[:, :4])
+    with open(trunc, "r+b") as f:
+        f.truncate(trunc.stat().st_size - 100)
+    with pytest.raises(LpxError):
+        load_pcd(trunc)
+    with pytest.raises(LpxError):
+        pcd_info(tmp_path / "missing.pcd")
+
+
+@pytest.mark.parametrize("cname", list(STREAM_CONFIGS))
+def test_feeder_streams_all_154_files_to_the_goldens(pcd_dir, cname):
+    """BASELINE configs[3] end to end: files -> pinned -> H2D -> chains of 32 -> D2H, two buffer sets"""
+    skw, ckw = STREAM_CONFIGS[cname]
+    scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
+    names = stream_names()
+    feeder = Feeder([pcd_dir / f"{n}.pcd" for n in names])
+    bctx = Context(0, batch=32)
+    try:
+        assert feeder.n_frames == 154
+        assert np.array_equal(feeder.frame(7).view(np.uint32), load_stream_frame(names[7]).view(np.uint32))
+        ids = np.arange(154)
+        out = feeder.run(bctx, ids, scfg, ccfg)
+        out2 = feeder.run(bctx, ids[::-1], scfg, ccfg)  # again, other order: buffers and events are reused
+    finally:
+        bctx.close()
+    g = stream_gold()
+    for o, order in ((out, ids), (out2, ids[::-1])):
+        for j, fid in enumerate(order):
+            ng, no, nc, status = (int(v) for v in o["counts"].array[j])
+            assert status == 0
+            res = dict(n_ground=ng, n_obstacle=no, n_clusters=nc,
+                       labels=o["labels"].array[j, :int(g["n"][fid])], obstacle_idx=o["obstacle_idx"].array[j, :no],
+                       cluster_labels=o["cluster_labels"].array[j, :no], planes=o["planes"].array[j].reshape(-1, 4))
+            assert golden_row(res) == [int(v) for v in g[cname][fid]], names[fid]
+            gi = o["ground_idx"].array[j, :ng]
+            assert (o["labels"].array[j, gi] == 1).all()
+    feeder.close()
+
+
+def test_feeder_short_runs_and_single_frame_parity(pcd_dir, ctx):
+    names = stream_names()[:5]
+    feeder = Feeder([pcd_dir / f"{n}.pcd" for n in names])
+    scfg, ccfg = SegmentationConfiguration(), ClusteringConfiguration()
+    bctx = Context(0, batch=2)  # chains of 2: 1, 2, 3 chains, a ragged tail
+    try:
+        for ids in ([3], [0, 1], [4, 2, 0], [1, 1, 1, 1, 1]):
+            out = feeder.run(bctx, ids, scfg, ccfg)
+            for j, fid in enumerate(ids):
+                want = ctx.segment_cluster(load_stream_frame(names[fid]), scfg, ccfg)
+                ng, no, nc, status = (int(v) for v in out["counts"].array[j])
+                assert (status, nc, ng, no) == (0, want["n_clusters"], len(want["ground_idx"]), len(want["obstacle_idx"]))
+                assert np.array_equal(out["labels"].array[j, :len(want["labels"])], want["labels"])
+                assert np.array_equal(out["ground_idx"].array[j, :ng], want["ground_idx"])
+                assert np.array_equal(out["obstacle_idx"].array[j, :no], want["obstacle_idx"])
+                assert np.array_equal(out["cluster_labels"].array[j, :no], want["cluster_labels"])
+                assert np.array_equal(out["planes"].array[j].reshape(-1, 4).view(np.uint32), want["planes"].view(np.uint32))
+        with pytest.raises(LpxError):
+            feeder.run(bctx, [9], scfg, ccfg)
+    finally:
+        bctx.close()
+        feeder.close()
