@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--single-pass-words", type=int, default=384,
                     help="extra neighbour workspace per point for single-pass lists (lpx_reserve_single_pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lists", action="store_true", help="round-1 path: materialise every radius list (A/B reference)")
     args = ap.parse_args()
 
     import torch
@@ -158,7 +159,9 @@ def main():
     C = max(1, min(args.contexts, len(chains)))
     ctxs = [Context(local_rank, batch=B) for _ in range(C)]
     for c in ctxs:
-        c.reserve_single_pass(args.single_pass_words)
+        if args.lists:
+            c.use_lists(True)
+            c.reserve_single_pass(args.single_pass_words)
         c.reserve(pitch, args.neighbour_words)
     d_labels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
     d_gidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)

@@ -114,6 +114,11 @@ class Context:
         """lpx_reserve_single_pass: extra neighbour workspace for lists reserved by an upper bound (0 = off)"""
         self.check(self._L.lpx_reserve_single_pass(self._h, int(words_per_point)))
 
+    def use_lists(self, on=True):
+        """lpx_dbg_use_lists: True selects the round-1 path that materialises every radius list (kept for A/B
+        measurements and the list tests); the default is the expansion-driven search"""
+        self.check(self._L.lpx_dbg_use_lists(self._h, 1 if on else 0))
+
     def synchronize(self):
         self.check(self._L.lpx_synchronize(self._h))
 

@@ -68,6 +68,12 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         if (hist_bytes < (1u << 16))
             hist_bytes = 1u << 16;
         const size_t blk_bytes = sizeof(uint32_t) * (2 * ((size_t)n / 4096 + LPX_MAX_PARTITIONS + 2) + 2);
+        // expansion-driven search: at most n / 16 + 2 kd groups (2^(D+1) with n >> D <= 64), a cell table of the
+        // next power of two >= 2 n slots
+        const size_t chunk_bytes = sizeof(uint2) * LPX_GROUP_CHUNKS * ((size_t)n / 16 + 64);
+        uint32_t cell_cap = 64;
+        while ((size_t)cell_cap < 2 * (size_t)n)
+            cell_cap <<= 1;
         struct Item
         {
             Buf *b;
@@ -89,6 +95,9 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             {&ctx->seed_of, n4},  {&ctx->queue, n4},    {&ctx->valid, n4},   {&ctx->d_labels, n4}, {&ctx->d_gidx, n4},
             {&ctx->d_oidx, n4},   {&ctx->d_clabels, n4}, {&ctx->key64_a, 2 * n4}, {&ctx->key64_b, 2 * n4},
             {&ctx->nodes, 4 * n4}, {&ctx->nodes_pre, 4 * n4}, {&ctx->flags, (size_t)n + 64}, {&ctx->state, (size_t)n + 64},
+            {&ctx->grp_of, n4},   {&ctx->cell_of, n4},  {&ctx->chunks, chunk_bytes},
+            {&ctx->cell_key, sizeof(uint64_t) * cell_cap}, {&ctx->cell_rep, sizeof(uint32_t) * cell_cap},
+            {&ctx->cell_parent, sizeof(uint32_t) * cell_cap},
         };
         size_t total = 0;
         for (const Item &it : items)
@@ -112,7 +121,10 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         }
         ctx->fstride = total;
         ctx->cap_n = n;
+        ctx->cell_cap = cell_cap;
     }
+    if (!ctx->use_lists && !ctx->nb_arena)
+        return LPX_OK;  // the neighbour-list workspace below belongs to the list path only (allocated on first use)
     // Neighbour workspace of a slot: cap_nb words for lists of exact length (what lpx_reserve promises), then
     // cap_rs words the neighbour kernel may use for single-pass lists reserved by an upper bound; a group that
     // finds no room there falls back to counting, so the second region only ever buys speed.
@@ -997,6 +1009,30 @@ extern "C" int lpx_dbg_frame_stats(lpx_ctx *ctx, uint32_t *out12)
     return lpx_dbg_frame_stats_slot(ctx, 0, out12);
 }
 
+int lpx_ensure_lists(lpx_ctx *ctx)
+{
+    const bool was = ctx->use_lists;
+    ctx->use_lists = true;
+    uint64_t nb = (uint64_t)ctx->cap_n * ctx->nb_per_point;
+    if (nb > 0xfffffff0ull)
+        nb = 0xfffffff0ull;
+    const int rc = lpx_ensure_capacity(ctx, ctx->cap_n, nb > ctx->cap_nb ? nb : ctx->cap_nb);
+    ctx->use_lists = was;
+    return rc;
+}
+
+// Selects how Clusterer::cluster finds neighbours.  0 (default): expansion-driven -- components from a uniform
+// grid, radius searches only for the points the greedy loop expands, nothing materialised.  1: the round-1 path
+// that writes every radius list first (kept as the reference point for A/B measurements and for the list tests).
+extern "C" int lpx_dbg_use_lists(lpx_ctx *ctx, int on)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->use_lists = on != 0;
+    return on ? lpx_ensure_lists(ctx) : LPX_OK;
+}
+
 // tools only: per-group statistics of the neighbour kernel ({T, intervals, queries, hits, cycles to
 // allocation, cycles total, -, -} per group); pass n_groups = 0 to switch it off again
 extern "C" int lpx_dbg_group_stats(lpx_ctx *ctx, uint32_t n_groups, uint32_t *out)
@@ -1110,7 +1146,7 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     if (m == 0)
         return LPX_OK;
     int rc = upload_xyz_as_obstacles(ctx, xyz, m);
-    if (rc || (rc = lpx_kd_build(ctx, m)))
+    if (rc || (rc = lpx_ensure_lists(ctx)) || (rc = lpx_kd_build(ctx, m)))
         return rc;
     FrameState fs;
     for (int attempt = 0; attempt < 2; ++attempt)
@@ -1203,7 +1239,7 @@ extern "C" int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     if (m == 0)
         return LPX_OK;
     int rc = upload_xyz_as_obstacles(ctx, xyz, m);
-    if (rc || (rc = lpx_kd_build(ctx, m)))
+    if (rc || (rc = lpx_ensure_lists(ctx)) || (rc = lpx_kd_build(ctx, m)))
         return rc;
     FrameState fs;
     for (int attempt = 0; attempt < 2; ++attempt)

@@ -470,6 +470,368 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
 #undef ST_OR
 }
 
+// ------------------------------------------------------------------------------------------------
+// Expansion-driven replay: the same greedy loop, but the radius search of a point happens WHEN the loop expands
+// it, against the candidate chunks of the point's kd group (lpx_kdtree.hip: nb_index_kernel).  Nothing is
+// materialised for the ~80 % of the points the reference never expands.
+//
+// One workgroup of four wavefronts per component set (lpx_grid_components), persistent over a work list.
+// Wavefront 0 is the sequencer: seeds, the queue window, the in-window expansion selection, and the ordered
+// application of every neighbour (touch / absorb / queue) to the 2-bit point states.  The expansions of a window
+// are known before any of them is applied (see replay_lds_kernel), so all four wavefronts SEARCH them in parallel
+// -- expansion e goes to wavefront e % 4 -- and leave compact, ordered hit lists (index | absorb << 31) in LDS;
+// the sequencer then applies them in expansion order.  A list that does not fit its LDS region is redone by the
+// sequencer itself, streaming candidates straight into the apply step.  A search is one load of the group's chunk
+// table and one independent 16-byte load per candidate (issued eight chunks at a time), then the reference's
+// float distance expression per candidate; hits keep candidate (= pre-order) order, so no sort is needed.
+// STATE_LDS: point states as a 2-bit LDS bitmap (fits up to ~390k points), else one byte per point in HBM.
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_WAVES = 4;
+constexpr int RS_THREADS = RS_WAVES * WAVE;
+constexpr int RS_REGION = 1536;              // words of hit-list space per wavefront and window
+constexpr int RS_BATCH = 8;                  // candidate chunks in flight per wavefront
+constexpr uint32_t RS_OVERFLOW = 0xffffffffu;
+constexpr uint32_t RS_DONE = 0xffffffffu;
+
+struct RsShared  // fixed part of the LDS of replay_search_kernel (the bitmap follows)
+{
+    uint32_t ring[RP_RING];
+    uint32_t lists[RS_WAVES * RS_REGION];
+    uint32_t ej[WAVE];           // expansions of the window: point index ...
+    float ex[WAVE], ey[WAVE], ez[WAVE];  // ... and coordinates
+    uint32_t eoff[WAVE], elen[WAVE];     // where its hit list is (words from lists[]), RS_OVERFLOW: not stored
+    uint32_t ctl[4];             // 0: number of expansions of the window / RS_DONE
+};
+
+typedef float4 KdNode;
+
+// distance-tests one chunk of candidates against (qx, qy, qz): per lane the list word of its candidate
+// (index | absorb << 31) or 0xffffffff
+__device__ __forceinline__ uint32_t rs_test(const KdNode &nd, bool valid, float qx, float qy, float qz, float r2,
+                                            float thr_f)
+{
+    const float a0 = qx - nd.x, a1 = qy - nd.y, a2 = qz - nd.z;
+    const float da = a0 * a0 + (a1 * a1 + a2 * a2);  // src/kdtree.hpp:145-157 (the + 0.0f is the identity)
+    const bool in = valid && da <= r2;               // :315 inclusive
+    return in ? (__float_as_uint(nd.w) | (da <= thr_f ? 0x80000000u : 0u)) : 0xffffffffu;
+}
+
+// Search of one expansion by one wavefront.  SINK(word) is called for every chunk step with the per-lane list word
+// (0xffffffff for lanes without a hit) in candidate order; returns false to stop (list region full).
+template <class Sink>
+__device__ __forceinline__ bool rs_search(const KdNode *__restrict__ PR, const uint2 *__restrict__ chunks,
+                                          uint32_t gid, float qx, float qy, float qz, float r2, float thr_f,
+                                          uint32_t lane, unsigned long long &cand, Sink &&sink)
+{
+    const uint2 ch = chunks[(size_t)gid * LPX_GROUP_CHUNKS + lane];  // lane c: chunk c = (rank, count)
+    const unsigned long long cm = __ballot(ch.y != 0u);
+    const uint32_t n_chunks = (uint32_t)__popcll(cm);  // chunks are packed from lane 0
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += RS_BATCH)
+    {
+        KdNode nd[RS_BATCH];
+        uint32_t cnt[RS_BATCH];
+#pragma unroll
+        for (int u = 0; u < RS_BATCH; ++u)
+        {
+            const uint32_t c = c0 + u;
+            const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)ch.x, c < n_chunks ? c : 0u);
+            cnt[u] = c < n_chunks ? (uint32_t)__builtin_amdgcn_readlane((int)ch.y, c < n_chunks ? c : 0u) : 0u;
+            // unconditional load (rank 0 for idle lanes): the loads of a batch are issued back to back
+            nd[u] = PR[lane < cnt[u] ? rank + lane : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < RS_BATCH; ++u)
+        {
+            if (cnt[u] == 0u)
+                break;
+            cand += min(cnt[u], 64u);
+            if (!sink(rs_test(nd[u], lane < cnt[u], qx, qy, qz, r2, thr_f)))
+                return false;
+            if (cnt[u] > 64u)
+            {
+                // the long tail chunk of a group with more than 64 chunks: the rest of its ranks, 64 at a time
+                const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)ch.x, c0 + u);
+                for (uint32_t o = 64; o < cnt[u]; o += 64)
+                {
+                    const bool v = o + lane < cnt[u];
+                    const KdNode n2 = PR[v ? rank + o + lane : 0u];
+                    cand += min(cnt[u] - o, 64u);
+                    if (!sink(rs_test(n2, v, qx, qy, qz, r2, thr_f)))
+                        return false;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+template <bool STATE_LDS>
+__global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
+    const FrameState *__restrict__ frame, const uint32_t *__restrict__ cc_lo, const uint32_t *__restrict__ cc_hi,
+    const uint32_t *__restrict__ members, const KdNode *__restrict__ PR, const uint2 *__restrict__ chunks,
+    const uint32_t *__restrict__ grp_of, const float *__restrict__ OX, const float *__restrict__ OY,
+    const float *__restrict__ OZ, uint8_t *gstate, int32_t *seed_of, uint32_t *queue, uint32_t *valid,
+    ReplayParams prm, FrameState *fstate, const uint32_t *__restrict__ roots, FV fv)
+{
+    extern __shared__ uint32_t smem[];
+    RsShared &sh = *(RsShared *)smem;
+    uint32_t *sbits = smem + sizeof(RsShared) / sizeof(uint32_t);
+    frame = lpx_slot(frame, fv.fs);
+    fstate = lpx_slot(fstate, fv.fs);
+    cc_lo = lpx_slot(cc_lo, fv.fs);
+    cc_hi = lpx_slot(cc_hi, fv.fs);
+    members = lpx_slot(members, fv.fs);
+    PR = lpx_slot(PR, fv.fs);
+    chunks = lpx_slot(chunks, fv.fs);
+    grp_of = lpx_slot(grp_of, fv.fs);
+    OX = lpx_slot(OX, fv.fs);
+    OY = lpx_slot(OY, fv.fs);
+    OZ = lpx_slot(OZ, fv.fs);
+    gstate = lpx_slot(gstate, fv.fs);
+    seed_of = lpx_slot(seed_of, fv.fs);
+    queue = lpx_slot(queue, fv.fs);
+    valid = lpx_slot(valid, fv.fs);
+    roots = lpx_slot(roots, fv.fs);
+    const uint32_t tid = threadIdx.x, w = tid / WAVE, lane = tid % WAVE;
+    const uint32_t M = frame->n_obstacle;
+    const uint32_t n_roots = frame->n_roots;
+    if (blockIdx.x >= n_roots)
+        return;
+    if (STATE_LDS)
+    {
+        // zeroed once: component sets own disjoint points, so one set never reads the states of another
+        const uint32_t words = (M + 15) / 16;
+        for (uint32_t i = tid; i < words; i += RS_THREADS)
+            sbits[i] = 0;
+    }
+    __syncthreads();
+    const unsigned long long lt = lpx_lanemask_lt();
+    const float r2 = prm.r2, thr_f = prm.thr_f;
+    unsigned long long st_cand = 0;
+
+    // one expansion searched into this wavefront's list region; returns the new fill level
+    auto search_to_lds = [&](uint32_t e, uint32_t fill) -> uint32_t {
+        const uint32_t j = sh.ej[e];
+        uint32_t *dst = sh.lists + w * RS_REGION;
+        uint32_t len = 0;
+        bool ok = fill != RS_OVERFLOW;
+        if (ok)
+            ok = rs_search(PR, chunks, grp_of[j], sh.ex[e], sh.ey[e], sh.ez[e], r2, thr_f, lane, st_cand,
+                           [&](uint32_t word) -> bool {
+                               const bool hit = word != 0xffffffffu;
+                               const unsigned long long hm = __ballot(hit);
+                               if (fill + len + (uint32_t)__popcll(hm) > (uint32_t)RS_REGION)
+                                   return false;
+                               if (hit)
+                                   dst[fill + len + __popcll(hm & lt)] = word;
+                               len += (uint32_t)__popcll(hm);
+                               return true;
+                           });
+        if (lane == 0)
+        {
+            sh.eoff[e] = w * RS_REGION + fill;
+            sh.elen[e] = ok ? len : RS_OVERFLOW;
+        }
+        return ok ? fill + len : RS_OVERFLOW;  // once a list did not fit, the later ones of this wavefront do not either
+    };
+
+    if (w != 0)
+    {
+        // helper wavefronts: search their share of every window the sequencer publishes
+        for (;;)
+        {
+            __syncthreads();  // A: window published
+            const uint32_t E = sh.ctl[0];
+            if (E == RS_DONE)
+                break;
+            uint32_t fill = 0;
+            for (uint32_t e = w; e < E; e += RS_WAVES)
+                fill = search_to_lds(e, fill);
+            __syncthreads();  // B: lists ready
+        }
+        if (lane == 0 && st_cand)
+            atomicAdd((unsigned long long *)&fstate->cand_total, st_cand);
+        return;
+    }
+
+    // ---- sequencer (wavefront 0) ----
+#define ST_GET(k) (STATE_LDS ? ((sbits[(k) >> 4] >> (((k) & 15u) * 2u)) & 3u) : (uint32_t)gstate[k])
+#define ST_OR(k, v)                                                                                                   \
+    do                                                                                                                \
+    {                                                                                                                 \
+        if (STATE_LDS)                                                                                                \
+            atomicOr(&sbits[(k) >> 4], (uint32_t)(v) << (((k) & 15u) * 2u));                                         \
+        else                                                                                                          \
+            gstate[k] = (uint8_t)(gstate[k] | (v));                                                                   \
+    } while (0)
+    unsigned long long st_entries = 0;
+    uint32_t st_exp = 0;
+    for (;;)
+    {
+        uint32_t ticket = 0;
+        if (lane == 0)
+            ticket = atomicAdd(&fstate->root_cursor, 1u);
+        ticket = __shfl(ticket, 0, 64);
+        if (ticket >= n_roots)
+            break;
+        const uint32_t r = roots[ticket];
+        const uint32_t lo = cc_lo[r], hi = cc_hi[r];
+        uint32_t *q = queue + lo;
+        uint32_t cursor = lo;
+        for (;;)
+        {
+            // next seed: first member (ascending index) that is not removed (src/clustering.cpp:70-75)
+            uint32_t seed = 0xffffffffu;
+            while (cursor < hi)
+            {
+                const uint32_t p = cursor + lane;
+                const uint32_t cand = (p < hi) ? members[p] : 0u;
+                const bool ok = (p < hi) && !(ST_GET(cand) & 2u);
+                const unsigned long long m = __ballot(ok);
+                if (m)
+                {
+                    const int f = __ffsll((long long)m) - 1;
+                    seed = __shfl(cand, f, 64);
+                    cursor += f + 1;
+                    break;
+                }
+                cursor += WAVE;
+            }
+            if (seed == 0xffffffffu)
+                break;
+            uint32_t qh = 0, qt = 1;
+            unsigned long long touches = 0;  // indices_.size(), duplicates included (:99-100)
+            if (lane == 0)
+            {
+                q[0] = seed;
+                sh.ring[0] = seed;
+                ST_OR(seed, 1u);
+                seed_of[seed] = (int32_t)seed;  // queued before it is ever touched
+            }
+            if (!STATE_LDS)
+                __threadfence_block();
+            // applies one chunk step of list words in order (:92-110): touch, absorb or queue
+            auto apply = [&](uint32_t word) {
+                const bool in = word != 0xffffffffu;
+                const uint32_t k = in ? (word & 0x7fffffffu) : 0u;
+                const uint32_t sk = in ? ST_GET(k) : 2u;
+                const bool vis = in && !(sk & 2u);
+                touches += __popcll(__ballot(vis));
+                const bool absorb = vis && (word >> 31);
+                const bool push = vis && !absorb && sk == 0u;
+                const unsigned long long pm = __ballot(push);
+                if (vis && sk == 0u)
+                    seed_of[k] = (int32_t)seed;  // first touch; later touches carry the same seed
+                if (absorb)
+                    ST_OR(k, 2u);
+                if (push)
+                {
+                    const uint32_t qi = qt + __popcll(pm & lt);
+                    q[qi] = k;
+                    sh.ring[qi % RP_RING] = k;
+                    ST_OR(k, 1u);
+                }
+                qt += __popcll(pm);
+                if (!STATE_LDS)
+                    __threadfence_block();  // the next step reads states written by other lanes
+            };
+            while (qh < qt)
+            {
+                // a window of up to 64 pops; which of them the reference expands is decided in registers (see
+                // replay_lds_kernel): a candidate is skipped iff it is removed already or an EXPANDED earlier
+                // candidate of the window holds it within the absorb radius
+                const uint32_t wb = qh;
+                const uint32_t wn = min((uint32_t)WAVE, qt - qh);
+                const bool inw = lane < wn;
+                uint32_t wcand;
+                if (qt - qh <= (uint32_t)RP_RING)
+                    wcand = inw ? sh.ring[(wb + lane) % RP_RING] : 0u;
+                else
+                {
+                    __threadfence_block();
+                    wcand = inw ? q[wb + lane] : 0u;
+                }
+                const bool alive = inw && !(ST_GET(wcand) & 2u);
+                const uint32_t ci = alive ? wcand : 0u;
+                const float wx = OX[ci], wy = OY[ci], wz = OZ[ci];
+                unsigned long long am = __ballot(alive), em = 0;
+                while (am)
+                {
+                    const int h = __ffsll((long long)am) - 1;
+                    em |= 1ull << h;
+                    const float hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), h));
+                    const float hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), h));
+                    const float hz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), h));
+                    const float d0 = hx - wx, d1 = hy - wy, d2 = hz - wz;
+                    const float dist = d0 * d0 + (d1 * d1 + (d2 * d2 + 0.0f));  // dist_sqr(points_[h], node)
+                    const bool conflict = alive && dist <= r2 && dist <= thr_f;
+                    am &= ~__ballot(conflict);
+                    am &= ~(1ull << h);
+                }
+                qh = wb + wn;
+                if (!em)
+                    continue;
+                // publish the expansions of the window
+                const uint32_t E = (uint32_t)__popcll(em);
+                if ((em >> lane) & 1ull)
+                {
+                    const uint32_t e = (uint32_t)__popcll(em & lt);
+                    sh.ej[e] = wcand;
+                    sh.ex[e] = wx;
+                    sh.ey[e] = wy;
+                    sh.ez[e] = wz;
+                }
+                if (lane == 0)
+                    sh.ctl[0] = E;
+                __syncthreads();  // A
+                uint32_t fill = 0;
+                for (uint32_t e = 0; e < E; e += RS_WAVES)
+                    fill = search_to_lds(e, fill);
+                __syncthreads();  // B
+                st_exp += E;
+                for (uint32_t e = 0; e < E; ++e)
+                {
+                    const uint32_t len = sh.elen[e];
+                    if (len == RS_OVERFLOW)
+                    {
+                        // did not fit its region: search again, streaming every chunk step into the apply
+                        unsigned long long before = touches;
+                        rs_search(PR, chunks, grp_of[sh.ej[e]], sh.ex[e], sh.ey[e], sh.ez[e], r2, thr_f, lane, st_cand,
+                                  [&](uint32_t word) -> bool {
+                                      st_entries += __popcll(__ballot(word != 0xffffffffu));
+                                      apply(word);
+                                      return true;
+                                  });
+                        (void)before;
+                        continue;
+                    }
+                    st_entries += len;
+                    const uint32_t *src = sh.lists + sh.eoff[e];
+                    for (uint32_t t0 = 0; t0 < len; t0 += WAVE)
+                        apply(t0 + lane < len ? src[t0 + lane] : 0xffffffffu);
+                }
+            }
+            if (lane == 0)
+                valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;  // :113
+        }
+    }
+    if (lane == 0)
+        sh.ctl[0] = RS_DONE;
+    __syncthreads();  // A: releases the helper wavefronts
+    if (lane == 0)
+    {
+        if (st_exp)
+        {
+            atomicAdd((unsigned long long *)&fstate->replay_entries, st_entries);
+            atomicAdd(&fstate->n_expansions, st_exp);
+        }
+        if (st_cand)
+            atomicAdd((unsigned long long *)&fstate->cand_total, st_cand);
+    }
+#undef ST_GET
+#undef ST_OR
+}
+
 __global__ void relabel_kernel(FrameState *frame, const int32_t *__restrict__ seed_of,
                                const uint32_t *__restrict__ valid, const uint32_t *__restrict__ dense,
                                int32_t *__restrict__ labels, uint64_t cap, const uint64_t *__restrict__ total,
@@ -784,19 +1146,30 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     prm.r2 = cfg->distance_squared;
     prm.min_size = cfg->min_cluster_size;
     prm.max_size = cfg->max_cluster_size;
-    rc = lpx_neighbours(ctx, m_max, cfg->distance_squared, prm.thr_f, true);
-    if (rc)
-        return rc;
-
     const dim3 blk(256), grd((m_max + 255) / 256, 1, ctx->cur_b);
     uint32_t *root = (uint32_t *)ctx->key_a.p, *iota = (uint32_t *)ctx->val_a.p;
     uint32_t *sroot = nullptr, *members = nullptr;
     uint32_t *cc_lo = (uint32_t *)ctx->cc_lo.p, *cc_hi = (uint32_t *)ctx->cc_hi.p;
     uint32_t *valid = (uint32_t *)ctx->valid.p;
+    if (ctx->use_lists)
+    {
+        // round-1 path: every radius list materialised, components by union-find over the lists
+        rc = lpx_neighbours(ctx, m_max, cfg->distance_squared, prm.thr_f, true);
+        if (rc)
+            return rc;
+    }
+    else
+    {
+        // expansion-driven path: candidate chunks per kd group, components from the uniform grid
+        if ((rc = lpx_group_index(ctx, m_max, cfg->distance_squared)) ||
+            (rc = lpx_grid_components(ctx, m_max, cfg->distance_squared, root, iota)))
+            return rc;
+    }
     {
         StageTimer tm(ctx, ST_CC);
-        hipLaunchKernelGGL(flatten_kernel, grd, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
-                           (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, fv.fs);
+        if (ctx->use_lists)
+            hipLaunchKernelGGL(flatten_kernel, grd, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
+                               (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, fv.fs);
         rc = lpx_sort_pairs(ctx, root, (uint32_t *)ctx->key_b.p, iota, (uint32_t *)ctx->val_b.p, m_max,
                             &frame->n_obstacle, bits_for_count(m_max), &sroot, &members);
         if (rc)
@@ -804,6 +1177,37 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, sroot, frame, cc_lo, cc_hi, (uint32_t *)ctx->rpos.p,
                            fv.fs);
     }
+    if (!ctx->use_lists)
+    {
+        StageTimer tm(ctx, ST_REPLAY);
+        const size_t fixed = sizeof(RsShared);
+        const size_t lds_bitmap = fixed + sizeof(uint32_t) * (((size_t)m_max + 15) / 16 + 4);
+        const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: workgroups pull component sets from a list
+        if (!ctx->attr_search)
+        {
+            LPX_HIP(ctx, hipFuncSetAttribute((const void *)replay_search_kernel<true>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            LPX_HIP(ctx, hipFuncSetAttribute((const void *)replay_search_kernel<false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            ctx->attr_search = true;
+        }
+        if (lds_bitmap <= 152 * 1024)
+            hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS), lds_bitmap, st,
+                               (const FrameState *)frame, (const uint32_t *)cc_lo, (const uint32_t *)cc_hi,
+                               (const uint32_t *)members, (const KdNode *)ctx->nodes_pre.p, (const uint2 *)ctx->chunks.p,
+                               (const uint32_t *)ctx->grp_of.p, (const float *)ctx->OX.p, (const float *)ctx->OY.p,
+                               (const float *)ctx->OZ.p, (uint8_t *)ctx->state.p, (int32_t *)ctx->seed_of.p,
+                               (uint32_t *)ctx->queue.p, valid, prm, frame, (const uint32_t *)ctx->rpos.p, fv);
+        else
+            hipLaunchKernelGGL(replay_search_kernel<false>, dim3(m_max < 4096u ? m_max : 4096u, 1, ctx->cur_b),
+                               dim3(RS_THREADS), fixed, st, (const FrameState *)frame, (const uint32_t *)cc_lo,
+                               (const uint32_t *)cc_hi, (const uint32_t *)members, (const KdNode *)ctx->nodes_pre.p,
+                               (const uint2 *)ctx->chunks.p, (const uint32_t *)ctx->grp_of.p, (const float *)ctx->OX.p,
+                               (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (uint8_t *)ctx->state.p,
+                               (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, frame,
+                               (const uint32_t *)ctx->rpos.p, fv);
+    }
+    else
     {
         StageTimer tm(ctx, ST_REPLAY);
         const size_t lds = sizeof(uint32_t) * (((((size_t)m_max + 15) / 16 + 3) & ~(size_t)3) + RP_RING);

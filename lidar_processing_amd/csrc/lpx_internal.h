@@ -45,9 +45,10 @@ struct FrameState
     uint32_t n_expansions;    // radius_search calls the reference would have made
     uint32_t n_in;            // points of the input cloud of this frame slot
     uint32_t has_far;         // some coordinate has |v| >= 2048 m: the plane kernels take the wide-moment path for it
-    uint32_t pad0;
+    uint32_t max_abs_bits;    // bit pattern of the largest |coordinate| of the input cloud (sizes the component grid)
     uint64_t nb_entries;      // neighbour entries written (sum of the list lengths)
     uint64_t rs_total;        // words asked from the single-pass region [cap_nb, cap_nb + cap_rs)
+    uint64_t cand_total;      // candidates distance-tested by the replay's searches (expansion-driven path)
 };
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
@@ -79,6 +80,7 @@ struct Buf
 // `upitch` elements per frame.  With one frame everything is offset 0.
 // ------------------------------------------------------------------------------------------------
 #define LPX_SORT_TILE 2048u  // keys per radix-sort block (lpx_primitives.hip)
+#define LPX_GROUP_CHUNKS 64u // candidate chunks kept per kd group: one per lane of the searching wavefront
 
 struct FV
 {
@@ -142,6 +144,14 @@ struct lpx_ctx
     Buf queue;                 // u32
     Buf valid;                 // u32 per seed
     Buf d_clabels;
+    // ---- expansion-driven search (default path): no neighbour lists at all ----
+    Buf grp_of;                // u32 per point: kd group (bucket or upper node) the point is a query of
+    Buf chunks;                // uint2 [groups][LPX_GROUP_CHUNKS]: candidate chunks (pre-order rank, count) of a group
+    Buf cell_key;              // u64 [cell_cap]: occupied cells of the component grid (open addressing)
+    Buf cell_rep, cell_parent; // u32 [cell_cap]: a point of the cell / union-find over cells
+    Buf cell_of;               // u32 per point: its cell slot
+    uint32_t cell_cap = 0;     // slots per frame slot (power of two >= 2 * cap_n)
+    bool use_lists = false;    // lpx_dbg_use_lists: materialise every radius list (the round-1 path, kept for tests)
     Buf frame;                 // FrameState
     // ---- pinned host staging ----
     void *h_pinned = nullptr;
@@ -149,7 +159,7 @@ struct lpx_ctx
 
     void *dbg_buf = nullptr;   // optional per-group statistics of the neighbour kernel (tools only)
     Buf dbg_store;
-    bool attr_kd = false, attr_replay = false;  // hipFuncSetAttribute done for this context's device
+    bool attr_kd = false, attr_replay = false, attr_search = false;  // hipFuncSetAttribute done for this context's device
     bool exact_lists_only = false;  // capacity retry: count every list, so nb_total is the exact requirement
 
     // profiling
@@ -246,6 +256,11 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max);
 // thr_f: absorb threshold of the clustering (largest float <= (1-q)^2 d^2), stored as bit 31 of every list
 // word; hook: also build the connected components
 int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hook);
+// expansion-driven path: candidate chunks per kd group + the point -> group map; components from a uniform grid
+int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2);
+int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota);
+// the neighbour-list workspace is only allocated for the list path
+int lpx_ensure_lists(lpx_ctx *ctx);
 
 // ------------------------------------------------------------------------------------------------
 // device helpers

@@ -1532,6 +1532,343 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Expansion-driven search, part 1: the candidate chunks of every kd group.
+//
+// The greedy loop of the reference expands (calls radius_search on) only ~15-20 % of the points; the rest are
+// absorbed.  Instead of materialising every radius list, the replay (lpx_cluster.hip) searches for a point when
+// it expands it.  What CAN be prepared for all points at once is the traversal: one wavefront per kd group (a
+// bucket subtree of <= 64 nodes, or one node above the bucket level) walks the top levels for the group's box
+// (+ radius) exactly like the list kernel does and leaves the candidate set as <= 64 CHUNKS of consecutive
+// pre-order ranks, <= 64 nodes each, in pre-order: chunks[gid][lane] = (rank, count).  A search then costs
+// one 512-byte load of the chunk table and one 16-byte load per candidate, all independent.  If a group has more
+// chunks than lanes the last one is long (covers the rest of the rank range, gaps included: nodes the traversal
+// pruned fail the distance test anyway).  grp_of[point] = gid.
+// ------------------------------------------------------------------------------------------------
+constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B + prefix = 4.6 KiB)
+
+__global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__restrict__ PR,
+                                                               const FrameState *__restrict__ frame, float rr,
+                                                               uint2 *__restrict__ chunks,
+                                                               uint32_t *__restrict__ grp_of, FV fv)
+{
+    __shared__ Item s_seq[NB_WAVES][2 * IX_CAPS];
+    __shared__ uint32_t s_pre[NB_WAVES][IX_CAPS + 8];
+    __shared__ uint32_t s_mrank[NB_WAVES][IX_CAPS + 8], s_mpre[NB_WAVES][IX_CAPS + 8];
+    __shared__ uint2 s_out[NB_WAVES][LPX_GROUP_CHUNKS];
+    PR = lpx_slot(PR, fv.fs);
+    frame = lpx_slot(frame, fv.fs);
+    chunks = lpx_slot(chunks, fv.fs);
+    grp_of = lpx_slot(grp_of, fv.fs);
+    const uint32_t w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const uint32_t M = frame->n_obstacle;
+    if (M == 0)
+        return;
+    uint32_t D = 0;
+    while ((M >> D) > (uint32_t)NB_BUCKET)
+        ++D;
+    const uint32_t nbk = 1u << D;
+    const uint32_t gid = blockIdx.x * NB_WAVES + w;  // [0, nbk): buckets; [nbk, 2 nbk - 1): upper nodes
+    if (gid >= 2 * nbk - 1)
+        return;
+    uint32_t level, path;
+    if (gid < nbk)
+    {
+        level = D;
+        path = gid;
+    }
+    else
+    {
+        const uint32_t u = gid - nbk;
+        level = 31 - __clz(u + 1);
+        path = u + 1 - (1u << level);
+    }
+    uint32_t gb = 0, ge = M, grank = 0;
+    for (int d = (int)level - 1; d >= 0; --d)
+    {
+        if (gb >= ge)
+            break;
+        const uint32_t mid = gb + (ge - gb) / 2;
+        if ((path >> d) & 1u)
+        {
+            grank += 1 + (mid - gb);
+            gb = mid + 1;
+        }
+        else
+        {
+            grank += 1;
+            ge = mid;
+        }
+    }
+    if (gb >= ge)
+        return;
+    const uint32_t nq = __builtin_amdgcn_readfirstlane(gid < nbk ? (ge - gb) : 1u);
+    const bool active = lane < nq;
+    const Node q = PR[grank + (active ? lane : 0u)];
+    if (active)
+        grp_of[__float_as_uint(q.w)] = gid;
+    float blo[3] = {q.x, q.y, q.z}, bhi[3] = {q.x, q.y, q.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            blo[a] = fminf(blo[a], __shfl_xor(blo[a], o, 64));
+            bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], o, 64));
+        }
+        blo[a] -= rr;
+        bhi[a] += rr;
+        blo[a] -= fabsf(blo[a]) * 2.4e-7f;  // two ulps: far from the origin the rounding beats any fixed margin
+        bhi[a] += fabsf(bhi[a]) * 2.4e-7f;
+    }
+    Item *cur = nullptr;
+    uint32_t T = 0;
+    uint32_t *pre = s_pre[w];
+    const uint32_t n_cur = nb_traverse(PR, M, D, blo, bhi, s_seq[w], IX_CAPS, pre, lane, &cur, &T);
+    // merge items with consecutive ranks into runs: run starts where the rank does not continue the previous item
+    uint32_t n_runs = 0;
+    for (uint32_t c0 = 0; c0 < n_cur; c0 += WAVE)
+    {
+        const uint32_t i = c0 + lane;
+        const bool valid = i < n_cur;
+        bool start = false;
+        uint32_t rank = 0;
+        if (valid)
+        {
+            rank = cur[i].rank;
+            const uint32_t cnt_prev = i ? pre[i] - pre[i - 1] : 0u;
+            start = (i == 0) || (cur[i - 1].rank + cnt_prev != rank);
+        }
+        const unsigned long long sm = __ballot(start);
+        if (start)
+        {
+            const uint32_t m = n_runs + (uint32_t)__popcll(sm & lpx_lanemask_lt());
+            s_mrank[w][m] = rank;
+            s_mpre[w][m] = pre[i];
+        }
+        n_runs += (uint32_t)__popcll(sm);
+    }
+    if (lane == 0)
+        s_mpre[w][n_runs] = T;
+    Coop<WAVE>::sync();
+    // cut every run into chunks of <= 64 ranks; chunk c of run m starts at rank + 64 c.  Chunks 0 .. 62 are stored as
+    // they are; everything from chunk 63 on becomes ONE tail chunk that starts at the lowest of their ranks
+    s_out[w][lane] = make_uint2(lane == LPX_GROUP_CHUNKS - 1 ? 0xffffffffu : 0u, 0u);
+    Coop<WAVE>::sync();
+    uint32_t n_chunks = 0;
+    for (uint32_t c0 = 0; c0 < n_runs; c0 += WAVE)
+    {
+        const uint32_t m = c0 + lane;
+        const bool valid = m < n_runs;
+        const uint32_t len = valid ? s_mpre[w][m + 1] - s_mpre[w][m] : 0u;
+        const uint32_t nc = (len + 63) / 64;
+        const uint32_t incl = lpx_wave_incl_scan_u32(nc);
+        uint32_t pos = n_chunks + incl - nc;
+        const uint32_t rank = valid ? s_mrank[w][m] : 0u;
+        for (uint32_t c = 0; c < nc; ++c, ++pos)
+        {
+            const uint32_t cr = rank + 64 * c, cc = min(64u, len - 64 * c);
+            if (pos < LPX_GROUP_CHUNKS - 1)
+                s_out[w][pos] = make_uint2(cr, cc);
+            else
+                atomicMin(&s_out[w][LPX_GROUP_CHUNKS - 1].x, cr);
+        }
+        n_chunks += __builtin_amdgcn_readfirstlane(__shfl(incl, WAVE - 1, 64));
+    }
+    Coop<WAVE>::sync();
+    if (lane == 0)
+    {
+        if (n_chunks >= LPX_GROUP_CHUNKS)
+        {
+            // [first rank of chunk 63, end of the last run): may be longer than 64 and may span pruned subtrees
+            // (their nodes fail the distance test), the search loops over it
+            const uint32_t first = s_out[w][LPX_GROUP_CHUNKS - 1].x;
+            const uint32_t last_end = s_mrank[w][n_runs - 1] + (s_mpre[w][n_runs] - s_mpre[w][n_runs - 1]);
+            s_out[w][LPX_GROUP_CHUNKS - 1] = make_uint2(first, last_end - first);
+        }
+        else
+            s_out[w][LPX_GROUP_CHUNKS - 1] = make_uint2(0u, 0u);
+    }
+    Coop<WAVE>::sync();
+    chunks[(size_t)gid * LPX_GROUP_CHUNKS + lane] = s_out[w][lane];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Expansion-driven search, part 2: components WITHOUT neighbour lists.
+//
+// The replay only needs a partition of the points into sets that no BFS can leave, i.e. unions of connected
+// components of the d-graph (replaying a union of components in ascending seed order reproduces the reference's
+// labels exactly: seeds of different components never interact).  A uniform grid of cells with edge c >= d gives
+// one for free: two points within d lie in the same or in adjacent cells (26-neighbourhood), so the connected
+// components of the OCCUPIED-CELL adjacency graph are such unions -- no distance is ever computed.  On the
+// reference's frames this partition is barely coarser than the exact one (the largest set holds 1.2-1.8 x the
+// expansions of the largest true component, tools/cc_analysis.py) and costs ~7k cells x 13 lookups per frame.
+// Cell edge: c = 1.01 d + X 2^-18 with X the largest |coordinate| of the frame, which keeps the float rounding
+// of floor(v / c) from ever putting two points within d more than one cell apart; indices saturate at +-2^20
+// cells (saturation is monotone, so adjacency is preserved).  Open-addressing table keyed by the packed index
+// triple; union-find over table slots (smaller slot wins); the representative of a cell is the point that
+// claimed it.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long CELL_EMPTY = ~0ull;
+
+__device__ __forceinline__ uint32_t cell_hash(unsigned long long k)
+{
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+__device__ __forceinline__ uint32_t cell_cap_for(uint32_t M, uint32_t cap_max)
+{
+    uint32_t cap = 64;
+    while (cap < 2 * M && cap < cap_max)
+        cap <<= 1;
+    return cap;
+}
+
+__device__ __forceinline__ float cell_inv_edge(float d, const FrameState *frame)
+{
+    const float X = __uint_as_float(frame->max_abs_bits);
+    return 1.0f / (d * 1.01f + X * 3.8146973e-6f);  // 2^-18
+}
+
+__device__ __forceinline__ uint32_t cell_coord(float v, float inv_c)
+{
+    const float f = fminf(fmaxf(floorf(v * inv_c), -1048576.0f), 1048575.0f);
+    return (uint32_t)((int)f + 1048576);  // 21 bits
+}
+
+__global__ void grid_clear_kernel(const FrameState *__restrict__ frame, unsigned long long *__restrict__ tkey,
+                                  uint32_t *__restrict__ tparent, uint32_t cap_max, size_t fs)
+{
+    frame = lpx_slot(frame, fs);
+    tkey = lpx_slot(tkey, fs);
+    tparent = lpx_slot(tparent, fs);
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cell_cap_for(frame->n_obstacle, cap_max) || frame->n_obstacle == 0)
+        return;
+    tkey[s] = CELL_EMPTY;
+    tparent[s] = s;
+}
+
+__global__ void grid_insert_kernel(const FrameState *__restrict__ frame, const float *__restrict__ OX,
+                                   const float *__restrict__ OY, const float *__restrict__ OZ, float d,
+                                   unsigned long long *tkey, uint32_t *__restrict__ trep,
+                                   uint32_t *__restrict__ cell_of, uint32_t cap_max, size_t fs)
+{
+    frame = lpx_slot(frame, fs);
+    OX = lpx_slot(OX, fs);
+    OY = lpx_slot(OY, fs);
+    OZ = lpx_slot(OZ, fs);
+    tkey = lpx_slot(tkey, fs);
+    trep = lpx_slot(trep, fs);
+    cell_of = lpx_slot(cell_of, fs);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = frame->n_obstacle;
+    if (i >= M)
+        return;
+    const uint32_t mask = cell_cap_for(M, cap_max) - 1;
+    const float inv_c = cell_inv_edge(d, frame);
+    const unsigned long long key = ((unsigned long long)cell_coord(OX[i], inv_c) << 42) |
+                                   ((unsigned long long)cell_coord(OY[i], inv_c) << 21) |
+                                   (unsigned long long)cell_coord(OZ[i], inv_c);
+    uint32_t h = cell_hash(key) & mask;
+    for (;;)
+    {
+        const unsigned long long old = atomicCAS(tkey + h, CELL_EMPTY, key);
+        if (old == CELL_EMPTY)
+        {
+            trep[h] = i;  // this point claimed the cell: it represents it
+            break;
+        }
+        if (old == key)
+            break;
+        h = (h + 1) & mask;
+    }
+    cell_of[i] = h;
+}
+
+__global__ void grid_link_kernel(const FrameState *__restrict__ frame, const unsigned long long *__restrict__ tkey,
+                                 uint32_t *tparent, uint32_t cap_max, size_t fs)
+{
+    frame = lpx_slot(frame, fs);
+    tkey = lpx_slot(tkey, fs);
+    tparent = lpx_slot(tparent, fs);
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = frame->n_obstacle;
+    if (M == 0)
+        return;
+    const uint32_t cap = cell_cap_for(M, cap_max), mask = cap - 1;
+    if (s >= cap)
+        return;
+    const unsigned long long key = tkey[s];
+    if (key == CELL_EMPTY)
+        return;
+    const int ix = (int)(key >> 42), iy = (int)((key >> 21) & 0x1fffffu), iz = (int)(key & 0x1fffffu);
+    // the 13 neighbours that follow (0, 0, 0) lexicographically: every adjacent pair is met from one side
+    for (int t = 14; t < 27; ++t)
+    {
+        const int nx = ix + t / 9 - 1, ny = iy + (t / 3) % 3 - 1, nz = iz + t % 3 - 1;
+        if ((unsigned)nx > 0x1fffffu || (unsigned)ny > 0x1fffffu || (unsigned)nz > 0x1fffffu)
+            continue;
+        const unsigned long long nk = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) |
+                                      (unsigned long long)nz;
+        uint32_t h = cell_hash(nk) & mask;
+        for (;;)
+        {
+            const unsigned long long k2 = tkey[h];
+            if (k2 == CELL_EMPTY)
+                break;
+            if (k2 == nk)
+            {
+                uf_unite(tparent, s, h);
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+    }
+}
+
+// root[i] = representative point of the set of point i (same word for all its members), iota, replay state reset
+__global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *tparent,
+                                    const uint32_t *__restrict__ trep, const uint32_t *__restrict__ cell_of,
+                                    uint32_t *__restrict__ root, uint32_t *__restrict__ iota,
+                                    uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
+                                    uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi, size_t fs)
+{
+    frame = lpx_slot(frame, fs);
+    tparent = lpx_slot(tparent, fs);
+    trep = lpx_slot(trep, fs);
+    cell_of = lpx_slot(cell_of, fs);
+    root = lpx_slot(root, fs);
+    iota = lpx_slot(iota, fs);
+    state = lpx_slot(state, fs);
+    valid = lpx_slot(valid, fs);
+    cc_lo = lpx_slot(cc_lo, fs);
+    cc_hi = lpx_slot(cc_hi, fs);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame->n_obstacle)
+        return;
+    uint32_t x = cell_of[i];
+    for (;;)
+    {
+        const uint32_t p = __hip_atomic_load(tparent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x)
+            break;
+        x = p;
+    }
+    root[i] = trep[x];
+    iota[i] = i;
+    state[i] = 0;
+    valid[i] = 0;
+    cc_lo[i] = 0;
+    cc_hi[i] = 0;
+}
+
 __global__ void layout_idx_kernel(const Node *__restrict__ nodes, uint32_t m, uint32_t *__restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1632,6 +1969,50 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
                                frame, (uint32_t *)ctx->parent.p, ctx->fstride);
         }
     }
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
+{
+    if (m_max == 0)
+        return LPX_OK;
+    StageTimer tm(ctx, ST_NB_FILL);
+    const float rr = sqrtf(r2) * 1.0001f + 1.0e-3f;
+    uint32_t dmax = 0;
+    while ((m_max >> dmax) > (uint32_t)NB_BUCKET)
+        ++dmax;
+    const uint32_t groups = (2u << dmax) - 1;
+    if (sizeof(uint2) * LPX_GROUP_CHUNKS * (size_t)groups > ctx->chunks.bytes)
+        return lpx_fail(ctx, LPX_ERR_INTERNAL, "chunk table of %u groups does not fit the workspace", groups);
+    hipLaunchKernelGGL(nb_index_kernel, dim3((groups + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b), dim3(NB_THREADS), 0,
+                       ctx->stream, (const Node *)ctx->nodes_pre.p, (const FrameState *)ctx->frame.p, rr,
+                       (uint2 *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, lpx_fv(ctx));
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota)
+{
+    if (m_max == 0)
+        return LPX_OK;
+    StageTimer tm(ctx, ST_NB_SCAN);
+    const FrameState *frame = (const FrameState *)ctx->frame.p;
+    uint32_t cap = 64;
+    while (cap < 2 * m_max && cap < ctx->cell_cap)
+        cap <<= 1;
+    const dim3 blk(256), gc((cap + 255) / 256, 1, ctx->cur_b), gm((m_max + 255) / 256, 1, ctx->cur_b);
+    unsigned long long *tkey = (unsigned long long *)ctx->cell_key.p;
+    uint32_t *tparent = (uint32_t *)ctx->cell_parent.p, *trep = (uint32_t *)ctx->cell_rep.p;
+    hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, ctx->cell_cap, ctx->fstride);
+    hipLaunchKernelGGL(grid_insert_kernel, gm, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
+                       (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, trep,
+                       (uint32_t *)ctx->cell_of.p, ctx->cell_cap, ctx->fstride);
+    hipLaunchKernelGGL(grid_link_kernel, gc, blk, 0, ctx->stream, frame, (const unsigned long long *)tkey, tparent,
+                       ctx->cell_cap, ctx->fstride);
+    hipLaunchKernelGGL(grid_flatten_kernel, gm, blk, 0, ctx->stream, frame, tparent, (const uint32_t *)trep,
+                       (const uint32_t *)ctx->cell_of.p, d_root, d_iota, (uint8_t *)ctx->state.p,
+                       (uint32_t *)ctx->valid.p, (uint32_t *)ctx->cc_lo.p, (uint32_t *)ctx->cc_hi.p, ctx->fstride);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

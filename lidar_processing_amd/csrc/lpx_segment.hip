@@ -69,7 +69,8 @@ __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacl
         f.n_expansions = 0;
         f.n_in = n.v[blockIdx.z];
         f.has_far = 0;
-        f.pad0 = 0;
+        f.max_abs_bits = 0;
+        f.cand_total = 0;
         f.nb_entries = 0;
         f.rs_total = 0;
         *frame = f;
@@ -125,20 +126,25 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
     frame = lpx_slot(frame, fv.fs);
     nodes = lpx_slot(nodes, fv.fs);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= frame->n_in)
-        return;
-    const char *p = pts + (size_t)i * stride;
-    const float x = ld_f32<ALIGNED>(p + off.x), y = ld_f32<ALIGNED>(p + off.y), z = ld_f32<ALIGNED>(p + off.z);
-    X[i] = x;
-    Y[i] = y;
-    Z[i] = z;
-    if (key)
+    const bool in = i < frame->n_in;  // no early return: the wavefront reduces at the end
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    if (in)
     {
-        key[i] = lpx_float_key(x);
-        val[i] = i;
+        const char *p = pts + (size_t)i * stride;
+        x = ld_f32<ALIGNED>(p + off.x);
+        y = ld_f32<ALIGNED>(p + off.y);
+        z = ld_f32<ALIGNED>(p + off.z);
+        X[i] = x;
+        Y[i] = y;
+        Z[i] = z;
+        if (key)
+        {
+            key[i] = lpx_float_key(x);
+            val[i] = i;
+        }
+        if (nodes)
+            nodes[i] = make_float4(x, y, z, __uint_as_float(i));
     }
-    if (nodes)
-        nodes[i] = make_float4(x, y, z, __uint_as_float(i));
     // Any finite cloud is processed like the reference does (src/segmentation.cpp:311-345).  NaN / Inf are
     // undefined behaviour upstream (comparators) and flag the frame.  Coordinates beyond +-2048 m leave the
     // int32 fixed-point range of the moment fast path: the plane kernels give those points the wide path.
@@ -151,6 +157,14 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
     }
     else if (!(amax < FIX_LIMIT))
         frame->has_far = 1u;
+    // largest |coordinate| of the frame (sizes the cells of the component grid so that float rounding of a cell
+    // index cannot separate two points within the radius): one atomic per wavefront, and only while its maximum
+    // still beats the value it reads (finite non-negative floats order like their bit patterns)
+    const float wm = lpx_wave_max63_f32(nonfinite == 0.0f ? amax : 0.0f);
+    const uint32_t wmax = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(wm), WAVE - 1);
+    if ((threadIdx.x % WAVE) == 0 &&
+        wmax > __hip_atomic_load(&frame->max_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&frame->max_abs_bits, wmax);
 }
 
 // ------------------------------------------------------------------------------------------------

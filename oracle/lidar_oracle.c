@@ -837,6 +837,8 @@ int orc_radius_search(const float *xyz, uint32_t m, const float *target, float r
 /* Clusterer::cluster, src/clustering.cpp:47-125                                               */
 /* ------------------------------------------------------------------------------------------ */
 
+static uint8_t *g_trace_expanded = NULL; /* analysis only: which points had radius_search called on them */
+
 int orc_cluster_stats(const void *pts, size_t stride, uint32_t m, const orc_clu_cfg *cfg, int32_t *labels,
                       uint32_t *n_clusters, uint64_t *n_expansions, uint64_t *n_visits)
 {
@@ -881,6 +883,8 @@ int orc_cluster_stats(const void *pts, size_t stride, uint32_t m, const orc_clu_
                 continue;
             const uint32_t cnt = kd_radius_search(nodes, m, xyz + 3 * (size_t)j, cfg->distance_squared, neigh, stack);
             ++expansions;
+            if (g_trace_expanded)
+                g_trace_expanded[j] = 1;
             for (uint32_t t = 0; t < cnt; ++t)
             {
                 const uint32_t k = neigh[t].idx;
@@ -923,6 +927,17 @@ int orc_cluster_stats(const void *pts, size_t stride, uint32_t m, const orc_clu_
     free(nodes);
     free(xyz);
     return ORC_OK;
+}
+
+/* analysis helper (tools/): expanded[i] = 1 iff the loop called radius_search on point i */
+int orc_cluster_trace(const void *pts, size_t stride, uint32_t m, const orc_clu_cfg *cfg, int32_t *labels,
+                      uint32_t *n_clusters, uint8_t *expanded)
+{
+    memset(expanded, 0, m);
+    g_trace_expanded = expanded;
+    const int rc = orc_cluster_stats(pts, stride, m, cfg, labels, n_clusters, NULL, NULL);
+    g_trace_expanded = NULL;
+    return rc;
 }
 
 int orc_cluster(const void *pts, size_t stride, uint32_t m, const orc_clu_cfg *cfg, int32_t *labels,

@@ -233,6 +233,29 @@ def test_cluster_real_frames_vs_reference_golden(ctx, frame, sname, skw, cname, 
     assert np.array_equal(lab, want)
 
 
+@pytest.mark.parametrize("frame", FRAMES)
+def test_list_path_and_search_path_agree(frame):
+    """the round-1 path (every radius list materialised) and the expansion-driven default give the labels of the
+    reference build, and the search tests far fewer candidates than the lists hold entries"""
+    from lidar_processing_amd import Context
+    pts = load_frame(frame)
+    skw = dict(number_of_planar_partitions=6, number_of_iterations=5)
+    want = gold()[f"clu_{frame}_p6i5_d025q05_labels"]
+    stats = {}
+    for lists in (True, False):
+        c = Context(0)
+        try:
+            c.use_lists(lists)
+            out = c.segment_cluster(pts, SegmentationConfiguration(**skw), ClusteringConfiguration(0.25, 0.5))
+            assert np.array_equal(out["cluster_labels"], want), f"lists={lists}"
+            stats[lists] = c.frame_stats()
+        finally:
+            c.close()
+    assert stats[True]["expansions"] == stats[False]["expansions"]          # the same radius_search calls
+    assert stats[True]["replay_entries"] == stats[False]["replay_entries"]  # ... returning the same neighbours
+    assert stats[False]["components"] <= stats[True]["components"]         # grid sets are unions of components
+
+
 def test_cluster_exact_ec_quality_one(ctx):
     pts = load_frame("0000000000")
     obs = pts[oracle.segment(pts)["obstacle_idx"]]
@@ -302,6 +325,7 @@ def test_cluster_dense_neighbour_workspace_grows(ctx):
     obs[:, :3] = rng.random((3000, 3)) * 0.3
     from lidar_processing_amd import Context
     c = Context(0)
+    c.use_lists(True)  # the workspace in question belongs to the list path
     c.reserve(3000, 8)
     lab, nc = c.cluster(obs, ClusteringConfiguration(0.18, 0.5))
     want, wn = oracle.cluster(obs, oracle.CluCfg(0.18, 0.5))
@@ -321,6 +345,7 @@ def test_workspace_retry_keeps_the_tree_of_the_first_attempt(frame):
     want = g[f"clu_{frame}_p6i5_d025q05_labels"]
     c = Context(0)
     try:
+        c.use_lists(True)
         c.reserve(pts.shape[0], 4)
         out = c.segment_cluster(pts, SegmentationConfiguration(**skw), ClusteringConfiguration(0.25, 0.5))
         assert np.array_equal(out["cluster_labels"], want)
@@ -329,6 +354,7 @@ def test_workspace_retry_keeps_the_tree_of_the_first_attempt(frame):
         c.close()
     c = Context(0)
     try:
+        c.use_lists(True)
         c.reserve(pts.shape[0], 4)
         lab, nc = c.cluster(pts[out["obstacle_idx"]], ClusteringConfiguration(0.25, 0.5))
         assert np.array_equal(lab, want) and nc == int(g[f"clu_{frame}_p6i5_d025q05_n"][0])
@@ -346,6 +372,7 @@ def test_single_pass_region_never_changes_results(words):
     obs = pts[oracle.segment(pts, oracle.SegCfg(number_of_planar_partitions=6, number_of_iterations=5))["obstacle_idx"]]
     c = Context(0)
     try:
+        c.use_lists(True)
         c.reserve_single_pass(words)
         c.reserve(obs.shape[0])
         lab, nc = c.cluster(obs, ClusteringConfiguration(0.25, 0.5))
