@@ -39,6 +39,10 @@ int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out12);
 /* plane from points through the device moment/Jacobi path */
 int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane);
 
+/* expansion-driven search counters of frame slot `slot`: out[4] = {candidates distance-tested lo/hi, queue windows
+ * with an expansion, searches redone by the sequencer (list larger than its LDS region)} */
+int lpx_dbg_search_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out4);
+
 /* 0 (default): expansion-driven neighbour search; 1: materialise every radius list first (round-1 path) */
 int lpx_dbg_use_lists(lpx_ctx *ctx, int on);
 

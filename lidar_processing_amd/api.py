@@ -260,9 +260,13 @@ class Context:
         o = np.zeros(12, np.uint32)
         self._L.lpx_dbg_frame_stats_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         self.check(self._L.lpx_dbg_frame_stats_slot(self._h, slot, _vp(o)))
+        s4 = np.zeros(4, np.uint32)
+        self._L.lpx_dbg_search_stats_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        self.check(self._L.lpx_dbg_search_stats_slot(self._h, slot, _vp(s4)))
         return dict(n_ground=int(o[0]), n_obstacle=int(o[1]), n_clusters=int(o[2]), status=int(o[3]),
                     neighbour_entries=int(o[4]) | (int(o[5]) << 32), components=int(o[6]), expansions=int(o[7]),
-                    replay_entries=int(o[8]) | (int(o[9]) << 32), neighbour_words=int(o[10]) | (int(o[11]) << 32))
+                    replay_entries=int(o[8]) | (int(o[9]) << 32), neighbour_words=int(o[10]) | (int(o[11]) << 32),
+                    candidates=int(s4[0]) | (int(s4[1]) << 32), windows=int(s4[2]), overflows=int(s4[3]))
 
     # ---- stage-level entry points (parity tests) ----
     def dbg_sort_pairs(self, keys, values, bits=32):

@@ -70,7 +70,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         const size_t blk_bytes = sizeof(uint32_t) * (2 * ((size_t)n / 4096 + LPX_MAX_PARTITIONS + 2) + 2);
         // expansion-driven search: at most n / 16 + 2 kd groups (2^(D+1) with n >> D <= 64), a cell table of the
         // next power of two >= 2 n slots
-        const size_t chunk_bytes = sizeof(uint2) * LPX_GROUP_CHUNKS * ((size_t)n / 16 + 64);
+        const size_t chunk_bytes = sizeof(ChunkRec) * LPX_GROUP_CHUNKS * ((size_t)n / 16 + 64);
         uint32_t cell_cap = 64;
         while ((size_t)cell_cap < 2 * (size_t)n)
             cell_cap <<= 1;
@@ -980,6 +980,21 @@ extern "C" int lpx_cluster_groups_device(lpx_ctx *ctx, const int32_t *d_labels, 
 
 // frame statistics of the last call on this context: {n_ground, n_obstacle, n_clusters, status,
 // neighbour entries (lo, hi), components, expansions, entries read by the replay (lo, hi)}
+extern "C" int lpx_dbg_search_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out4)
+{
+    if (!ctx || !out4 || slot >= ctx->batch)
+        return LPX_ERR_ARG;
+    FrameState fs;
+    LPX_HIP(ctx, hipMemcpyAsync(&fs, (const char *)ctx->frame.p + (size_t)slot * ctx->fstride, sizeof fs,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out4[0] = (uint32_t)fs.cand_total;
+    out4[1] = (uint32_t)(fs.cand_total >> 32);
+    out4[2] = fs.n_windows;
+    out4[3] = fs.n_overflow;
+    return LPX_OK;
+}
+
 extern "C" int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out12)
 {
     if (!ctx || !out12 || slot >= ctx->batch)

@@ -479,28 +479,34 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
 // Wavefront 0 is the sequencer: seeds, the queue window, the in-window expansion selection, and the ordered
 // application of every neighbour (touch / absorb / queue) to the 2-bit point states.  The expansions of a window
 // are known before any of them is applied (see replay_lds_kernel), so all four wavefronts SEARCH them in parallel
-// -- expansion e goes to wavefront e % 4 -- and leave compact, ordered hit lists (index | absorb << 31) in LDS;
-// the sequencer then applies them in expansion order.  A list that does not fit its LDS region is redone by the
-// sequencer itself, streaming candidates straight into the apply step.  A search is one load of the group's chunk
-// table and one independent 16-byte load per candidate (issued eight chunks at a time), then the reference's
-// float distance expression per candidate; hits keep candidate (= pre-order) order, so no sort is needed.
-// STATE_LDS: point states as a 2-bit LDS bitmap (fits up to ~390k points), else one byte per point in HBM.
+// (expansion e goes to wavefront e % 4): read the chunk table of the expansion's kd group, cull the chunks against
+// the query ball, load the surviving candidates (16 bytes each, independent loads, eight chunks in flight), apply
+// the reference's float distance expression and leave the hits -- index | absorb << 31, in candidate = pre-order
+// order -- in the wavefront's LDS region.  The sequencer then applies the lists in expansion order.  A list that
+// does not fit its region is redone by the sequencer itself, streaming candidates straight into the apply step.
+// (Splitting ONE search over the four wavefronts was measured and is slower: the per-search setup, not the
+// candidate tests, dominates.)
+// Point states: STATE_LDS keeps them as a 2-bit LDS bitmap of `cap_pts` points; frames with more obstacle points
+// are served by a second launch (larger bitmap, or one byte per point in HBM).  Each launch checks on the device
+// whether the frame is its own.
 // ------------------------------------------------------------------------------------------------
 constexpr int RS_WAVES = 4;
 constexpr int RS_THREADS = RS_WAVES * WAVE;
-constexpr int RS_REGION = 1536;              // words of hit-list space per wavefront and window
+constexpr int RS_REGION = 1024;              // words of hit-list space per wavefront and window
+constexpr int RS_RING = 2048;                // queue entries mirrored in LDS
 constexpr int RS_BATCH = 8;                  // candidate chunks in flight per wavefront
 constexpr uint32_t RS_OVERFLOW = 0xffffffffu;
 constexpr uint32_t RS_DONE = 0xffffffffu;
+constexpr uint32_t RS_SMALL_PTS = 65536;     // obstacle points the small-LDS launch serves (16 KiB bitmap)
 
 struct RsShared  // fixed part of the LDS of replay_search_kernel (the bitmap follows)
 {
-    uint32_t ring[RP_RING];
+    uint32_t ring[RS_RING];
     uint32_t lists[RS_WAVES * RS_REGION];
-    uint32_t ej[WAVE];           // expansions of the window: point index ...
+    uint32_t ej[WAVE], eg[WAVE];         // expansions of the window: point index, kd group ...
     float ex[WAVE], ey[WAVE], ez[WAVE];  // ... and coordinates
-    uint32_t eoff[WAVE], elen[WAVE];     // where its hit list is (words from lists[]), RS_OVERFLOW: not stored
-    uint32_t ctl[4];             // 0: number of expansions of the window / RS_DONE
+    uint32_t eoff[WAVE], elen[WAVE];     // hit list of expansion e: offset into lists[], length (RS_OVERFLOW: did not fit)
+    uint32_t ctl[4];                     // 0: number of expansions of the window / RS_DONE
 };
 
 typedef float4 KdNode;
@@ -516,28 +522,39 @@ __device__ __forceinline__ uint32_t rs_test(const KdNode &nd, bool valid, float 
     return in ? (__float_as_uint(nd.w) | (da <= thr_f ? 0x80000000u : 0u)) : 0xffffffffu;
 }
 
-// Search of one expansion by one wavefront.  SINK(word) is called for every chunk step with the per-lane list word
-// (0xffffffff for lanes without a hit) in candidate order; returns false to stop (list region full).
-template <class Sink>
-__device__ __forceinline__ bool rs_search(const KdNode *__restrict__ PR, const uint2 *__restrict__ chunks,
-                                          uint32_t gid, float qx, float qy, float qz, float r2, float thr_f,
-                                          uint32_t lane, unsigned long long &cand, Sink &&sink)
+// chunks of a kd group that can hold a neighbour of q (conservative box test): lane c answers for chunk c
+__device__ __forceinline__ unsigned long long rs_cull(const ChunkRec &ch, float qx, float qy, float qz, float r2)
 {
-    const uint2 ch = chunks[(size_t)gid * LPX_GROUP_CHUNKS + lane];  // lane c: chunk c = (rank, count)
-    const unsigned long long cm = __ballot(ch.y != 0u);
-    const uint32_t n_chunks = (uint32_t)__popcll(cm);  // chunks are packed from lane 0
-    for (uint32_t c0 = 0; c0 < n_chunks; c0 += RS_BATCH)
+    const float ex = fmaxf(fmaxf(ch.lo[0] - qx, qx - ch.hi[0]), 0.0f);
+    const float ey = fmaxf(fmaxf(ch.lo[1] - qy, qy - ch.hi[1]), 0.0f);
+    const float ez = fmaxf(fmaxf(ch.lo[2] - qz, qz - ch.hi[2]), 0.0f);
+    return __ballot(ch.count != 0u && (ex * ex + ey * ey + ez * ez) <= r2 * 1.0001f + 1.0e-6f);
+}
+
+// Tests the chunks named by the bits of `km` (lane c of `ch` describes chunk c) in order; SINK(word) gets the
+// per-lane list words of every chunk step and returns false to stop.
+template <class Sink>
+__device__ __forceinline__ bool rs_scan(const KdNode *__restrict__ PR, const ChunkRec &ch, unsigned long long km,
+                                        float qx, float qy, float qz, float r2, float thr_f, uint32_t lane,
+                                        unsigned long long &cand, Sink &&sink)
+{
+    while (km)
     {
         KdNode nd[RS_BATCH];
-        uint32_t cnt[RS_BATCH];
+        uint32_t cnt[RS_BATCH], rk[RS_BATCH];
 #pragma unroll
         for (int u = 0; u < RS_BATCH; ++u)
         {
-            const uint32_t c = c0 + u;
-            const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)ch.x, c < n_chunks ? c : 0u);
-            cnt[u] = c < n_chunks ? (uint32_t)__builtin_amdgcn_readlane((int)ch.y, c < n_chunks ? c : 0u) : 0u;
-            // unconditional load (rank 0 for idle lanes): the loads of a batch are issued back to back
-            nd[u] = PR[lane < cnt[u] ? rank + lane : 0u];
+            cnt[u] = 0u;
+            rk[u] = 0u;
+            if (km)
+            {
+                const int c = __ffsll((long long)km) - 1;
+                km &= km - 1;
+                rk[u] = (uint32_t)__builtin_amdgcn_readlane((int)ch.rank, c);
+                cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)ch.count, c);
+            }
+            nd[u] = PR[lane < cnt[u] ? rk[u] + lane : 0u];  // unconditional: the loads of a batch go out back to back
         }
 #pragma unroll
         for (int u = 0; u < RS_BATCH; ++u)
@@ -547,18 +564,14 @@ __device__ __forceinline__ bool rs_search(const KdNode *__restrict__ PR, const u
             cand += min(cnt[u], 64u);
             if (!sink(rs_test(nd[u], lane < cnt[u], qx, qy, qz, r2, thr_f)))
                 return false;
-            if (cnt[u] > 64u)
+            // the long tail chunk of a group with more than 64 chunks: the rest of its ranks, 64 at a time
+            for (uint32_t o = 64; o < cnt[u]; o += 64)
             {
-                // the long tail chunk of a group with more than 64 chunks: the rest of its ranks, 64 at a time
-                const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)ch.x, c0 + u);
-                for (uint32_t o = 64; o < cnt[u]; o += 64)
-                {
-                    const bool v = o + lane < cnt[u];
-                    const KdNode n2 = PR[v ? rank + o + lane : 0u];
-                    cand += min(cnt[u] - o, 64u);
-                    if (!sink(rs_test(n2, v, qx, qy, qz, r2, thr_f)))
-                        return false;
-                }
+                const bool v = o + lane < cnt[u];
+                const KdNode n2 = PR[v ? rk[u] + o + lane : 0u];
+                cand += min(cnt[u] - o, 64u);
+                if (!sink(rs_test(n2, v, qx, qy, qz, r2, thr_f)))
+                    return false;
             }
         }
     }
@@ -568,10 +581,10 @@ __device__ __forceinline__ bool rs_search(const KdNode *__restrict__ PR, const u
 template <bool STATE_LDS>
 __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const FrameState *__restrict__ frame, const uint32_t *__restrict__ cc_lo, const uint32_t *__restrict__ cc_hi,
-    const uint32_t *__restrict__ members, const KdNode *__restrict__ PR, const uint2 *__restrict__ chunks,
+    const uint32_t *__restrict__ members, const KdNode *__restrict__ PR, const ChunkRec *__restrict__ chunks,
     const uint32_t *__restrict__ grp_of, const float *__restrict__ OX, const float *__restrict__ OY,
     const float *__restrict__ OZ, uint8_t *gstate, int32_t *seed_of, uint32_t *queue, uint32_t *valid,
-    ReplayParams prm, FrameState *fstate, const uint32_t *__restrict__ roots, FV fv)
+    ReplayParams prm, FrameState *fstate, const uint32_t *__restrict__ roots, uint32_t m_lo, uint32_t m_hi, FV fv)
 {
     extern __shared__ uint32_t smem[];
     RsShared &sh = *(RsShared *)smem;
@@ -595,7 +608,8 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const uint32_t tid = threadIdx.x, w = tid / WAVE, lane = tid % WAVE;
     const uint32_t M = frame->n_obstacle;
     const uint32_t n_roots = frame->n_roots;
-    if (blockIdx.x >= n_roots)
+    // this launch serves the frames with m_lo < M <= m_hi obstacle points (another launch takes the rest)
+    if (M <= m_lo || M > m_hi || blockIdx.x >= n_roots)
         return;
     if (STATE_LDS)
     {
@@ -609,45 +623,49 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const float r2 = prm.r2, thr_f = prm.thr_f;
     unsigned long long st_cand = 0;
 
-    // one expansion searched into this wavefront's list region; returns the new fill level
-    auto search_to_lds = [&](uint32_t e, uint32_t fill) -> uint32_t {
-        const uint32_t j = sh.ej[e];
+    // Search phase of a window of E expansions: expansion e belongs to wavefront e % 4, which culls the chunk table
+    // of e's kd group against the query ball, loads and tests the surviving chunks and leaves the hits in its region
+    auto search_window = [&](uint32_t E) {
         uint32_t *dst = sh.lists + w * RS_REGION;
-        uint32_t len = 0;
-        bool ok = fill != RS_OVERFLOW;
-        if (ok)
-            ok = rs_search(PR, chunks, grp_of[j], sh.ex[e], sh.ey[e], sh.ez[e], r2, thr_f, lane, st_cand,
-                           [&](uint32_t word) -> bool {
-                               const bool hit = word != 0xffffffffu;
-                               const unsigned long long hm = __ballot(hit);
-                               if (fill + len + (uint32_t)__popcll(hm) > (uint32_t)RS_REGION)
-                                   return false;
-                               if (hit)
-                                   dst[fill + len + __popcll(hm & lt)] = word;
-                               len += (uint32_t)__popcll(hm);
-                               return true;
-                           });
-        if (lane == 0)
+        uint32_t fill = 0;
+        for (uint32_t e = w; e < E; e += RS_WAVES)
         {
-            sh.eoff[e] = w * RS_REGION + fill;
-            sh.elen[e] = ok ? len : RS_OVERFLOW;
+            const ChunkRec ch = chunks[(size_t)sh.eg[e] * LPX_GROUP_CHUNKS + lane];
+            const float qx = sh.ex[e], qy = sh.ey[e], qz = sh.ez[e];
+            uint32_t len = 0;
+            bool ok = fill != RS_OVERFLOW;
+            if (ok)
+                ok = rs_scan(PR, ch, rs_cull(ch, qx, qy, qz, r2), qx, qy, qz, r2, thr_f, lane, st_cand,
+                             [&](uint32_t word) -> bool {
+                                 const bool hit = word != 0xffffffffu;
+                                 const unsigned long long hm = __ballot(hit);
+                                 if (fill + len + (uint32_t)__popcll(hm) > (uint32_t)RS_REGION)
+                                     return false;
+                                 if (hit)
+                                     dst[fill + len + __popcll(hm & lt)] = word;
+                                 len += (uint32_t)__popcll(hm);
+                                 return true;
+                             });
+            if (lane == 0)
+            {
+                sh.eoff[e] = w * RS_REGION + fill;
+                sh.elen[e] = ok ? len : RS_OVERFLOW;
+            }
+            fill = ok ? fill + len : RS_OVERFLOW;  // once a list did not fit, the later ones of this wavefront do not either
         }
-        return ok ? fill + len : RS_OVERFLOW;  // once a list did not fit, the later ones of this wavefront do not either
     };
 
     if (w != 0)
     {
-        // helper wavefronts: search their share of every window the sequencer publishes
+        // helper wavefronts: their share of every window the sequencer publishes
         for (;;)
         {
             __syncthreads();  // A: window published
             const uint32_t E = sh.ctl[0];
             if (E == RS_DONE)
                 break;
-            uint32_t fill = 0;
-            for (uint32_t e = w; e < E; e += RS_WAVES)
-                fill = search_to_lds(e, fill);
-            __syncthreads();  // B: lists ready
+            search_window(E);
+            __syncthreads();  // B: sub-lists ready
         }
         if (lane == 0 && st_cand)
             atomicAdd((unsigned long long *)&fstate->cand_total, st_cand);
@@ -665,7 +683,19 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
             gstate[k] = (uint8_t)(gstate[k] | (v));                                                                   \
     } while (0)
     unsigned long long st_entries = 0;
-    uint32_t st_exp = 0;
+    uint32_t st_exp = 0, st_win = 0, st_ovf = 0;
+#ifdef LPX_RS_TIMING
+    unsigned long long tm_a = 0, tm_b = 0, tm_c = 0, tm_other = 0, tm_t0 = __builtin_amdgcn_s_memtime(), tm_x;
+#define TM_MARK(acc)                                                                                                  \
+    do                                                                                                                \
+    {                                                                                                                 \
+        tm_x = __builtin_amdgcn_s_memtime();                                                                          \
+        acc += tm_x - tm_t0;                                                                                          \
+        tm_t0 = tm_x;                                                                                                 \
+    } while (0)
+#else
+#define TM_MARK(acc)
+#endif
     for (;;)
     {
         uint32_t ticket = 0;
@@ -728,7 +758,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 {
                     const uint32_t qi = qt + __popcll(pm & lt);
                     q[qi] = k;
-                    sh.ring[qi % RP_RING] = k;
+                    sh.ring[qi % RS_RING] = k;
                     ST_OR(k, 1u);
                 }
                 qt += __popcll(pm);
@@ -737,6 +767,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
             };
             while (qh < qt)
             {
+                TM_MARK(tm_other);
                 // a window of up to 64 pops; which of them the reference expands is decided in registers (see
                 // replay_lds_kernel): a candidate is skipped iff it is removed already or an EXPANDED earlier
                 // candidate of the window holds it within the absorb radius
@@ -744,8 +775,8 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 const uint32_t wn = min((uint32_t)WAVE, qt - qh);
                 const bool inw = lane < wn;
                 uint32_t wcand;
-                if (qt - qh <= (uint32_t)RP_RING)
-                    wcand = inw ? sh.ring[(wb + lane) % RP_RING] : 0u;
+                if (qt - qh <= (uint32_t)RS_RING)
+                    wcand = inw ? sh.ring[(wb + lane) % RS_RING] : 0u;
                 else
                 {
                     __threadfence_block();
@@ -754,6 +785,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 const bool alive = inw && !(ST_GET(wcand) & 2u);
                 const uint32_t ci = alive ? wcand : 0u;
                 const float wx = OX[ci], wy = OY[ci], wz = OZ[ci];
+                const uint32_t wg = grp_of[ci];  // gathered with the coordinates: no extra round trip per search
                 unsigned long long am = __ballot(alive), em = 0;
                 while (am)
                 {
@@ -777,32 +809,35 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 {
                     const uint32_t e = (uint32_t)__popcll(em & lt);
                     sh.ej[e] = wcand;
+                    sh.eg[e] = wg;
                     sh.ex[e] = wx;
                     sh.ey[e] = wy;
                     sh.ez[e] = wz;
                 }
                 if (lane == 0)
                     sh.ctl[0] = E;
+                TM_MARK(tm_a);
                 __syncthreads();  // A
-                uint32_t fill = 0;
-                for (uint32_t e = 0; e < E; e += RS_WAVES)
-                    fill = search_to_lds(e, fill);
+                search_window(E);
                 __syncthreads();  // B
+                TM_MARK(tm_b);
                 st_exp += E;
+                ++st_win;
                 for (uint32_t e = 0; e < E; ++e)
                 {
                     const uint32_t len = sh.elen[e];
                     if (len == RS_OVERFLOW)
                     {
                         // did not fit its region: search again, streaming every chunk step into the apply
-                        unsigned long long before = touches;
-                        rs_search(PR, chunks, grp_of[sh.ej[e]], sh.ex[e], sh.ey[e], sh.ez[e], r2, thr_f, lane, st_cand,
-                                  [&](uint32_t word) -> bool {
-                                      st_entries += __popcll(__ballot(word != 0xffffffffu));
-                                      apply(word);
-                                      return true;
-                                  });
-                        (void)before;
+                        ++st_ovf;
+                        const ChunkRec ch = chunks[(size_t)sh.eg[e] * LPX_GROUP_CHUNKS + lane];
+                        const float qx = sh.ex[e], qy = sh.ey[e], qz = sh.ez[e];
+                        rs_scan(PR, ch, rs_cull(ch, qx, qy, qz, r2), qx, qy, qz, r2, thr_f, lane, st_cand,
+                                [&](uint32_t word) -> bool {
+                                    st_entries += __popcll(__ballot(word != 0xffffffffu));
+                                    apply(word);
+                                    return true;
+                                });
                         continue;
                     }
                     st_entries += len;
@@ -810,6 +845,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                     for (uint32_t t0 = 0; t0 < len; t0 += WAVE)
                         apply(t0 + lane < len ? src[t0 + lane] : 0xffffffffu);
                 }
+                TM_MARK(tm_c);
             }
             if (lane == 0)
                 valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;  // :113
@@ -824,12 +860,23 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
         {
             atomicAdd((unsigned long long *)&fstate->replay_entries, st_entries);
             atomicAdd(&fstate->n_expansions, st_exp);
+            atomicAdd(&fstate->n_windows, st_win);
+            if (st_ovf)
+                atomicAdd(&fstate->n_overflow, st_ovf);
         }
         if (st_cand)
             atomicAdd((unsigned long long *)&fstate->cand_total, st_cand);
+#ifdef LPX_RS_TIMING
+        // diagnostic build: cycles of the sequencer per bucket, summed over workgroups (reuses list-path counters)
+        atomicAdd((unsigned long long *)&fstate->nb_total, tm_a);      // gather + window selection
+        atomicAdd((unsigned long long *)&fstate->nb_entries, tm_b);    // search (barrier A .. barrier B)
+        atomicAdd(&fstate->n_overflow, (uint32_t)(tm_c >> 10));       // apply, kilo-cycles
+        atomicMax((unsigned long long *)&fstate->cand_total, tm_a + tm_b + tm_c + tm_other);  // busiest workgroup
+#endif
     }
 #undef ST_GET
 #undef ST_OR
+#undef TM_MARK
 }
 
 __global__ void relabel_kernel(FrameState *frame, const int32_t *__restrict__ seed_of,
@@ -1181,8 +1228,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     {
         StageTimer tm(ctx, ST_REPLAY);
         const size_t fixed = sizeof(RsShared);
-        const size_t lds_bitmap = fixed + sizeof(uint32_t) * (((size_t)m_max + 15) / 16 + 4);
-        const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: workgroups pull component sets from a list
+        auto bitmap_bytes = [](size_t pts) { return sizeof(uint32_t) * ((pts + 15) / 16 + 4); };
         if (!ctx->attr_search)
         {
             LPX_HIP(ctx, hipFuncSetAttribute((const void *)replay_search_kernel<true>,
@@ -1191,21 +1237,28 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             ctx->attr_search = true;
         }
-        if (lds_bitmap <= 152 * 1024)
-            hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS), lds_bitmap, st,
-                               (const FrameState *)frame, (const uint32_t *)cc_lo, (const uint32_t *)cc_hi,
-                               (const uint32_t *)members, (const KdNode *)ctx->nodes_pre.p, (const uint2 *)ctx->chunks.p,
-                               (const uint32_t *)ctx->grp_of.p, (const float *)ctx->OX.p, (const float *)ctx->OY.p,
-                               (const float *)ctx->OZ.p, (uint8_t *)ctx->state.p, (int32_t *)ctx->seed_of.p,
-                               (uint32_t *)ctx->queue.p, valid, prm, frame, (const uint32_t *)ctx->rpos.p, fv);
-        else
-            hipLaunchKernelGGL(replay_search_kernel<false>, dim3(m_max < 4096u ? m_max : 4096u, 1, ctx->cur_b),
-                               dim3(RS_THREADS), fixed, st, (const FrameState *)frame, (const uint32_t *)cc_lo,
-                               (const uint32_t *)cc_hi, (const uint32_t *)members, (const KdNode *)ctx->nodes_pre.p,
-                               (const uint2 *)ctx->chunks.p, (const uint32_t *)ctx->grp_of.p, (const float *)ctx->OX.p,
-                               (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (uint8_t *)ctx->state.p,
-                               (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, frame,
-                               (const uint32_t *)ctx->rpos.p, fv);
+        const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: workgroups pull component sets from a list
+#define RS_ARGS(lo_, hi_)                                                                                             \
+    (const FrameState *)frame, (const uint32_t *)cc_lo, (const uint32_t *)cc_hi, (const uint32_t *)members,            \
+        (const KdNode *)ctx->nodes_pre.p, (const ChunkRec *)ctx->chunks.p, (const uint32_t *)ctx->grp_of.p,            \
+        (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (uint8_t *)ctx->state.p,          \
+        (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, frame, (const uint32_t *)ctx->rpos.p,         \
+        (uint32_t)(lo_), (uint32_t)(hi_), fv
+        // frames of up to RS_SMALL_PTS obstacle points: a 16 KiB bitmap, three workgroups per CU
+        const uint32_t small = m_max < RS_SMALL_PTS ? m_max : RS_SMALL_PTS;
+        hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS),
+                           fixed + bitmap_bytes(small), st, RS_ARGS(0u, small));
+        if (m_max > RS_SMALL_PTS)
+        {
+            // the host's bound allows more: a second launch serves those frames (the device decides per frame)
+            if (fixed + bitmap_bytes(m_max) <= 152 * 1024)
+                hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS),
+                                   fixed + bitmap_bytes(m_max), st, RS_ARGS(RS_SMALL_PTS, m_max));
+            else
+                hipLaunchKernelGGL(replay_search_kernel<false>, dim3(m_max < 4096u ? m_max : 4096u, 1, ctx->cur_b),
+                                   dim3(RS_THREADS), fixed, st, RS_ARGS(RS_SMALL_PTS, m_max));
+        }
+#undef RS_ARGS
     }
     else
     {

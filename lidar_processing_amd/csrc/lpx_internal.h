@@ -45,10 +45,12 @@ struct FrameState
     uint32_t n_expansions;    // radius_search calls the reference would have made
     uint32_t n_in;            // points of the input cloud of this frame slot
     uint32_t has_far;         // some coordinate has |v| >= 2048 m: the plane kernels take the wide-moment path for it
-    uint32_t max_abs_bits;    // bit pattern of the largest |coordinate| of the input cloud (sizes the component grid)
+    uint32_t pad0;
     uint64_t nb_entries;      // neighbour entries written (sum of the list lengths)
     uint64_t rs_total;        // words asked from the single-pass region [cap_nb, cap_nb + cap_rs)
     uint64_t cand_total;      // candidates distance-tested by the replay's searches (expansion-driven path)
+    uint32_t n_windows;       // queue windows with at least one expansion (expansion-driven path)
+    uint32_t n_overflow;      // searches redone by the sequencer because the list did not fit its LDS region
 };
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
@@ -64,6 +66,13 @@ struct SegState  // per segment
     uint32_t fitted;  // at least one plane was fitted
     float thr;        // orthogonal_distance_threshold * |normal| of `plane`
     uint32_t pad[2];
+};
+
+// one candidate chunk of a kd group: `count` consecutive pre-order ranks from `rank`, and their bounding box
+struct ChunkRec
+{
+    uint32_t rank, count;
+    float lo[3], hi[3];
 };
 
 struct Buf
@@ -146,7 +155,7 @@ struct lpx_ctx
     Buf d_clabels;
     // ---- expansion-driven search (default path): no neighbour lists at all ----
     Buf grp_of;                // u32 per point: kd group (bucket or upper node) the point is a query of
-    Buf chunks;                // uint2 [groups][LPX_GROUP_CHUNKS]: candidate chunks (pre-order rank, count) of a group
+    Buf chunks;                // ChunkRec [groups][LPX_GROUP_CHUNKS]: candidate chunks (pre-order rank, count, box) of a group
     Buf cell_key;              // u64 [cell_cap]: occupied cells of the component grid (open addressing)
     Buf cell_rep, cell_parent; // u32 [cell_cap]: a point of the cell / union-find over cells
     Buf cell_of;               // u32 per point: its cell slot

@@ -1549,7 +1549,7 @@ constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B +
 
 __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__restrict__ PR,
                                                                const FrameState *__restrict__ frame, float rr,
-                                                               uint2 *__restrict__ chunks,
+                                                               ChunkRec *__restrict__ chunks,
                                                                uint32_t *__restrict__ grp_of, FV fv)
 {
     __shared__ Item s_seq[NB_WAVES][2 * IX_CAPS];
@@ -1691,7 +1691,52 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
             s_out[w][LPX_GROUP_CHUNKS - 1] = make_uint2(0u, 0u);
     }
     Coop<WAVE>::sync();
-    chunks[(size_t)gid * LPX_GROUP_CHUNKS + lane] = s_out[w][lane];
+    // bounding box of every chunk (a search culls chunks against its query ball before it loads a candidate):
+    // chunk c is reduced by the whole wavefront, lane c keeps the result
+    const uint2 mine = s_out[w][lane];
+    const uint32_t stored = min(n_chunks, (uint32_t)LPX_GROUP_CHUNKS);
+    float lo0 = 0.0f, lo1 = 0.0f, lo2 = 0.0f, hi0 = 0.0f, hi1 = 0.0f, hi2 = 0.0f;
+    for (uint32_t c = 0; c < stored; ++c)
+    {
+        const uint2 cc = s_out[w][c];
+        float a0 = 3.0e38f, a1 = 3.0e38f, a2 = 3.0e38f, b0 = -3.0e38f, b1 = -3.0e38f, b2 = -3.0e38f;
+        for (uint32_t o = 0; o < cc.y; o += WAVE)
+            if (o + lane < cc.y)
+            {
+                const Node nd = PR[cc.x + o + lane];
+                a0 = fminf(a0, nd.x);
+                a1 = fminf(a1, nd.y);
+                a2 = fminf(a2, nd.z);
+                b0 = fmaxf(b0, nd.x);
+                b1 = fmaxf(b1, nd.y);
+                b2 = fmaxf(b2, nd.z);
+            }
+        a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_min63_f32(a0)), WAVE - 1));
+        a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_min63_f32(a1)), WAVE - 1));
+        a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_min63_f32(a2)), WAVE - 1));
+        b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_max63_f32(b0)), WAVE - 1));
+        b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_max63_f32(b1)), WAVE - 1));
+        b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_max63_f32(b2)), WAVE - 1));
+        if (lane == c)
+        {
+            lo0 = a0;
+            lo1 = a1;
+            lo2 = a2;
+            hi0 = b0;
+            hi1 = b1;
+            hi2 = b2;
+        }
+    }
+    ChunkRec rec;
+    rec.rank = mine.x;
+    rec.count = mine.y;
+    rec.lo[0] = lo0;
+    rec.lo[1] = lo1;
+    rec.lo[2] = lo2;
+    rec.hi[0] = hi0;
+    rec.hi[1] = hi1;
+    rec.hi[2] = hi2;
+    chunks[(size_t)gid * LPX_GROUP_CHUNKS + lane] = rec;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1704,9 +1749,9 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
 // components of the OCCUPIED-CELL adjacency graph are such unions -- no distance is ever computed.  On the
 // reference's frames this partition is barely coarser than the exact one (the largest set holds 1.2-1.8 x the
 // expansions of the largest true component, tools/cc_analysis.py) and costs ~7k cells x 13 lookups per frame.
-// Cell edge: c = 1.01 d + X 2^-18 with X the largest |coordinate| of the frame, which keeps the float rounding
-// of floor(v / c) from ever putting two points within d more than one cell apart; indices saturate at +-2^20
-// cells (saturation is monotone, so adjacency is preserved).  Open-addressing table keyed by the packed index
+// Cell edge c = 1.01 d; the cell index floor(v / c) is evaluated in double precision, whose rounding (2^-53
+// relative, indices below 2^20) can never put two points within d more than one cell apart, however far from the
+// origin the cloud lies; indices saturate at +-2^20 cells (saturation is monotone, so adjacency is preserved).  Open-addressing table keyed by the packed index
 // triple; union-find over table slots (smaller slot wins); the representative of a cell is the point that
 // claimed it.
 // ------------------------------------------------------------------------------------------------
@@ -1730,15 +1775,9 @@ __device__ __forceinline__ uint32_t cell_cap_for(uint32_t M, uint32_t cap_max)
     return cap;
 }
 
-__device__ __forceinline__ float cell_inv_edge(float d, const FrameState *frame)
+__device__ __forceinline__ uint32_t cell_coord(float v, double inv_c)
 {
-    const float X = __uint_as_float(frame->max_abs_bits);
-    return 1.0f / (d * 1.01f + X * 3.8146973e-6f);  // 2^-18
-}
-
-__device__ __forceinline__ uint32_t cell_coord(float v, float inv_c)
-{
-    const float f = fminf(fmaxf(floorf(v * inv_c), -1048576.0f), 1048575.0f);
+    const double f = fmin(fmax(floor((double)v * inv_c), -1048576.0), 1048575.0);
     return (uint32_t)((int)f + 1048576);  // 21 bits
 }
 
@@ -1772,7 +1811,7 @@ __global__ void grid_insert_kernel(const FrameState *__restrict__ frame, const f
     if (i >= M)
         return;
     const uint32_t mask = cell_cap_for(M, cap_max) - 1;
-    const float inv_c = cell_inv_edge(d, frame);
+    const double inv_c = 1.0 / ((double)d * 1.01);
     const unsigned long long key = ((unsigned long long)cell_coord(OX[i], inv_c) << 42) |
                                    ((unsigned long long)cell_coord(OY[i], inv_c) << 21) |
                                    (unsigned long long)cell_coord(OZ[i], inv_c);
@@ -1983,11 +2022,11 @@ int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
     while ((m_max >> dmax) > (uint32_t)NB_BUCKET)
         ++dmax;
     const uint32_t groups = (2u << dmax) - 1;
-    if (sizeof(uint2) * LPX_GROUP_CHUNKS * (size_t)groups > ctx->chunks.bytes)
+    if (sizeof(ChunkRec) * LPX_GROUP_CHUNKS * (size_t)groups > ctx->chunks.bytes)
         return lpx_fail(ctx, LPX_ERR_INTERNAL, "chunk table of %u groups does not fit the workspace", groups);
     hipLaunchKernelGGL(nb_index_kernel, dim3((groups + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b), dim3(NB_THREADS), 0,
                        ctx->stream, (const Node *)ctx->nodes_pre.p, (const FrameState *)ctx->frame.p, rr,
-                       (uint2 *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, lpx_fv(ctx));
+                       (ChunkRec *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, lpx_fv(ctx));
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

@@ -69,8 +69,10 @@ __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacl
         f.n_expansions = 0;
         f.n_in = n.v[blockIdx.z];
         f.has_far = 0;
-        f.max_abs_bits = 0;
+        f.pad0 = 0;
         f.cand_total = 0;
+        f.n_windows = 0;
+        f.n_overflow = 0;
         f.nb_entries = 0;
         f.rs_total = 0;
         *frame = f;
@@ -157,14 +159,6 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
     }
     else if (!(amax < FIX_LIMIT))
         frame->has_far = 1u;
-    // largest |coordinate| of the frame (sizes the cells of the component grid so that float rounding of a cell
-    // index cannot separate two points within the radius): one atomic per wavefront, and only while its maximum
-    // still beats the value it reads (finite non-negative floats order like their bit patterns)
-    const float wm = lpx_wave_max63_f32(nonfinite == 0.0f ? amax : 0.0f);
-    const uint32_t wmax = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(wm), WAVE - 1);
-    if ((threadIdx.x % WAVE) == 0 &&
-        wmax > __hip_atomic_load(&frame->max_abs_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(&frame->max_abs_bits, wmax);
 }
 
 // ------------------------------------------------------------------------------------------------
