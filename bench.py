@@ -160,7 +160,7 @@ def main():
     ctxs = [Context(local_rank, batch=B) for _ in range(C)]
     for c in ctxs:
         if args.lists:
-            c.use_lists(True)
+            c.set_neighbour_mode("lists")
             c.reserve_single_pass(args.single_pass_words)
         c.reserve(pitch, args.neighbour_words)
     d_labels = torch.empty((F, pitch), dtype=torch.int32, device=dev)

@@ -88,6 +88,18 @@ int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_per_point);
  * lists reserved by an upper bound of their length, which saves its counting pass.  It never changes what
  * fits: a kd group that finds no room there counts first and uses the lpx_reserve workspace.  0 disables. */
 int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point);
+/* How Clusterer::cluster finds neighbours.  Both modes give the reference's labels; they trade latency for work.
+ *   LPX_NEIGHBOURS_LISTS : every radius list is materialised by the whole device at once, then the greedy loop
+ *                          replays over them: shortest critical path for ONE frame alone on the device, but ~30x
+ *                          the neighbour work and a large list workspace (lpx_reserve's neighbours_per_point).
+ *   LPX_NEIGHBOURS_SEARCH: expansion-driven -- point sets from a uniform grid, and a radius search only when the
+ *                          greedy loop expands a point; nothing is materialised, no list workspace.  Highest
+ *                          throughput when many frames share the device.
+ *   LPX_NEIGHBOURS_AUTO  : (default) LISTS for a single-frame context (lpx_create), SEARCH for lpx_create_batch. */
+#define LPX_NEIGHBOURS_AUTO 0
+#define LPX_NEIGHBOURS_LISTS 1
+#define LPX_NEIGHBOURS_SEARCH 2
+int lpx_set_neighbour_mode(lpx_ctx *ctx, int mode);
 const char *lpx_last_error(const lpx_ctx *ctx);
 /* blocks until everything enqueued on the context stream has finished */
 int lpx_synchronize(lpx_ctx *ctx);

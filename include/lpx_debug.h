@@ -43,9 +43,6 @@ int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane);
  * with an expansion, searches redone by the sequencer (list larger than its LDS region)} */
 int lpx_dbg_search_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out4);
 
-/* 0 (default): expansion-driven neighbour search; 1: materialise every radius list first (round-1 path) */
-int lpx_dbg_use_lists(lpx_ctx *ctx, int on);
-
 /* tools only: per-group statistics of the neighbour kernel, 8 words per kd group ({candidates, intervals,
  * queries, list words, cycles to allocation, cycles total, -, -}).  n_groups > 0 with out == NULL arms the
  * collection for the following calls, out != NULL copies what was collected, n_groups == 0 switches it off. */

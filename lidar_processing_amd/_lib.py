@@ -111,7 +111,7 @@ def lib():
     L.lpx_profile_stage_name.argtypes = [C.c_int]
     L.lpx_profile_stage_name.restype = C.c_char_p
     L.lpx_profile_read.argtypes = [vp, vp, vp, C.c_int]
-    L.lpx_dbg_use_lists.argtypes = [vp, C.c_int]
+    L.lpx_set_neighbour_mode.argtypes = [vp, C.c_int]
     L.lpx_dbg_sort_pairs.argtypes = [vp, vp, vp, u32, u32]
     L.lpx_dbg_sort_keys64.argtypes = [vp, vp, u32, u32]
     L.lpx_dbg_scan.argtypes = [vp, vp, u32, C.POINTER(C.c_uint64)]

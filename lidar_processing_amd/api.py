@@ -114,10 +114,14 @@ class Context:
         """lpx_reserve_single_pass: extra neighbour workspace for lists reserved by an upper bound (0 = off)"""
         self.check(self._L.lpx_reserve_single_pass(self._h, int(words_per_point)))
 
+    def set_neighbour_mode(self, mode):
+        """lpx_set_neighbour_mode: "auto" (lists for a single-frame context, search for a batch context), "lists"
+        (every radius list materialised: lowest single-frame latency) or "search" (expansion-driven: highest
+        throughput, no list workspace); all give the same labels"""
+        self.check(self._L.lpx_set_neighbour_mode(self._h, {"auto": 0, "lists": 1, "search": 2}[mode]))
+
     def use_lists(self, on=True):
-        """lpx_dbg_use_lists: True selects the round-1 path that materialises every radius list (kept for A/B
-        measurements and the list tests); the default is the expansion-driven search"""
-        self.check(self._L.lpx_dbg_use_lists(self._h, 1 if on else 0))
+        self.set_neighbour_mode("lists" if on else "search")
 
     def synchronize(self):
         self.check(self._L.lpx_synchronize(self._h))

@@ -307,6 +307,7 @@ static int create_common(int device, hipStream_t stream, bool own, uint32_t batc
     else
         ctx->stream = stream;
     ctx->batch = batch;
+    ctx->use_lists = batch == 1;  // LPX_NEIGHBOURS_AUTO
     int rc;
     if ((rc = lpx_ensure_capacity(ctx, 1024, 1024)))
     {
@@ -1036,16 +1037,13 @@ int lpx_ensure_lists(lpx_ctx *ctx)
     return rc;
 }
 
-// Selects how Clusterer::cluster finds neighbours.  0 (default): expansion-driven -- components from a uniform
-// grid, radius searches only for the points the greedy loop expands, nothing materialised.  1: the round-1 path
-// that writes every radius list first (kept as the reference point for A/B measurements and for the list tests).
-extern "C" int lpx_dbg_use_lists(lpx_ctx *ctx, int on)
+extern "C" int lpx_set_neighbour_mode(lpx_ctx *ctx, int mode)
 {
-    if (!ctx)
+    if (!ctx || mode < LPX_NEIGHBOURS_AUTO || mode > LPX_NEIGHBOURS_SEARCH)
         return LPX_ERR_ARG;
     LPX_HIP(ctx, hipSetDevice(ctx->device));
-    ctx->use_lists = on != 0;
-    return on ? lpx_ensure_lists(ctx) : LPX_OK;
+    ctx->use_lists = mode == LPX_NEIGHBOURS_LISTS || (mode == LPX_NEIGHBOURS_AUTO && ctx->batch == 1);
+    return ctx->use_lists ? lpx_ensure_lists(ctx) : LPX_OK;
 }
 
 // tools only: per-group statistics of the neighbour kernel ({T, intervals, queries, hits, cycles to

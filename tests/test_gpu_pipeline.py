@@ -245,7 +245,7 @@ def test_list_path_and_search_path_agree(frame):
     for lists in (True, False):
         c = Context(0)
         try:
-            c.use_lists(lists)
+            c.set_neighbour_mode("lists" if lists else "search")
             out = c.segment_cluster(pts, SegmentationConfiguration(**skw), ClusteringConfiguration(0.25, 0.5))
             assert np.array_equal(out["cluster_labels"], want), f"lists={lists}"
             stats[lists] = c.frame_stats()
