@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the segmentation + clustering hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kitti|synth1m|synth5m|stream]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (lpx_segment_cluster_batch_device: Segmenter::segment followed by
-Clusterer::cluster with the obstacle cloud kept on the device, `--batch` frames per launch chain) over
-one batch of frames whose points are already resident in HBM.  Workload = BASELINE.json configs[1]: real 120k-point KITTI frames
-(tests/golden/frames.npz, bit-identical to the reference's data/*.pcd), 6 segments, 5 plane-fit
-iterations, FEC d = 0.5 m (distance_squared 0.25), quality 0.5.  Frames are independent, so with N
-GPUs every rank runs its own batch (frame i -> GPU i mod N, "weak" scaling) and there is no
-data-path collective; RCCL is used only for the barrier and the max-over-ranks time.
+Clusterer::cluster with the obstacle cloud kept on the device, `--batch` frames per launch chain) over one batch
+of frames whose points are already resident in HBM.  Workloads (BASELINE.json configs):
+  kitti   (default, configs[1]) real 120k-point KITTI frames (committed fixtures of the reference's data/*.pcd),
+          6 segments, 5 plane-fit iterations, FEC d = 0.5 m (distance_squared 0.25), quality 0.5 -- the headline.
+  synth1m (configs[2]) the 1M-point plane + boxes cloud, 12 segments, d = 0.3 m -- BASELINE's roofline run.
+  synth5m (configs[4]) the 5M-point cloud, 24 segments, d = 0.2 m.
+  stream  (configs[3]) all 154 frames in filename order, frame i -> GPU i mod N, frames/s; also reports the
+          PCIe-inclusive rate of the double-buffered feeder (files -> pinned -> H2D -> chains -> D2H).
+Frames are independent, so with N GPUs every rank runs its own frames ("weak" scaling) and there is no data-path
+collective; RCCL is used only for the barrier and the max-over-ranks time.
 
-Prints ONE JSON line (rank 0) with the metric, a `roofline` object for the kernel that fills the device
-(HIP-event times measured live: the same K steps under load, and one step with every chain alone on the
-device) and, at N = 1, a `cpu_baseline` object: the oracle restatement of the reference path timed on this
-host.
+Prints ONE JSON line (rank 0): the metric; `roofline` for the kernel that dominates a launch chain (HIP-event
+times measured live on the streams the kernels run on), with `roofline.frame` (SURVEY 8d bytes per frame over the
+step time), the streaming kernels' own fractions and the copy-kernel bandwidth of this device; `latency` (one
+frame at a time: device-resident and through the host API with pageable / pinned buffers); and at N = 1
+`cpu_baseline`: the oracle restatement of the reference path timed on this host (1 core; "reference-like" with the
+two index sorts on several threads; all cores, one frame per core).
 """
 import argparse
 import json
@@ -35,50 +41,74 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
-SEG = dict(number_of_planar_partitions=6, number_of_iterations=5)
-CLU = dict(distance_squared=0.25, cluster_quality=0.5)
-
+WORKLOADS = {
+    "kitti": dict(config="configs[1]: 120k-pt KITTI frames, 6 segments, 5 iters, FEC d=0.5 m q=0.5",
+                  seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
+                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=256, batch=32, contexts=8),
+    "stream": dict(config="configs[3]: all 154 data/*.pcd frames in order, 6 segments, 5 iters, FEC d=0.5 m q=0.5",
+                   seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
+                   clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=154, batch=32, contexts=5),
+    "synth1m": dict(config="configs[2]: synthetic 1M-pt plane + boxes, 12 segments, 3 iters, FEC d=0.3 m q=0.5",
+                    seg=dict(number_of_planar_partitions=12, number_of_iterations=3),
+                    clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=16, batch=4, contexts=4),
+    "synth5m": dict(config="configs[4]: synthetic 5M-pt plane + boxes, 24 segments, 3 iters, FEC d=0.2 m q=0.5",
+                    seg=dict(number_of_planar_partitions=24, number_of_iterations=3),
+                    clu=dict(distance_squared=0.04, cluster_quality=0.5), frames_per_step=4, batch=1, contexts=4),
+}
 
 # stage -> kernel that dominates it (names as rocprofv3 prints them), for the PMC traffic lookup
 STAGE_KERNEL = {"ingest": "ingest_kernel", "xsort": "radix_scatter_kernel<unsigned int, true>", "gather": "gather_kernel",
-                "zsort": "radix_scatter_kernel<unsigned long, false>", "seeds": "seed_kernel",
+                "zsort": "radix_scatter_kernel<unsigned long, false>", "seeds": "seed_select_kernel",
                 "plane_passes": "plane_single_kernel", "compact": "compact_kernel", "kd_build": "kd_block_kernel",
-                "cc_hook": "cc_hook_kernel", "neighbours": "nb_group_kernel",
-                "components": "radix_scatter_kernel<unsigned int, true>", "replay": "replay_lds_kernel",
+                "cc_hook": "grid_link_kernel", "neighbours": "nb_index_kernel",
+                "components": "radix_scatter_kernel<unsigned int, true>", "replay": "replay_search_kernel",
                 "labels": "relabel_kernel"}
+STREAMING = ("ingest", "gather", "compact", "labels")  # stages whose kernels are plain coalesced streams
 
 
-def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None):
-    """Algorithmic HBM bytes of `stage` for ONE frame with N points, M obstacle points, E neighbour-list
-    entries, E_replay entries in the lists of the points the reference would expand ("Kernels and
-    their algorithmic bytes").  A launch group of a batched chain processes frames_per_launch frames."""
+def frame_bytes(N, M, I):
+    """algorithmic HBM bytes of ONE frame, B = N (44 + 12 I) + 80 M"""
+    return N * (44 + 12 * I) + 80 * M
+
+
+def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=None):
+    """Algorithmic HBM bytes of `stage` for ONE frame with N points, M obstacle points (kernel table).
+    Expansion-driven path: `cand` candidates distance-tested by the replay's searches, `groups` kd groups.  List
+    path (E neighbour-list entries, E_replay of them read by the replay) when cand is None."""
     if E_replay is None:
         E_replay = E
+    search = cand is not None
+    if groups is None:
+        groups = M / 16 + 1
     return {
         "ingest": N * (16 + 12 + 8),                 # AoS read, SoA write, (key, index) write
         "xsort": 4 * N * (8 + 8 + 8),                # per pass: histogram read, scatter read + write of 8 B pairs
-        "gather": N * (4 + 12 + 12 + 8),             # index, gather, x-sorted SoA, (segment, z) key
+        "gather": N * (4 + 12 + 12),                 # index, gather, x-sorted SoA
         "zsort": 5 * N * (8 + 8 + 8),
         "seeds": N * 4 + P * 64,                     # the selection kernel reads the x-sorted z once
         "plane_passes": N * 12 + N,                  # the SoA is read once and stays in registers; flag write
         "compact": N * (1 + 4 + 4 + 4) + M * (12 + 16),  # flag, index, label, list, obstacle SoA + kd nodes
         "kd_build": M * 16 * 2 * 17,                 # ~log2(M) levels, each reads + writes the node array
-        "cc_hook": E * 4 + M * (8 + 8),              # list words read, offsets/lengths, parents
-        "neighbours": M * 16 + E * 4 + M * 8,        # nodes read once, one word per neighbour written, off/len
+        # components: (search) cell table insert + 13 lookups per cell + root per point / (lists) every list re-read
+        "cc_hook": (M * (12 + 8 + 4 + 4 + 4) + M * 13 * 8 // 6) if search else (E * 4 + M * (8 + 8)),
+        # neighbours: (search) chunk table of every kd group written once, nodes read for the boxes / (lists) every list
+        "neighbours": (groups * 64 * 32 + M * 16 + M * 4) if search else (M * 16 + E * 4 + M * 8),
         "components": M * (4 + 4 + 4 + 1 + 4 + 8) + 3 * M * 24,
-        "replay": E_replay * 4 + M * (8 + 4 + 4 + 4),  # expanded lists, off/len, seed, queue, valid
+        # replay: (search) one chunk table + 16 B per candidate per expansion / (lists) the lists of expanded points
+        "replay": ((cand or 0) * 16 + M * (12 + 4 + 4 + 4 + 4)) if search else (E_replay * 4 + M * (8 + 4 + 4 + 4)),
         "labels": M * (4 + 4 + 4 + 4),
         "groups": M * (4 + 4 + 4) + 2 * M * 24,
     }[stage]
 
 
-def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's dominant kernel from the committed rocprofv3 --pmc summary of this
-    same command (profiles/): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half of a coalesced
-    read on gfx950 (guides/MI355X_MICROARCH.md, HBM).  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_g_pmc_fetch_write_per_kernel.json")
+def pmc_traffic(stage, workload):
+    """HBM bytes per launch of the stage's dominant kernel from the COMMITTED rocprofv3 --pmc summary of this same
+    command (profiles/r02_<workload>_pmc_fetch_write_per_kernel.json): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 --
+    FETCH_SIZE counts half of a coalesced read on gfx950 (guides/MI355X_MICROARCH.md, HBM).  None when no summary
+    is committed for this workload: the value is never measured inside this run."""
+    path = os.path.join(ROOT, "profiles", f"r02_{workload}_pmc_fetch_write_per_kernel.json")
     try:
         d = json.load(open(path))
         k = next(v for name, v in d.items() if name.startswith(STAGE_KERNEL[stage][:40]))
@@ -105,30 +135,94 @@ def aggregate(elapsed_s, points_per_step, device, world):
     return float(t.item()), float(pts.item())
 
 
+def load_workload(name):
+    from util import FRAMES, load_frame, load_stream_frame, stream_names, synthetic_scene
+    if name == "kitti":
+        return [load_frame(f) for f in FRAMES]
+    if name == "stream":
+        return [load_stream_frame(n) for n in stream_names()]
+    if name == "synth1m":
+        return [synthetic_scene(600_000, 2000, 200, 20240601)]
+    return [synthetic_scene(2_000_000, 3000, 1000, 20240602, extent=100.0)]
+
+
+# ---- CPU baselines (before anything touches the GPU: the all-cores leg forks worker processes) ---------------------
+def _cpu_frame(args):
+    import oracle
+    pts, seg, clu = args
+    r = oracle.segment(pts, oracle.SegCfg(**seg))
+    oracle.cluster(pts[r["obstacle_idx"]], oracle.CluCfg(clu["distance_squared"], clu["cluster_quality"]))
+    return pts.shape[0]
+
+
+def cpu_baselines(host_frames, wl, budget_s):
+    """the oracle restatement of the reference path on this host: (a) one core -- the reference is single-threaded
+    apart from two index sorts; (b) "reference-like": those two sorts on several threads (pthreads merge sort in the
+    oracle, since TBB is not part of it); (c) every core, one frame per core (the fair comparator for frames/s)"""
+    import multiprocessing as mp
+    import oracle
+    cores = os.cpu_count() or 1
+
+    def timed(budget):
+        done, t, n = 0, 0.0, 0
+        while t < budget:
+            a = time.perf_counter()
+            done += _cpu_frame((host_frames[n % len(host_frames)], wl["seg"], wl["clu"]))
+            t += time.perf_counter() - a
+            n += 1
+        return done / t / 1e6, n, t
+
+    one, n1, t1 = timed(budget_s)
+    threads = min(cores, 16)
+    oracle.set_sort_threads(threads)
+    par, n2, t2 = timed(budget_s / 2)
+    oracle.set_sort_threads(1)
+    jobs = [(host_frames[j % len(host_frames)], wl["seg"], wl["clu"]) for j in range(max(cores, 8) * 4)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_cpu_frame, jobs[:cores])  # start-up and page-in outside the timed part
+        a = time.perf_counter()
+        pts_done = sum(pool.map(_cpu_frame, jobs, chunksize=1))
+        t3 = time.perf_counter() - a
+    return {"value": round(one, 4), "unit": "Mpts/s", "cores": 1, "kind": "port",
+            "sample": f"{n1} frame passes (segment+cluster, oracle/lidar_oracle.c, {t1:.1f} s)", "host_cpus": cores,
+            "reference_like": {"value": round(par, 4), "unit": "Mpts/s", "cores": threads,
+                               "what": "the two index sorts (the reference's only parallelism, std::sort(par)) on "
+                                       f"{threads} threads, everything else on one; {n2} frame passes, {t2:.1f} s"},
+            "all_cores_frame_parallel": {"value": round(pts_done / t3 / 1e6, 3), "unit": "Mpts/s", "cores": cores,
+                                         "frames_per_s": round(len(jobs) / t3, 1),
+                                         "what": f"one frame per core, {len(jobs)} frames in {t3:.1f} s"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=256, help="frames in one step (per GPU)")
-    ap.add_argument("--batch", type=int, default=32, help="frames per launch chain (lpx_segment_cluster_batch_device)")
-    ap.add_argument("--contexts", type=int, default=8, help="concurrent lpx contexts (HIP streams) per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti")
+    ap.add_argument("--frames-per-step", type=int, default=0, help="frames in one step (per GPU); 0 = workload default")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch chain; 0 = workload default")
+    ap.add_argument("--contexts", type=int, default=0, help="concurrent lpx contexts (HIP streams) per GPU; 0 = default")
     ap.add_argument("--threads", type=int, default=2, help="host threads that enqueue (ctypes releases the GIL)")
-    ap.add_argument("--neighbour-words", type=int, default=256, help="neighbour workspace per point (lpx_reserve)")
-    ap.add_argument("--single-pass-words", type=int, default=384,
-                    help="extra neighbour workspace per point for single-pass lists (lpx_reserve_single_pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lists", action="store_true", help="round-1 path: materialise every radius list (A/B reference)")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the one-core CPU baseline leg")
+    ap.add_argument("--lists", action="store_true", help="A/B: materialise every radius list (LPX_NEIGHBOURS_LISTS)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from lidar_processing_amd import ClusteringConfiguration, Context, SegmentationConfiguration
-    from util import FRAMES, load_frame
-
+    wl = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    host_frames = load_workload(args.workload)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baselines(host_frames, wl, args.cpu_seconds)  # before the GPU is initialised (fork)
+
+    import torch
+    import torch.distributed as dist
+    from lidar_processing_amd import (ClusteringConfiguration, Context, Feeder, PinnedArray, SegmentationConfiguration,
+                                      write_pcd)
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -139,14 +233,13 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    scfg = SegmentationConfiguration(**SEG)
-    ccfg = ClusteringConfiguration(**CLU)
-    P = SEG["number_of_planar_partitions"]
+    scfg = SegmentationConfiguration(**wl["seg"])
+    ccfg = ClusteringConfiguration(**wl["clu"])
+    P, I = wl["seg"]["number_of_planar_partitions"], wl["seg"]["number_of_iterations"]
 
     # ---- inputs: resident in HBM before the timed region (32-byte PointXYZI records, one pitched array) ----
-    host_frames = [load_frame(f) for f in FRAMES]
-    F = args.frames_per_step
-    B = max(1, min(args.batch, F))
+    F = args.frames_per_step or wl["frames_per_step"]
+    B = max(1, min(args.batch or wl["batch"], F))
     my_ids = frame_ids_for_rank(rank, world, F, len(host_frames))
     pitch = max(hf.shape[0] for hf in host_frames)
     host_in = np.zeros((F, pitch, 8), np.float32)
@@ -156,13 +249,11 @@ def main():
     del host_in
     n_points = np.array([host_frames[fid].shape[0] for fid in my_ids], np.uint32)
     chains = [(k, min(k + B, F)) for k in range(0, F, B)]  # frames [lo, hi) of every launch chain
-    C = max(1, min(args.contexts, len(chains)))
+    C = max(1, min(args.contexts or wl["contexts"], len(chains)))
     ctxs = [Context(local_rank, batch=B) for _ in range(C)]
     for c in ctxs:
-        if args.lists:
-            c.set_neighbour_mode("lists")
-            c.reserve_single_pass(args.single_pass_words)
-        c.reserve(pitch, args.neighbour_words)
+        c.set_neighbour_mode("lists" if args.lists else "search")  # a batch=1 context would default to lists
+        c.reserve(pitch)
     d_labels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
     d_gidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
     d_oidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
@@ -175,16 +266,19 @@ def main():
     T = max(1, min(args.threads, C))
     pool = concurrent.futures.ThreadPoolExecutor(T) if T > 1 else None
 
+    def enqueue_chain(k):
+        lo, hi = chains[k]
+        ctxs[k % C].segment_cluster_batch_device(n_points[lo:hi], d_pts[lo].data_ptr(), 32, pitch, scfg, ccfg,
+                                                 d_labels[lo].data_ptr(), d_gidx[lo].data_ptr(), d_oidx[lo].data_ptr(),
+                                                 d_planes[lo].data_ptr(), d_clabels[lo].data_ptr(),
+                                                 d_counts[lo].data_ptr())
+
     def enqueue(tid):
         # thread tid owns contexts tid, tid + T, ... and therefore chains k with (k % C) % T == tid
         torch.cuda.set_device(local_rank)
-        for k, (lo, hi) in enumerate(chains):
-            if (k % C) % T != tid:
-                continue
-            ctxs[k % C].segment_cluster_batch_device(n_points[lo:hi], d_pts[lo].data_ptr(), 32, pitch, scfg, ccfg,
-                                                     d_labels[lo].data_ptr(), d_gidx[lo].data_ptr(),
-                                                     d_oidx[lo].data_ptr(), d_planes[lo].data_ptr(),
-                                                     d_clabels[lo].data_ptr(), d_counts[lo].data_ptr())
+        for k in range(len(chains)):
+            if (k % C) % T == tid:
+                enqueue_chain(k)
 
     def step():
         if pool is None:
@@ -217,16 +311,12 @@ def main():
     counts = d_counts.cpu().numpy().view(np.uint32)
     if (counts[:, 3] != 0).any():
         raise SystemExit(f"device status != 0: {counts[:, 3].tolist()}")
-
     elapsed, total_points_per_step = aggregate(elapsed, points_per_step, dev, world)
 
     # ---- stage times: HIP-event pairs around every stage (lpx_profile_*), on the streams the kernels run on ----
-    # (1) the same K steps under the same load as the timed region: what a launch group costs while eleven other
-    #     chains compete for the device (mostly waiting for free CUs);
-    # (2) every chain of one step alone on the device: the launch duration of the kernels themselves.
-    # The roofline object is for the kernel that dominates (2) -- the one that fills the device -- and also
-    # carries its average duration under load.
-    roofline = None
+    # (1) the same K steps under the same load as the timed region; (2) every chain of one step alone on the device:
+    # the launch duration of the kernels themselves.  `roofline` describes the stage that dominates (2).
+    roofline, latency, stream_info = None, None, None
     stage_ms = {}
     if rank == 0:
         def profiled(run):
@@ -247,59 +337,138 @@ def main():
                 step()
 
         def isolated():
-            for k, (lo, hi) in enumerate(chains):
-                c = ctxs[k % C]
-                c.segment_cluster_batch_device(n_points[lo:hi], d_pts[lo].data_ptr(), 32, pitch, scfg, ccfg,
-                                               d_labels[lo].data_ptr(), d_gidx[lo].data_ptr(), d_oidx[lo].data_ptr(),
-                                               d_planes[lo].data_ptr(), d_clabels[lo].data_ptr(),
-                                               d_counts[lo].data_ptr())
-                c.synchronize()
+            for k in range(len(chains)):
+                enqueue_chain(k)
+                ctxs[k % C].synchronize()
 
         stage_ms, launches = profiled(loaded)
         iso_ms, iso_launches = profiled(isolated)
-        dom = max(iso_ms, key=iso_ms.get)
-        avg_ms = iso_ms[dom] / max(1, iso_launches[dom])
-        avg_ms_loaded = stage_ms[dom] / max(1, launches[dom])
-        # one launch (group) of a stage covers the B frames of a chain: frame-averaged sizes of this rank's
-        # batch times the frames per chain; list sizes come from the device counters of the frame slots
+        per_launch = {k: iso_ms[k] / max(1, iso_launches[k]) for k in iso_ms}
+        dom = max(per_launch, key=per_launch.get)
+        # one launch (group) of a stage covers the frames of a chain: frame-averaged sizes of this rank's step times
+        # the frames per chain; search / list sizes come from the device counters of the frame slots
         frames_per_launch = float(np.mean([hi - lo for lo, hi in chains]))
-        Nn = float(n_points.mean())
-        Mm = float(counts[:, 1].mean())
+        Nn, Mm = float(n_points.mean()), float(counts[:, 1].mean())
         fst = [c.frame_stats(slot) for c in ctxs for slot in range(B)]
         E = float(np.mean([f["neighbour_entries"] for f in fst]))
         E_replay = float(np.mean([f["replay_entries"] for f in fst]))
-        algo = frames_per_launch * algorithmic_bytes(dom, Nn, Mm, E, SEG["number_of_iterations"], P, E_replay)
-        achieved = algo / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": STAGE_KERNEL.get(dom, dom), "stage": dom, "achieved": round(achieved, 3),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": pmc_traffic(dom), "avg_launch_ms": round(avg_ms, 5),
-                    "avg_launch_ms_under_load": round(avg_ms_loaded, 5), "algorithmic_bytes_per_launch": int(algo),
-                    "frames_per_launch": frames_per_launch,
-                    "stage_ms_per_launch_alone": {k: round(v / max(1, iso_launches[k]), 5) for k, v in iso_ms.items()}}
+        cand = None if args.lists else float(np.mean([f["candidates"] for f in fst]))
+        D = 0
+        while (int(Mm) >> D) > 64:
+            D += 1
+        groups = float((2 << D) - 1)
 
-    # ---- CPU baseline: the oracle restatement on this host, bounded sample (rank 0, N = 1 only) ----
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
-        oscfg = oracle.SegCfg(**SEG)
-        occfg = oracle.CluCfg(CLU["distance_squared"], CLU["cluster_quality"])
-        done_pts, t_cpu, passes = 0, 0.0, 0
-        while t_cpu < 10.0:
-            hf = host_frames[passes % len(host_frames)]
-            a = time.perf_counter()
-            r = oracle.segment(hf, oscfg)
-            oracle.cluster(hf[r["obstacle_idx"]], occfg)
-            t_cpu += time.perf_counter() - a
-            done_pts += hf.shape[0]
-            passes += 1
-        cpu = {"value": round(done_pts / t_cpu / 1e6, 4), "unit": "Mpts/s", "cores": 1, "kind": "port",
-               "sample": f"{passes} frame passes of the same 3 KITTI frames (segment+cluster, oracle/lidar_oracle.c, "
-                         f"{t_cpu:.1f} s)", "host_cpus": os.cpu_count()}
+        def stage_row(stage):
+            algo = frames_per_launch * algorithmic_bytes(stage, Nn, Mm, E, I, P, E_replay, cand, groups)
+            ms = per_launch[stage]
+            ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": STAGE_KERNEL.get(stage, stage), "avg_launch_ms": round(ms, 5),
+                    "algorithmic_bytes_per_launch": int(algo), "achieved": round(ach, 2),
+                    "frac": round(ach / HBM_PEAK_GBS, 5)}
+
+        row = stage_row(dom)
+        step_ms = elapsed / args.steps * 1e3
+        fb = frame_bytes(Nn, Mm, I)
+        frame_gbs = fb * F * world / (step_ms * 1e-3) / 1e9
+        copy_gbs = ctxs[0].copy_bandwidth(1 << 30, 10)
+        roofline = {"bound": "hbm", "kernel": row["kernel"], "stage": dom, "achieved": row["achieved"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": row["frac"], "traffic": pmc_traffic(dom, args.workload),
+                    "traffic_source": "committed profiles/r02_*_pmc summary of this command (not measured in this run)",
+                    "avg_launch_ms": row["avg_launch_ms"],
+                    "avg_launch_ms_under_load": round(stage_ms[dom] / max(1, launches[dom]), 5),
+                    "algorithmic_bytes_per_launch": row["algorithmic_bytes_per_launch"],
+                    "frames_per_launch": frames_per_launch,
+                    "note": "the dominant kernel of a chain is latency-bound (one sequencer wavefront per component "
+                            "set), not an HBM stream; see roofline.frame and roofline.streaming_kernels",
+                    # the whole frame against the roofline, B = N (44 + 12 I) + 80 M over the step time
+                    "frame": {"bytes_per_frame": int(fb), "achieved": round(frame_gbs, 2), "unit": "GB/s",
+                              "frac": round(frame_gbs / HBM_PEAK_GBS, 5),
+                              "frac_of_copy_bandwidth": round(frame_gbs / copy_gbs, 5) if copy_gbs else None},
+                    # the kernels that ARE plain HBM streams, each alone on the device, algorithmic bytes only
+                    "streaming_kernels": {s: stage_row(s) for s in STREAMING if per_launch.get(s, 0) > 0},
+                    "hbm_copy_kernel_gbs": round(copy_gbs, 1),
+                    "stage_ms_per_launch_alone": {k: round(v, 5) for k, v in per_launch.items()}}
+
+        # ---- latency: one frame at a time (what the drop-in Segmenter / Clusterer classes do per callback) ----
+        if not args.no_latency:
+            hf = host_frames[my_ids[0]]
+            n0 = hf.shape[0]
+            one = Context(local_rank)  # single-frame context: LPX_NEIGHBOURS_AUTO = lists, the low-latency mode
+            one.reserve(n0)
+
+            def med(fn, reps=15):
+                fn()
+                ts = []
+                for _ in range(reps):
+                    a = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - a)
+                return float(np.median(ts)) * 1e3
+
+            def dev_call():
+                one.segment_cluster_device(d_pts[0].data_ptr(), 32, n0, scfg, ccfg, d_labels[0].data_ptr(),
+                                           d_gidx[0].data_ptr(), d_oidx[0].data_ptr(), d_planes[0].data_ptr(),
+                                           d_clabels[0].data_ptr(), d_counts[0].data_ptr())
+                one.synchronize()
+
+            dev_ms = med(dev_call)
+            pageable = np.ascontiguousarray(hf)
+            host_ms = med(lambda: one.segment_cluster(pageable, scfg, ccfg))
+            # pinned: input and every result array page-locked (lpx_host_alloc)
+            import ctypes as Cc
+            pin_in = PinnedArray(hf.shape, np.float32)
+            pin_in.array[:] = hf
+            outs = [PinnedArray(n0, np.uint32) for _ in range(3)] + [PinnedArray(n0, np.int32), PinnedArray(4 * P, np.float32)]
+            ng, no, nc = Cc.c_uint32(0), Cc.c_uint32(0), Cc.c_uint32(0)
+            sc, cc = scfg._c(), ccfg._c()
+
+            def pinned_call():
+                one.check(one._L.lpx_segment_cluster(one._h, pin_in.array.ctypes.data, 16, n0, Cc.byref(sc), Cc.byref(cc),
+                                                     outs[0].array.ctypes.data, outs[1].array.ctypes.data, Cc.byref(ng),
+                                                     outs[2].array.ctypes.data, Cc.byref(no), outs[4].array.ctypes.data,
+                                                     outs[3].array.ctypes.data, Cc.byref(nc)))
+
+            pin_ms = med(pinned_call)
+            one.set_neighbour_mode("search")
+            dev_search_ms = med(dev_call)
+            one.close()
+            latency = {"frame_points": n0, "what": "one frame at a time on a single-frame context, median of 15",
+                       "device_resident_ms": round(dev_ms, 4), "device_resident_mpts_s": round(n0 / dev_ms / 1e3, 2),
+                       "host_api_pageable_ms": round(host_ms, 4), "host_api_pinned_ms": round(pin_ms, 4),
+                       "host_api_pinned_mpts_s": round(n0 / pin_ms / 1e3, 2),
+                       "device_resident_ms_search_mode": round(dev_search_ms, 4),
+                       "note": "single-frame contexts default to LPX_NEIGHBOURS_LISTS (shortest critical path); the "
+                               "throughput figure uses LPX_NEIGHBOURS_SEARCH"}
+
+        # ---- stream: the same frames through the feeder (PCIe-inclusive) ----
+        if args.workload == "stream":
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                paths = []
+                for j, hf in enumerate(host_frames):
+                    paths.append(os.path.join(tmp, f"{j:010d}.pcd"))
+                    write_pcd(paths[-1], hf)
+                feeder = Feeder(paths, local_rank)
+                ids = np.array(my_ids, np.uint32)
+                out = feeder.run(ctxs[0], ids, scfg, ccfg)
+                a = time.perf_counter()
+                passes = 3
+                for _ in range(passes):
+                    feeder.run(ctxs[0], ids, scfg, ccfg, out)
+                tf = (time.perf_counter() - a) / passes
+                feeder.close()
+            stream_info = {"frames": len(my_ids), "device_resident_frames_per_s": round(F * world * args.steps / elapsed, 1),
+                           "feeder_frames_per_s": round(len(ids) / tf, 1),
+                           "feeder_mpts_s": round(points_per_step / tf / 1e6, 2),
+                           "feeder_what": "lpx_feeder_run on ONE batch context: pinned records H2D, chains of "
+                                          f"{B}, exact-size D2H of labels / index lists / cluster labels / planes, "
+                                          "two buffer sets (PCIe-inclusive; never the headline value)"}
 
     if rank == 0:
         value = total_points_per_step * args.steps / elapsed / 1e6
         line = {
-            "metric": "Mpts/s seg+cluster (120k-pt frame)",
+            "metric": "Mpts/s seg+cluster (120k-pt frame)" if args.workload in ("kitti", "stream")
+                      else f"Mpts/s seg+cluster ({args.workload})",
             "value": round(value, 3),
             "unit": "Mpts/s",
             "n_gpus": world,
@@ -310,17 +479,21 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "real KITTI frames (committed fixture of the reference's data/*.pcd), random-free",
-            "config": {"workload": "configs[1]: 120k-pt KITTI frames, 6 segments, 5 iters, FEC d=0.5 m q=0.5",
+            "data": ("real KITTI frames (committed fixture of the reference's data/*.pcd)" if args.workload in ("kitti", "stream")
+                     else "synthetic plane + boxes cloud (SURVEY 8d generator, 1 mm quantised)"),
+            "config": {"workload": wl["config"], "neighbour_mode": "lists" if args.lists else "search",
                        "frames_per_step_per_gpu": F, "frames_per_launch_chain": B, "contexts_per_gpu": C,
-                       "host_threads_per_gpu": T,
-                       "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "host_threads_per_gpu": T, "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "points_per_step": int(total_points_per_step),
                        "frames_per_s": round(F * world * args.steps / elapsed, 2)},
+            "vs_target": {"north_star_mpts_s": 50.0, "ratio": round(value / 50.0, 2)},
             "roofline": roofline,
+            "latency": latency,
             "cpu_baseline": cpu,
             "stage_ms_per_frame_under_load": {k: round(v / (args.steps * F), 5) for k, v in stage_ms.items()},
         }
+        if stream_info:
+            line["stream"] = stream_info
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -43,6 +43,10 @@ int lpx_dbg_plane(lpx_ctx *ctx, const float *xyz, uint32_t n, float *plane);
  * with an expansion, searches redone by the sequencer (list larger than its LDS region)} */
 int lpx_dbg_search_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *out4);
 
+/* achievable HBM bandwidth of this device: GB/s (read + write) of a plain 16-byte-per-lane streaming copy of
+ * `bytes` bytes, `reps` launches timed with HIP events */
+int lpx_dbg_copy_bandwidth(lpx_ctx *ctx, size_t bytes, uint32_t reps, double *gb_per_s);
+
 /* tools only: per-group statistics of the neighbour kernel, 8 words per kd group ({candidates, intervals,
  * queries, list words, cycles to allocation, cycles total, -, -}).  n_groups > 0 with out == NULL arms the
  * collection for the following calls, out != NULL copies what was collected, n_groups == 0 switches it off. */

@@ -272,6 +272,13 @@ class Context:
                     replay_entries=int(o[8]) | (int(o[9]) << 32), neighbour_words=int(o[10]) | (int(o[11]) << 32),
                     candidates=int(s4[0]) | (int(s4[1]) << 32), windows=int(s4[2]), overflows=int(s4[3]))
 
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        """lpx_dbg_copy_bandwidth: GB/s (read + write) of a streaming device copy -- the achievable HBM bandwidth"""
+        g = C.c_double(0.0)
+        self._L.lpx_dbg_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_double)]
+        self.check(self._L.lpx_dbg_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(g)))
+        return g.value
+
     # ---- stage-level entry points (parity tests) ----
     def dbg_sort_pairs(self, keys, values, bits=32):
         k = np.array(keys, dtype=np.uint32)

@@ -1278,6 +1278,61 @@ extern "C" int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     return LPX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// achievable HBM bandwidth: a plain streaming copy (16 bytes per lane, grid-stride), timed with HIP events
+// on the context stream.  Reported next to the 8 TB/s nominal peak.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16)
+{
+    // four independent 16-byte loads per lane and trip keep ~16 KiB in flight per workgroup
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride)
+    {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride)
+        dst[i] = src[i];
+}
+
+extern "C" int lpx_dbg_copy_bandwidth(lpx_ctx *ctx, size_t bytes, uint32_t reps, double *gb_per_s)
+{
+    if (!ctx || !gb_per_s || bytes < 4096 || reps == 0)
+        return LPX_ERR_ARG;
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    void *a = nullptr, *b = nullptr;
+    LPX_HIP(ctx, hipMalloc(&a, bytes));
+    if (hipMalloc(&b, bytes) != hipSuccess)
+    {
+        hipFree(a);
+        return lpx_fail(ctx, LPX_ERR_HIP, "hipMalloc of the copy destination failed");
+    }
+    hipMemsetAsync(a, 1, bytes, ctx->stream);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const size_t n16 = bytes / 16;
+    const dim3 grid(256 * 8), blk(256);  // 8 workgroups per CU
+    hipLaunchKernelGGL(copy_kernel, grid, blk, 0, ctx->stream, (const float4 *)a, (float4 *)b, n16);  // warm-up
+    hipEventRecord(e0, ctx->stream);
+    for (uint32_t r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(copy_kernel, grid, blk, 0, ctx->stream, (const float4 *)a, (float4 *)b, n16);
+    hipEventRecord(e1, ctx->stream);
+    hipEventSynchronize(e1);
+    float ms = 0.0f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(a);
+    hipFree(b);
+    *gb_per_s = ms > 0.0f ? 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;  // read + write
+    return LPX_OK;
+}
+
 int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out);
 
 // plane of all n points through the device moment + Jacobi path; returns 1 if the fit failed (n < 3)

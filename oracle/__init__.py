@@ -117,6 +117,11 @@ def segment(points, cfg=None):
                 planes=planes[:P], status=status[:P], rc=rc)
 
 
+def set_sort_threads(n):
+    """threads of the two index sorts in segment() (the reference's std::sort(std::execution::par)); default 1"""
+    lib().orc_set_sort_threads(C.c_int(int(n)))
+
+
 def cluster(points, cfg=None, stats=False):
     """Clusterer::cluster restated.  Returns (labels int32, n_clusters[, expansions, visits])."""
     cfg = cfg or CluCfg()

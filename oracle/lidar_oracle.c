@@ -30,6 +30,8 @@ typedef struct
 } key_idx;
 
 /* total order (key, idx): what a stable sort of iota by key gives.  Canonical tie rule (H2). */
+static int cmp_key_idx(const void *pa, const void *pb);
+static void sort_key_idx(void *base, size_t n);
 static int cmp_key_idx(const void *pa, const void *pb)
 {
     const key_idx *a = (const key_idx *)pa;
@@ -45,6 +47,87 @@ static int cmp_key_idx(const void *pa, const void *pb)
 /* 3x3 Jacobi SVD: Eigen 3.4 JacobiSVD<Matrix3f>::compute as used at src/segmentation.cpp:87-94 */
 /* (Eigen/src/SVD/JacobiSVD.h, Eigen/src/Jacobi/Jacobi.h; square real case, V only).            */
 /* ------------------------------------------------------------------------------------------ */
+
+/* The reference's only parallelism is these two index sorts: std::sort(std::execution::par) maps onto TBB
+ * (src/segmentation.cpp:119-122, :165-168).  For the "reference-like" CPU baseline of bench.py the restatement
+ * can run them on several threads too: chunks are qsort'ed concurrently and merged pairwise (the order is total,
+ * so the result does not depend on the thread count).  Default 1 thread. */
+#include <pthread.h>
+static int g_sort_threads = 1;
+
+void orc_set_sort_threads(int n)
+{
+    g_sort_threads = n < 1 ? 1 : n;
+}
+
+typedef struct
+{
+    key_idx *a, *tmp;
+    size_t lo, mid, hi;
+} sort_job;
+
+static void *sort_chunk_job(void *arg)
+{
+    sort_job *j = (sort_job *)arg;
+    qsort(j->a + j->lo, j->hi - j->lo, sizeof(key_idx), cmp_key_idx);
+    return NULL;
+}
+
+static void *merge_job(void *arg)
+{
+    sort_job *j = (sort_job *)arg;
+    size_t i = j->lo, k = j->mid, o = j->lo;
+    while (i < j->mid && k < j->hi)
+        j->tmp[o++] = cmp_key_idx(&j->a[k], &j->a[i]) < 0 ? j->a[k++] : j->a[i++];
+    while (i < j->mid)
+        j->tmp[o++] = j->a[i++];
+    while (k < j->hi)
+        j->tmp[o++] = j->a[k++];
+    memcpy(j->a + j->lo, j->tmp + j->lo, sizeof(key_idx) * (j->hi - j->lo));
+    return NULL;
+}
+
+static void sort_key_idx(void *base, size_t n)
+{
+    size_t t = (size_t)g_sort_threads;
+    if (t > n / 8192)
+        t = n / 8192; /* grain: threads only pay off on chunks of thousands of keys */
+    if (t < 2)
+    {
+        qsort(base, n, sizeof(key_idx), cmp_key_idx);
+        return;
+    }
+    key_idx *a = (key_idx *)base, *tmp = (key_idx *)malloc(sizeof(key_idx) * n);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * t);
+    sort_job *jobs = (sort_job *)malloc(sizeof(sort_job) * t);
+    size_t *cut = (size_t *)malloc(sizeof(size_t) * (t + 1));
+    for (size_t c = 0; c <= t; ++c)
+        cut[c] = n * c / t;
+    for (size_t c = 0; c < t; ++c)
+    {
+        jobs[c] = (sort_job){a, tmp, cut[c], 0, cut[c + 1]};
+        pthread_create(&th[c], NULL, sort_chunk_job, &jobs[c]);
+    }
+    for (size_t c = 0; c < t; ++c)
+        pthread_join(th[c], NULL);
+    for (size_t width = 1; width < t; width *= 2) /* pairwise merges, each round in parallel */
+    {
+        size_t nj = 0;
+        for (size_t c = 0; c + width < t; c += 2 * width)
+        {
+            const size_t hi = c + 2 * width < t ? c + 2 * width : t;
+            jobs[nj] = (sort_job){a, tmp, cut[c], cut[c + width], cut[hi]};
+            pthread_create(&th[nj], NULL, merge_job, &jobs[nj]);
+            ++nj;
+        }
+        for (size_t c = 0; c < nj; ++c)
+            pthread_join(th[c], NULL);
+    }
+    free(cut);
+    free(jobs);
+    free(th);
+    free(tmp);
+}
 
 typedef struct
 {
@@ -357,7 +440,7 @@ int orc_segment(const void *pts, size_t stride, uint32_t n, const orc_seg_cfg *c
         sx[i].key = pt_at(pts, stride, i)[0];
         sx[i].idx = i;
     }
-    qsort(sx, n, sizeof(key_idx), cmp_key_idx);
+    sort_key_idx(sx, n); /* :119-122 std::sort(std::execution::par, ...) */
 
     const uint32_t n_per = n / P; /* :124 */
     key_idx *sz = (key_idx *)malloc(sizeof(key_idx) * (n_per ? n_per : 1));
@@ -378,7 +461,7 @@ int orc_segment(const void *pts, size_t stride, uint32_t n, const orc_seg_cfg *c
             sz[k].key = pt_at(pts, stride, seg[k].idx)[2];
             sz[k].idx = k;
         }
-        qsort(sz, ns, sizeof(key_idx), cmp_key_idx);
+        sort_key_idx(sz, ns); /* :165-168 std::sort(std::execution::par, ...) */
         const float z_floor = -1.5f * cfg->sensor_height_m; /* :171 */
         uint32_t cut_lo = 0;
         for (uint32_t i = 0; i < ns; ++i)

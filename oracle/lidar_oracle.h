@@ -74,6 +74,10 @@ int orc_segment(const void *pts, size_t stride_bytes, uint32_t n, const orc_seg_
                 uint32_t *ground_idx, uint32_t *n_ground, uint32_t *obstacle_idx, uint32_t *n_obstacle,
                 float *planes, uint32_t *seg_status);
 
+/* threads for the two index sorts of orc_segment (the reference runs them with std::execution::par, its only
+ * parallelism): 1 by default; results do not depend on it */
+void orc_set_sort_threads(int n);
+
 /* Clusterer::cluster, src/clustering.cpp:47-125 over src/kdtree.hpp:174-225,292-341. */
 int orc_cluster(const void *pts, size_t stride_bytes, uint32_t m, const orc_clu_cfg *cfg, int32_t *labels,
                 uint32_t *n_clusters);
