@@ -19,6 +19,7 @@
 #include "lpx_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace
 {
@@ -475,38 +476,38 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
 // it, against the candidate chunks of the point's kd group (lpx_kdtree.hip: nb_index_kernel).  Nothing is
 // materialised for the ~80 % of the points the reference never expands.
 //
-// One workgroup of four wavefronts per component set (lpx_grid_components), persistent over a work list.
-// Wavefront 0 is the sequencer: seeds, the queue window, the in-window expansion selection, and the ordered
-// application of every neighbour (touch / absorb / queue) to the 2-bit point states.  The expansions of a window
-// are known before any of them is applied (see replay_lds_kernel), so all four wavefronts SEARCH them in parallel
-// (expansion e goes to wavefront e % 4): read the chunk table of the expansion's kd group, cull the chunks against
-// the query ball, load the surviving candidates (16 bytes each, independent loads, eight chunks in flight), apply
-// the reference's float distance expression and leave the hits -- index | absorb << 31, in candidate = pre-order
-// order -- in the wavefront's LDS region.  The sequencer then applies the lists in expansion order.  A list that
-// does not fit its region is redone by the sequencer itself, streaming candidates straight into the apply step.
-// (Splitting ONE search over the four wavefronts was measured and is slower: the per-search setup, not the
-// candidate tests, dominates.)
-// Point states: STATE_LDS keeps them as a 2-bit LDS bitmap of `cap_pts` points; frames with more obstacle points
-// are served by a second launch (larger bitmap, or one byte per point in HBM).  Each launch checks on the device
-// whether the frame is its own.
+// This is the THROUGHPUT path (batch contexts): a single frame alone on the device is served faster by the list
+// path, whose whole-device list build shortens the critical path.  So the kernel is organised for the least work
+// and the most independent wavefronts, not for the latency of one component: every wavefront is a complete
+// sequencer for its own component (work list, seeds, queue windows, in-window expansion selection -- see
+// replay_lds_kernel -- search, ordered application); the eight wavefronts of a workgroup only share the LDS bitmap
+// of point states (components own disjoint points).  A search is one load of the group's chunk table (prefetched one
+// expansion ahead), a cull of the chunks against the query ball, and one independent 16-byte load per surviving
+// candidate (eight chunks in flight); the reference's float distance expression is applied per candidate and the
+// hits go straight into the apply step in candidate (= pre-order) order -- no list is ever stored, not even in LDS.
+// (A cooperative variant -- four wavefronts searching the expansions of one window in parallel, hit lists in LDS --
+// was built and measured: it halves the latency of one component but costs 40 % more LDS and three mostly idle
+// wavefronts per workgroup; and splitting ONE search over several wavefronts is slower than not splitting it,
+// because the per-search setup, not the candidate tests, dominates.)
+// Point states: STATE_LDS keeps them as a 2-bit LDS bitmap; frames with more obstacle points than the small launch
+// covers are served by a second launch (larger bitmap, or one byte per point in HBM).  Each launch checks on the
+// device whether a frame is its own.
 // ------------------------------------------------------------------------------------------------
-constexpr int RS_WAVES = 4;
+#ifndef LPX_RS_WAVES
+#define LPX_RS_WAVES 8
+#endif
+constexpr int RS_WAVES = LPX_RS_WAVES;
 constexpr int RS_THREADS = RS_WAVES * WAVE;
-constexpr int RS_REGION = 1024;              // words of hit-list space per wavefront and window
-constexpr int RS_RING = 2048;                // queue entries mirrored in LDS
+#ifndef LPX_RS_RING
+#define LPX_RS_RING 256
+#endif
+constexpr int RS_RING = LPX_RS_RING;         // queue entries mirrored in LDS, per wavefront
 constexpr int RS_BATCH = 8;                  // candidate chunks in flight per wavefront
-constexpr uint32_t RS_OVERFLOW = 0xffffffffu;
-constexpr uint32_t RS_DONE = 0xffffffffu;
 constexpr uint32_t RS_SMALL_PTS = 65536;     // obstacle points the small-LDS launch serves (16 KiB bitmap)
 
 struct RsShared  // fixed part of the LDS of replay_search_kernel (the bitmap follows)
 {
-    uint32_t ring[RS_RING];
-    uint32_t lists[RS_WAVES * RS_REGION];
-    uint32_t ej[WAVE], eg[WAVE];         // expansions of the window: point index, kd group ...
-    float ex[WAVE], ey[WAVE], ez[WAVE];  // ... and coordinates
-    uint32_t eoff[WAVE], elen[WAVE];     // hit list of expansion e: offset into lists[], length (RS_OVERFLOW: did not fit)
-    uint32_t ctl[4];                     // 0: number of expansions of the window / RS_DONE
+    uint32_t ring[RS_WAVES][RS_RING];
 };
 
 typedef float4 KdNode;
@@ -532,9 +533,9 @@ __device__ __forceinline__ unsigned long long rs_cull(const ChunkRec &ch, float 
 }
 
 // Tests the chunks named by the bits of `km` (lane c of `ch` describes chunk c) in order; SINK(word) gets the
-// per-lane list words of every chunk step and returns false to stop.
+// per-lane list words of every chunk step.
 template <class Sink>
-__device__ __forceinline__ bool rs_scan(const KdNode *__restrict__ PR, const ChunkRec &ch, unsigned long long km,
+__device__ __forceinline__ void rs_scan(const KdNode *__restrict__ PR, const ChunkRec &ch, unsigned long long km,
                                         float qx, float qy, float qz, float r2, float thr_f, uint32_t lane,
                                         unsigned long long &cand, Sink &&sink)
 {
@@ -562,20 +563,17 @@ __device__ __forceinline__ bool rs_scan(const KdNode *__restrict__ PR, const Chu
             if (cnt[u] == 0u)
                 break;
             cand += min(cnt[u], 64u);
-            if (!sink(rs_test(nd[u], lane < cnt[u], qx, qy, qz, r2, thr_f)))
-                return false;
+            sink(rs_test(nd[u], lane < cnt[u], qx, qy, qz, r2, thr_f));
             // the long tail chunk of a group with more than 64 chunks: the rest of its ranks, 64 at a time
             for (uint32_t o = 64; o < cnt[u]; o += 64)
             {
                 const bool v = o + lane < cnt[u];
                 const KdNode n2 = PR[v ? rk[u] + o + lane : 0u];
                 cand += min(cnt[u] - o, 64u);
-                if (!sink(rs_test(n2, v, qx, qy, qz, r2, thr_f)))
-                    return false;
+                sink(rs_test(n2, v, qx, qy, qz, r2, thr_f));
             }
         }
     }
-    return true;
 }
 
 template <bool STATE_LDS>
@@ -609,70 +607,19 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const uint32_t M = frame->n_obstacle;
     const uint32_t n_roots = frame->n_roots;
     // this launch serves the frames with m_lo < M <= m_hi obstacle points (another launch takes the rest)
-    if (M <= m_lo || M > m_hi || blockIdx.x >= n_roots)
+    if (M <= m_lo || M > m_hi || blockIdx.x * RS_WAVES >= n_roots)
         return;
     if (STATE_LDS)
     {
-        // zeroed once: component sets own disjoint points, so one set never reads the states of another
+        // zeroed once: components own disjoint points, so one never reads the states of another
         const uint32_t words = (M + 15) / 16;
         for (uint32_t i = tid; i < words; i += RS_THREADS)
             sbits[i] = 0;
     }
-    __syncthreads();
+    __syncthreads();  // the only workgroup barrier: from here on the wavefronts are independent sequencers
     const unsigned long long lt = lpx_lanemask_lt();
     const float r2 = prm.r2, thr_f = prm.thr_f;
-    unsigned long long st_cand = 0;
-
-    // Search phase of a window of E expansions: expansion e belongs to wavefront e % 4, which culls the chunk table
-    // of e's kd group against the query ball, loads and tests the surviving chunks and leaves the hits in its region
-    auto search_window = [&](uint32_t E) {
-        uint32_t *dst = sh.lists + w * RS_REGION;
-        uint32_t fill = 0;
-        for (uint32_t e = w; e < E; e += RS_WAVES)
-        {
-            const ChunkRec ch = chunks[(size_t)sh.eg[e] * LPX_GROUP_CHUNKS + lane];
-            const float qx = sh.ex[e], qy = sh.ey[e], qz = sh.ez[e];
-            uint32_t len = 0;
-            bool ok = fill != RS_OVERFLOW;
-            if (ok)
-                ok = rs_scan(PR, ch, rs_cull(ch, qx, qy, qz, r2), qx, qy, qz, r2, thr_f, lane, st_cand,
-                             [&](uint32_t word) -> bool {
-                                 const bool hit = word != 0xffffffffu;
-                                 const unsigned long long hm = __ballot(hit);
-                                 if (fill + len + (uint32_t)__popcll(hm) > (uint32_t)RS_REGION)
-                                     return false;
-                                 if (hit)
-                                     dst[fill + len + __popcll(hm & lt)] = word;
-                                 len += (uint32_t)__popcll(hm);
-                                 return true;
-                             });
-            if (lane == 0)
-            {
-                sh.eoff[e] = w * RS_REGION + fill;
-                sh.elen[e] = ok ? len : RS_OVERFLOW;
-            }
-            fill = ok ? fill + len : RS_OVERFLOW;  // once a list did not fit, the later ones of this wavefront do not either
-        }
-    };
-
-    if (w != 0)
-    {
-        // helper wavefronts: their share of every window the sequencer publishes
-        for (;;)
-        {
-            __syncthreads();  // A: window published
-            const uint32_t E = sh.ctl[0];
-            if (E == RS_DONE)
-                break;
-            search_window(E);
-            __syncthreads();  // B: sub-lists ready
-        }
-        if (lane == 0 && st_cand)
-            atomicAdd((unsigned long long *)&fstate->cand_total, st_cand);
-        return;
-    }
-
-    // ---- sequencer (wavefront 0) ----
+    uint32_t *ring = sh.ring[w];
 #define ST_GET(k) (STATE_LDS ? ((sbits[(k) >> 4] >> (((k) & 15u) * 2u)) & 3u) : (uint32_t)gstate[k])
 #define ST_OR(k, v)                                                                                                   \
     do                                                                                                                \
@@ -682,20 +629,8 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
         else                                                                                                          \
             gstate[k] = (uint8_t)(gstate[k] | (v));                                                                   \
     } while (0)
-    unsigned long long st_entries = 0;
-    uint32_t st_exp = 0, st_win = 0, st_ovf = 0;
-#ifdef LPX_RS_TIMING
-    unsigned long long tm_a = 0, tm_b = 0, tm_c = 0, tm_other = 0, tm_t0 = __builtin_amdgcn_s_memtime(), tm_x;
-#define TM_MARK(acc)                                                                                                  \
-    do                                                                                                                \
-    {                                                                                                                 \
-        tm_x = __builtin_amdgcn_s_memtime();                                                                          \
-        acc += tm_x - tm_t0;                                                                                          \
-        tm_t0 = tm_x;                                                                                                 \
-    } while (0)
-#else
-#define TM_MARK(acc)
-#endif
+    unsigned long long st_entries = 0, st_cand = 0;
+    uint32_t st_exp = 0, st_win = 0;
     for (;;)
     {
         uint32_t ticket = 0;
@@ -734,15 +669,19 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
             if (lane == 0)
             {
                 q[0] = seed;
-                sh.ring[0] = seed;
+                ring[0] = seed;
                 ST_OR(seed, 1u);
                 seed_of[seed] = (int32_t)seed;  // queued before it is ever touched
             }
             if (!STATE_LDS)
                 __threadfence_block();
-            // applies one chunk step of list words in order (:92-110): touch, absorb or queue
+            // one chunk step of list words in order (:92-110): touch, absorb or queue
             auto apply = [&](uint32_t word) {
                 const bool in = word != 0xffffffffu;
+                const unsigned long long im = __ballot(in);
+                if (!im)
+                    return;  // no candidate of this chunk is a neighbour
+                st_entries += __popcll(im);
                 const uint32_t k = in ? (word & 0x7fffffffu) : 0u;
                 const uint32_t sk = in ? ST_GET(k) : 2u;
                 const bool vis = in && !(sk & 2u);
@@ -758,7 +697,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 {
                     const uint32_t qi = qt + __popcll(pm & lt);
                     q[qi] = k;
-                    sh.ring[qi % RS_RING] = k;
+                    ring[qi % RS_RING] = k;
                     ST_OR(k, 1u);
                 }
                 qt += __popcll(pm);
@@ -767,7 +706,6 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
             };
             while (qh < qt)
             {
-                TM_MARK(tm_other);
                 // a window of up to 64 pops; which of them the reference expands is decided in registers (see
                 // replay_lds_kernel): a candidate is skipped iff it is removed already or an EXPANDED earlier
                 // candidate of the window holds it within the absorb radius
@@ -776,7 +714,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 const bool inw = lane < wn;
                 uint32_t wcand;
                 if (qt - qh <= (uint32_t)RS_RING)
-                    wcand = inw ? sh.ring[(wb + lane) % RS_RING] : 0u;
+                    wcand = inw ? ring[(wb + lane) % RS_RING] : 0u;
                 else
                 {
                     __threadfence_block();
@@ -803,80 +741,45 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 qh = wb + wn;
                 if (!em)
                     continue;
-                // publish the expansions of the window
-                const uint32_t E = (uint32_t)__popcll(em);
-                if ((em >> lane) & 1ull)
-                {
-                    const uint32_t e = (uint32_t)__popcll(em & lt);
-                    sh.ej[e] = wcand;
-                    sh.eg[e] = wg;
-                    sh.ex[e] = wx;
-                    sh.ey[e] = wy;
-                    sh.ez[e] = wz;
-                }
-                if (lane == 0)
-                    sh.ctl[0] = E;
-                TM_MARK(tm_a);
-                __syncthreads();  // A
-                search_window(E);
-                __syncthreads();  // B
-                TM_MARK(tm_b);
-                st_exp += E;
                 ++st_win;
-                for (uint32_t e = 0; e < E; ++e)
+                // the expansions of the window, in order; the chunk table of the next one is requested before the
+                // current one is searched
+                int e = __ffsll((long long)em) - 1;
+                em &= em - 1;
+                ChunkRec ch = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, e) * LPX_GROUP_CHUNKS + lane];
+                for (;;)
                 {
-                    const uint32_t len = sh.elen[e];
-                    if (len == RS_OVERFLOW)
+                    const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), e));
+                    const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), e));
+                    const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), e));
+                    const int e_next = em ? __ffsll((long long)em) - 1 : -1;
+                    ChunkRec ch_next = ch;
+                    if (e_next >= 0)
                     {
-                        // did not fit its region: search again, streaming every chunk step into the apply
-                        ++st_ovf;
-                        const ChunkRec ch = chunks[(size_t)sh.eg[e] * LPX_GROUP_CHUNKS + lane];
-                        const float qx = sh.ex[e], qy = sh.ey[e], qz = sh.ez[e];
-                        rs_scan(PR, ch, rs_cull(ch, qx, qy, qz, r2), qx, qy, qz, r2, thr_f, lane, st_cand,
-                                [&](uint32_t word) -> bool {
-                                    st_entries += __popcll(__ballot(word != 0xffffffffu));
-                                    apply(word);
-                                    return true;
-                                });
-                        continue;
+                        em &= em - 1;
+                        ch_next = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, e_next) * LPX_GROUP_CHUNKS + lane];
                     }
-                    st_entries += len;
-                    const uint32_t *src = sh.lists + sh.eoff[e];
-                    for (uint32_t t0 = 0; t0 < len; t0 += WAVE)
-                        apply(t0 + lane < len ? src[t0 + lane] : 0xffffffffu);
+                    ++st_exp;
+                    rs_scan(PR, ch, rs_cull(ch, qx, qy, qz, r2), qx, qy, qz, r2, thr_f, lane, st_cand, apply);
+                    if (e_next < 0)
+                        break;
+                    e = e_next;
+                    ch = ch_next;
                 }
-                TM_MARK(tm_c);
             }
             if (lane == 0)
                 valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;  // :113
         }
     }
-    if (lane == 0)
-        sh.ctl[0] = RS_DONE;
-    __syncthreads();  // A: releases the helper wavefronts
-    if (lane == 0)
+    if (lane == 0 && st_exp)
     {
-        if (st_exp)
-        {
-            atomicAdd((unsigned long long *)&fstate->replay_entries, st_entries);
-            atomicAdd(&fstate->n_expansions, st_exp);
-            atomicAdd(&fstate->n_windows, st_win);
-            if (st_ovf)
-                atomicAdd(&fstate->n_overflow, st_ovf);
-        }
-        if (st_cand)
-            atomicAdd((unsigned long long *)&fstate->cand_total, st_cand);
-#ifdef LPX_RS_TIMING
-        // diagnostic build: cycles of the sequencer per bucket, summed over workgroups (reuses list-path counters)
-        atomicAdd((unsigned long long *)&fstate->nb_total, tm_a);      // gather + window selection
-        atomicAdd((unsigned long long *)&fstate->nb_entries, tm_b);    // search (barrier A .. barrier B)
-        atomicAdd(&fstate->n_overflow, (uint32_t)(tm_c >> 10));       // apply, kilo-cycles
-        atomicMax((unsigned long long *)&fstate->cand_total, tm_a + tm_b + tm_c + tm_other);  // busiest workgroup
-#endif
+        atomicAdd((unsigned long long *)&fstate->replay_entries, st_entries);
+        atomicAdd(&fstate->n_expansions, st_exp);
+        atomicAdd(&fstate->n_windows, st_win);
+        atomicAdd((unsigned long long *)&fstate->cand_total, st_cand);
     }
 #undef ST_GET
 #undef ST_OR
-#undef TM_MARK
 }
 
 __global__ void relabel_kernel(FrameState *frame, const int32_t *__restrict__ seed_of,
@@ -1237,7 +1140,14 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             ctx->attr_search = true;
         }
-        const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: workgroups pull component sets from a list
+        // persistent: every wavefront pulls components from the work list; 1024 workgroups x 4 wavefronts per frame
+        // Workgroups per frame: a sequencer wavefront needs little of a CU but holds its LDS for milliseconds, so a
+        // chain keeps its resident footprint small (about 256 workgroups in all, at least 8 per frame: 64
+        // sequencers; proportionally more for frames beyond 128k points) and leaves the CUs to the short, wide kernels of the other chains in flight (measured: 1125 ->
+        // 1230 Mpts/s against 1024 workgroups per frame).  LPX_RS_GRID overrides the per-frame count.
+        static const uint32_t rg_env = getenv("LPX_RS_GRID") ? (uint32_t)atoi(getenv("LPX_RS_GRID")) : 0u;
+        uint32_t rg_cap = rg_env ? rg_env : (256u / ctx->cur_b > 8u ? 256u / ctx->cur_b : 8u) * (1u + m_max / 131072u);
+        const uint32_t rgrid = (m_max + RS_WAVES - 1) / RS_WAVES < rg_cap ? (m_max + RS_WAVES - 1) / RS_WAVES : rg_cap;
 #define RS_ARGS(lo_, hi_)                                                                                             \
     (const FrameState *)frame, (const uint32_t *)cc_lo, (const uint32_t *)cc_hi, (const uint32_t *)members,            \
         (const KdNode *)ctx->nodes_pre.p, (const ChunkRec *)ctx->chunks.p, (const uint32_t *)ctx->grp_of.p,            \
@@ -1255,7 +1165,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                 hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS),
                                    fixed + bitmap_bytes(m_max), st, RS_ARGS(RS_SMALL_PTS, m_max));
             else
-                hipLaunchKernelGGL(replay_search_kernel<false>, dim3(m_max < 4096u ? m_max : 4096u, 1, ctx->cur_b),
+                hipLaunchKernelGGL(replay_search_kernel<false>, dim3(m_max < 1024u ? m_max : 1024u, 1, ctx->cur_b),
                                    dim3(RS_THREADS), fixed, st, RS_ARGS(RS_SMALL_PTS, m_max));
         }
 #undef RS_ARGS

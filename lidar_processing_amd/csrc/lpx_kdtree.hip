@@ -1540,10 +1540,11 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
 // it expands it.  What CAN be prepared for all points at once is the traversal: one wavefront per kd group (a
 // bucket subtree of <= 64 nodes, or one node above the bucket level) walks the top levels for the group's box
 // (+ radius) exactly like the list kernel does and leaves the candidate set as <= 64 CHUNKS of consecutive
-// pre-order ranks, <= 64 nodes each, in pre-order: chunks[gid][lane] = (rank, count).  A search then costs
-// one 512-byte load of the chunk table and one 16-byte load per candidate, all independent.  If a group has more
+// pre-order ranks, <= 64 nodes each, in pre-order, each with the exact bounding box of its nodes:
+// chunks[gid][lane] = (rank, count, box).  A search then costs one 2 KiB load of the chunk table, a cull of the
+// chunks against its query ball and one 16-byte load per surviving candidate, all independent.  If a group has more
 // chunks than lanes the last one is long (covers the rest of the rank range, gaps included: nodes the traversal
-// pruned fail the distance test anyway).  grp_of[point] = gid.
+// pruned fail the distance test anyway) and is never culled.  grp_of[point] = gid.
 // ------------------------------------------------------------------------------------------------
 constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B + prefix = 4.6 KiB)
 
@@ -1691,19 +1692,26 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
             s_out[w][LPX_GROUP_CHUNKS - 1] = make_uint2(0u, 0u);
     }
     Coop<WAVE>::sync();
-    // bounding box of every chunk (a search culls chunks against its query ball before it loads a candidate):
-    // chunk c is reduced by the whole wavefront, lane c keeps the result
+    // Exact bounding box of every chunk (a search culls chunks against its query ball before it loads a candidate).
+    // Four chunks at a time, one per row of 16 lanes: a lane folds its 4 nodes of the chunk, the row reduces with
+    // DPP row shifts (the result sits in lane 15 of the row), and lane 4 i + row of the output keeps it.
     const uint2 mine = s_out[w][lane];
     const uint32_t stored = min(n_chunks, (uint32_t)LPX_GROUP_CHUNKS);
+    const uint32_t row = lane / 16, col = lane % 16;
     float lo0 = 0.0f, lo1 = 0.0f, lo2 = 0.0f, hi0 = 0.0f, hi1 = 0.0f, hi2 = 0.0f;
-    for (uint32_t c = 0; c < stored; ++c)
+    for (uint32_t c4 = 0; c4 < stored; c4 += 4)
     {
-        const uint2 cc = s_out[w][c];
+        const uint32_t c = c4 + row;
+        const uint2 cc = c < stored ? s_out[w][c] : make_uint2(0u, 0u);
         float a0 = 3.0e38f, a1 = 3.0e38f, a2 = 3.0e38f, b0 = -3.0e38f, b1 = -3.0e38f, b2 = -3.0e38f;
-        for (uint32_t o = 0; o < cc.y; o += WAVE)
-            if (o + lane < cc.y)
+        const uint32_t span = cc.y > 64u ? 64u : cc.y;  // the long tail chunk gets an unbounded box below
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            const uint32_t o = col + 16 * u;
+            const Node nd = PR[o < span ? cc.x + o : 0u];  // unconditional: the four loads go out together
+            if (o < span)
             {
-                const Node nd = PR[cc.x + o + lane];
                 a0 = fminf(a0, nd.x);
                 a1 = fminf(a1, nd.y);
                 a2 = fminf(a2, nd.z);
@@ -1711,21 +1719,38 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
                 b1 = fmaxf(b1, nd.y);
                 b2 = fmaxf(b2, nd.z);
             }
-        a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_min63_f32(a0)), WAVE - 1));
-        a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_min63_f32(a1)), WAVE - 1));
-        a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_min63_f32(a2)), WAVE - 1));
-        b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_max63_f32(b0)), WAVE - 1));
-        b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_max63_f32(b1)), WAVE - 1));
-        b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpx_wave_max63_f32(b2)), WAVE - 1));
-        if (lane == c)
-        {
-            lo0 = a0;
-            lo1 = a1;
-            lo2 = a2;
-            hi0 = b0;
-            hi1 = b1;
-            hi2 = b2;
         }
+        a0 = lpx_row_min15_f32(a0);
+        a1 = lpx_row_min15_f32(a1);
+        a2 = lpx_row_min15_f32(a2);
+        b0 = lpx_row_max15_f32(b0);
+        b1 = lpx_row_max15_f32(b1);
+        b2 = lpx_row_max15_f32(b2);
+        // row r's result (its lane 15) belongs to output lane c4 + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0), 16 * r + 15));
+            const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), 16 * r + 15));
+            const float v2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 16 * r + 15));
+            const float v3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0), 16 * r + 15));
+            const float v4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1), 16 * r + 15));
+            const float v5 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b2), 16 * r + 15));
+            if (lane == c4 + r)
+            {
+                lo0 = v0;
+                lo1 = v1;
+                lo2 = v2;
+                hi0 = v3;
+                hi1 = v4;
+                hi2 = v5;
+            }
+        }
+    }
+    if (mine.y > 64u)
+    {
+        lo0 = lo1 = lo2 = -3.0e38f;  // long tail chunk: never culled
+        hi0 = hi1 = hi2 = 3.0e38f;
     }
     ChunkRec rec;
     rec.rank = mine.x;
@@ -1740,22 +1765,27 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Expansion-driven search, part 2: components WITHOUT neighbour lists.
+// Expansion-driven search, part 2: the connected components of the d-graph WITHOUT neighbour lists.
 //
-// The replay only needs a partition of the points into sets that no BFS can leave, i.e. unions of connected
-// components of the d-graph (replaying a union of components in ascending seed order reproduces the reference's
-// labels exactly: seeds of different components never interact).  A uniform grid of cells with edge c >= d gives
-// one for free: two points within d lie in the same or in adjacent cells (26-neighbourhood), so the connected
-// components of the OCCUPIED-CELL adjacency graph are such unions -- no distance is ever computed.  On the
-// reference's frames this partition is barely coarser than the exact one (the largest set holds 1.2-1.8 x the
-// expansions of the largest true component, tools/cc_analysis.py) and costs ~7k cells x 13 lookups per frame.
-// Cell edge c = 1.01 d; the cell index floor(v / c) is evaluated in double precision, whose rounding (2^-53
-// relative, indices below 2^20) can never put two points within d more than one cell apart, however far from the
-// origin the cloud lies; indices saturate at +-2^20 cells (saturation is monotone, so adjacency is preserved).  Open-addressing table keyed by the packed index
-// triple; union-find over table slots (smaller slot wins); the representative of a cell is the point that
-// claimed it.
+// The replay needs sets of points that no BFS can leave.  A uniform grid with cell edge c = 0.99 d / sqrt(3) makes
+// every cell a CLIQUE of the d-graph (its diagonal is shorter than d), so the components are those of the graph
+// whose vertices are the occupied cells and whose edges are the cell pairs that hold a point pair within d.  A
+// point within d of a point of cell A lies at most 2 cells away on every axis (2 c > d), so each cell has 124
+// possible partners, 62 by symmetry: one wavefront per occupied cell probes them, one partner per lane, and a lane
+// that finds its partner occupied and not yet in the same set walks the partner's points against the cell's own
+// (staged in LDS) until the first pair within d -- the reference's float expression, inclusive -- and unites the
+// two cells.  Touching cells first, the others in a second launch that skips pairs already in one set.  (A coarser grid with
+// 26-adjacency and no distance test at all gives sets that are only unions of components; on the reference's
+// frames they are barely coarser, but on a cluttered scene -- BASELINE's synthetic box clouds -- they collapse
+// into one giant set and serialise the replay: measured 88 ms against 6 ms per 1M-point frame.)
+// Cell indices are floor(v / c) in double precision; indices saturate at +-2^20 cells, which can only merge
+// sets (allowed: a set may be a union of components, it must never split one).  Open-addressing table keyed by
+// the packed index triple; the points of a cell hang on a linked list (head per slot, next per point); union-find
+// over table slots.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned long long CELL_EMPTY = ~0ull;
+constexpr uint32_t CELL_NONE = 0xffffffffu;
+constexpr int CELL_STAGE = 32;  // points of the wavefront's own cell staged in LDS per pass
 
 __device__ __forceinline__ uint32_t cell_hash(unsigned long long k)
 {
@@ -1781,37 +1811,50 @@ __device__ __forceinline__ uint32_t cell_coord(float v, double inv_c)
     return (uint32_t)((int)f + 1048576);  // 21 bits
 }
 
-__global__ void grid_clear_kernel(const FrameState *__restrict__ frame, unsigned long long *__restrict__ tkey,
-                                  uint32_t *__restrict__ tparent, uint32_t cap_max, size_t fs)
+__host__ __device__ __forceinline__ double cell_inv_edge(float d)
+{
+    return 1.0 / ((double)d * 0.5716);  // edge = 0.99 d / sqrt(3): every cell is a clique
+}
+
+__global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long long *__restrict__ tkey,
+                                  uint32_t *__restrict__ tparent, uint32_t *__restrict__ thead, uint32_t cap_max,
+                                  size_t fs)
 {
     frame = lpx_slot(frame, fs);
     tkey = lpx_slot(tkey, fs);
     tparent = lpx_slot(tparent, fs);
+    thead = lpx_slot(thead, fs);
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0)
+        frame->n_cells = 0;
     if (s >= cell_cap_for(frame->n_obstacle, cap_max) || frame->n_obstacle == 0)
         return;
     tkey[s] = CELL_EMPTY;
     tparent[s] = s;
+    thead[s] = CELL_NONE;
 }
 
-__global__ void grid_insert_kernel(const FrameState *__restrict__ frame, const float *__restrict__ OX,
+__global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *__restrict__ OX,
                                    const float *__restrict__ OY, const float *__restrict__ OZ, float d,
-                                   unsigned long long *tkey, uint32_t *__restrict__ trep,
-                                   uint32_t *__restrict__ cell_of, uint32_t cap_max, size_t fs)
+                                   unsigned long long *tkey, uint32_t *thead, uint32_t *__restrict__ next,
+                                   uint32_t *__restrict__ cells, uint32_t *__restrict__ cell_of, uint32_t cap_max,
+                                   size_t fs)
 {
     frame = lpx_slot(frame, fs);
     OX = lpx_slot(OX, fs);
     OY = lpx_slot(OY, fs);
     OZ = lpx_slot(OZ, fs);
     tkey = lpx_slot(tkey, fs);
-    trep = lpx_slot(trep, fs);
+    thead = lpx_slot(thead, fs);
+    next = lpx_slot(next, fs);
+    cells = lpx_slot(cells, fs);
     cell_of = lpx_slot(cell_of, fs);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
     if (i >= M)
         return;
     const uint32_t mask = cell_cap_for(M, cap_max) - 1;
-    const double inv_c = 1.0 / ((double)d * 1.01);
+    const double inv_c = cell_inv_edge(d);
     const unsigned long long key = ((unsigned long long)cell_coord(OX[i], inv_c) << 42) |
                                    ((unsigned long long)cell_coord(OY[i], inv_c) << 21) |
                                    (unsigned long long)cell_coord(OZ[i], inv_c);
@@ -1821,7 +1864,7 @@ __global__ void grid_insert_kernel(const FrameState *__restrict__ frame, const f
         const unsigned long long old = atomicCAS(tkey + h, CELL_EMPTY, key);
         if (old == CELL_EMPTY)
         {
-            trep[h] = i;  // this point claimed the cell: it represents it
+            cells[atomicAdd(&frame->n_cells, 1u)] = h;  // this point claimed the cell: list it
             break;
         }
         if (old == key)
@@ -1829,59 +1872,151 @@ __global__ void grid_insert_kernel(const FrameState *__restrict__ frame, const f
         h = (h + 1) & mask;
     }
     cell_of[i] = h;
+    next[i] = atomicExch(thead + h, i);  // push on the cell's point list
 }
 
-__global__ void grid_link_kernel(const FrameState *__restrict__ frame, const unsigned long long *__restrict__ tkey,
-                                 uint32_t *tparent, uint32_t cap_max, size_t fs)
+__global__ __launch_bounds__(256) void grid_link_kernel(const FrameState *__restrict__ frame,
+                                                        const unsigned long long *__restrict__ tkey,
+                                                        uint32_t *tparent, const uint32_t *__restrict__ thead,
+                                                        const uint32_t *__restrict__ next,
+                                                        const uint32_t *__restrict__ cells,
+                                                        const float *__restrict__ OX, const float *__restrict__ OY,
+                                                        const float *__restrict__ OZ, float r2, uint32_t cap_max,
+                                                        uint32_t far_pass, size_t fs)
 {
+    __shared__ float s_a[4][CELL_STAGE][3];
     frame = lpx_slot(frame, fs);
     tkey = lpx_slot(tkey, fs);
     tparent = lpx_slot(tparent, fs);
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    thead = lpx_slot(thead, fs);
+    next = lpx_slot(next, fs);
+    cells = lpx_slot(cells, fs);
+    OX = lpx_slot(OX, fs);
+    OY = lpx_slot(OY, fs);
+    OZ = lpx_slot(OZ, fs);
     const uint32_t M = frame->n_obstacle;
     if (M == 0)
         return;
-    const uint32_t cap = cell_cap_for(M, cap_max), mask = cap - 1;
-    if (s >= cap)
-        return;
-    const unsigned long long key = tkey[s];
-    if (key == CELL_EMPTY)
-        return;
-    const int ix = (int)(key >> 42), iy = (int)((key >> 21) & 0x1fffffu), iz = (int)(key & 0x1fffffu);
-    // the 13 neighbours that follow (0, 0, 0) lexicographically: every adjacent pair is met from one side
-    for (int t = 14; t < 27; ++t)
+    const uint32_t mask = cell_cap_for(M, cap_max) - 1;
+    const uint32_t n_cells = frame->n_cells;
+    const uint32_t w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    // lane l < 62: the l-th of the offsets in [-2, 2]^3 that follow (0, 0, 0) lexicographically
+    const int t = 63 + (int)lane;  // (0,0,0) has index 62 in the 5 x 5 x 5 enumeration
+    const int dx = t / 25 - 2, dy = (t / 5) % 5 - 2, dz = t % 5 - 2;
+    // Two passes (two launches).  Pass 0 handles the 13 partners that touch the cell: almost all of them are
+    // connected and the walk ends at its first tests.  Pass 1 handles the 49 partners one cell further away: by then
+    // every union of pass 0 is visible, most of these pairs already share a set through the cells between them and
+    // are skipped by the root comparison -- only pairs of different sets pay for a full point-pair scan.
+    const bool near = abs(dx) <= 1 && abs(dy) <= 1 && abs(dz) <= 1;
+    const bool my_pass = lane < 62 && (near == (far_pass == 0u));
+    const uint32_t stride = gridDim.x * (blockDim.x / WAVE);
+    for (uint32_t c = blockIdx.x * (blockDim.x / WAVE) + w; c < n_cells; c += stride)
     {
-        const int nx = ix + t / 9 - 1, ny = iy + (t / 3) % 3 - 1, nz = iz + t % 3 - 1;
-        if ((unsigned)nx > 0x1fffffu || (unsigned)ny > 0x1fffffu || (unsigned)nz > 0x1fffffu)
-            continue;
-        const unsigned long long nk = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) |
-                                      (unsigned long long)nz;
-        uint32_t h = cell_hash(nk) & mask;
-        for (;;)
+        const uint32_t s = cells[c];
+        const unsigned long long key = tkey[s];
+        const int ix = (int)(key >> 42), iy = (int)((key >> 21) & 0x1fffffu), iz = (int)(key & 0x1fffffu);
+        // partner cell of this lane, if it is occupied
+        uint32_t partner = CELL_NONE;
+        const int nx = ix + dx, ny = iy + dy, nz = iz + dz;
+        if (my_pass && (unsigned)nx <= 0x1fffffu && (unsigned)ny <= 0x1fffffu && (unsigned)nz <= 0x1fffffu)
         {
-            const unsigned long long k2 = tkey[h];
-            if (k2 == CELL_EMPTY)
-                break;
-            if (k2 == nk)
+            const unsigned long long nk = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) |
+                                          (unsigned long long)nz;
+            uint32_t h = cell_hash(nk) & mask;
+            for (;;)
             {
-                uf_unite(tparent, s, h);
-                break;
+                const unsigned long long k2 = tkey[h];
+                if (k2 == CELL_EMPTY)
+                    break;
+                if (k2 == nk)
+                {
+                    partner = h;
+                    break;
+                }
+                h = (h + 1) & mask;
             }
-            h = (h + 1) & mask;
+        }
+        if (partner != CELL_NONE && uf_find(tparent, s) == uf_find(tparent, partner))
+            partner = CELL_NONE;  // already in one set
+        if (!__ballot(partner != CELL_NONE))
+            continue;
+        // quick test: the first point of the cell against the first point of the partner.  Cells are a third of
+        // a radius wide, so for touching cells this pair is within d most of the time and nothing else is read.
+        {
+            const uint32_t a0 = thead[s];
+            const float ax = OX[a0], ay = OY[a0], az = OZ[a0];
+            if (partner != CELL_NONE)
+            {
+                const uint32_t b0 = thead[partner];
+                const float d0 = ax - OX[b0], d1 = ay - OY[b0], d2 = az - OZ[b0];
+                if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)
+                {
+                    uf_unite(tparent, s, partner);
+                    partner = CELL_NONE;
+                }
+            }
+            if (!__ballot(partner != CELL_NONE))
+                continue;
+        }
+        // the cell's own points, CELL_STAGE at a time, against every open partner
+        uint32_t pa = thead[s];
+        while (pa != CELL_NONE && __ballot(partner != CELL_NONE))
+        {
+            // lane i walks i links from pa: one dependent chain of CELL_STAGE short hops, then a parallel fetch
+            uint32_t mine = CELL_NONE, cur = pa;
+            uint32_t n_a = 0;
+            for (int i = 0; i < CELL_STAGE && cur != CELL_NONE; ++i)
+            {
+                if ((int)lane == i)
+                    mine = cur;
+                cur = next[cur];
+                ++n_a;
+            }
+            pa = cur;
+            if (mine != CELL_NONE)
+            {
+                s_a[w][lane][0] = OX[mine];
+                s_a[w][lane][1] = OY[mine];
+                s_a[w][lane][2] = OZ[mine];
+            }
+            Coop<WAVE>::sync();
+            if (partner != CELL_NONE)
+            {
+                bool joined = false;
+                for (uint32_t pb = thead[partner]; pb != CELL_NONE && !joined; pb = next[pb])
+                {
+                    const float bx = OX[pb], by = OY[pb], bz = OZ[pb];
+                    for (uint32_t i = 0; i < n_a; ++i)
+                    {
+                        const float d0 = s_a[w][i][0] - bx, d1 = s_a[w][i][1] - by, d2 = s_a[w][i][2] - bz;
+                        if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)  // dist_sqr, src/kdtree.hpp:145-157, inclusive :315
+                        {
+                            joined = true;
+                            break;
+                        }
+                    }
+                }
+                if (joined)
+                {
+                    uf_unite(tparent, s, partner);
+                    partner = CELL_NONE;
+                }
+            }
+            Coop<WAVE>::sync();
         }
     }
 }
 
-// root[i] = representative point of the set of point i (same word for all its members), iota, replay state reset
+// root[i] = a point of the root cell of point i's set (the same word for all its members), iota, state reset
 __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *tparent,
-                                    const uint32_t *__restrict__ trep, const uint32_t *__restrict__ cell_of,
+                                    const uint32_t *__restrict__ thead, const uint32_t *__restrict__ cell_of,
                                     uint32_t *__restrict__ root, uint32_t *__restrict__ iota,
                                     uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
                                     uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi, size_t fs)
 {
     frame = lpx_slot(frame, fs);
     tparent = lpx_slot(tparent, fs);
-    trep = lpx_slot(trep, fs);
+    thead = lpx_slot(thead, fs);
     cell_of = lpx_slot(cell_of, fs);
     root = lpx_slot(root, fs);
     iota = lpx_slot(iota, fs);
@@ -1900,7 +2035,7 @@ __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32
             break;
         x = p;
     }
-    root[i] = trep[x];
+    root[i] = thead[x];
     iota[i] = i;
     state[i] = 0;
     valid[i] = 0;
@@ -2036,22 +2171,30 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     if (m_max == 0)
         return LPX_OK;
     StageTimer tm(ctx, ST_NB_SCAN);
-    const FrameState *frame = (const FrameState *)ctx->frame.p;
+    FrameState *frame = (FrameState *)ctx->frame.p;
     uint32_t cap = 64;
     while (cap < 2 * m_max && cap < ctx->cell_cap)
         cap <<= 1;
     const dim3 blk(256), gc((cap + 255) / 256, 1, ctx->cur_b), gm((m_max + 255) / 256, 1, ctx->cur_b);
     unsigned long long *tkey = (unsigned long long *)ctx->cell_key.p;
-    uint32_t *tparent = (uint32_t *)ctx->cell_parent.p, *trep = (uint32_t *)ctx->cell_rep.p;
-    hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, ctx->cell_cap, ctx->fstride);
+    uint32_t *tparent = (uint32_t *)ctx->cell_parent.p, *thead = (uint32_t *)ctx->cell_rep.p;
+    uint32_t *next = (uint32_t *)ctx->parent.p, *cells = (uint32_t *)ctx->lpos.p;  // free in this path
+    hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, thead, ctx->cell_cap,
+                       ctx->fstride);
     hipLaunchKernelGGL(grid_insert_kernel, gm, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
-                       (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, trep,
+                       (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells,
                        (uint32_t *)ctx->cell_of.p, ctx->cell_cap, ctx->fstride);
-    hipLaunchKernelGGL(grid_link_kernel, gc, blk, 0, ctx->stream, frame, (const unsigned long long *)tkey, tparent,
-                       ctx->cell_cap, ctx->fstride);
-    hipLaunchKernelGGL(grid_flatten_kernel, gm, blk, 0, ctx->stream, frame, tparent, (const uint32_t *)trep,
-                       (const uint32_t *)ctx->cell_of.p, d_root, d_iota, (uint8_t *)ctx->state.p,
-                       (uint32_t *)ctx->valid.p, (uint32_t *)ctx->cc_lo.p, (uint32_t *)ctx->cc_hi.p, ctx->fstride);
+    // one wavefront per occupied cell, grid-stride (the device knows how many cells there are)
+    const uint32_t lgrid = (m_max + 3) / 4 < 2048u ? (m_max + 3) / 4 : 2048u;
+    for (uint32_t far_pass = 0; far_pass < 2; ++far_pass)
+        hipLaunchKernelGGL(grid_link_kernel, dim3(lgrid, 1, ctx->cur_b), blk, 0, ctx->stream, (const FrameState *)frame,
+                           (const unsigned long long *)tkey, tparent, (const uint32_t *)thead, (const uint32_t *)next,
+                           (const uint32_t *)cells, (const float *)ctx->OX.p, (const float *)ctx->OY.p,
+                           (const float *)ctx->OZ.p, r2, ctx->cell_cap, far_pass, ctx->fstride);
+    hipLaunchKernelGGL(grid_flatten_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, tparent,
+                       (const uint32_t *)thead, (const uint32_t *)ctx->cell_of.p, d_root, d_iota,
+                       (uint8_t *)ctx->state.p, (uint32_t *)ctx->valid.p, (uint32_t *)ctx->cc_lo.p,
+                       (uint32_t *)ctx->cc_hi.p, ctx->fstride);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

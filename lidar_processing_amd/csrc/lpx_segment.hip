@@ -17,6 +17,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace
 {
@@ -71,6 +72,8 @@ __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacl
         f.has_far = 0;
         f.pad0 = 0;
         f.cand_total = 0;
+        f.n_cells = 0;
+        f.pad1 = 0;
         f.n_windows = 0;
         f.n_overflow = 0;
         f.nb_entries = 0;
@@ -1701,7 +1704,13 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     uint32_t *blk_counts = (uint32_t *)ctx->blk_counts.p;
     {
         StageTimer tm(ctx, ST_PLANE);
-        if (prm.n_per <= ONE_MAX_POINTS)
+        // One frame: all passes in one launch (1024-thread workgroups that keep the points in registers: shortest
+        // latency).  A batch shares the device with other chains, and a workgroup that needs a whole CU's registers
+        // waits for a CU to drain (measured 3.2 ms under load against 0.17 ms alone): batches take the launch-per-pass
+        // kernel, whose 256-thread workgroups schedule anywhere (0.5 ms under load).  LPX_PLANE_MODE=0 forces the
+        // single launch.
+        static const int plane_mode = getenv("LPX_PLANE_MODE") ? atoi(getenv("LPX_PLANE_MODE")) : 1;
+        if (prm.n_per <= ONE_MAX_POINTS && !(plane_mode == 1 && B > 1))
             hipLaunchKernelGGL(plane_single_kernel, dim3(P, 1, B), dim3(ONE_THREADS), 0, st, XS, YS, ZS, prm, sst, facc,
                                (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
         else
