@@ -177,9 +177,12 @@ def cpu_baselines(host_frames, wl, budget_s):
     oracle.set_sort_threads(threads)
     par, n2, t2 = timed(budget_s / 2)
     oracle.set_sort_threads(1)
-    jobs = [(host_frames[j % len(host_frames)], wl["seg"], wl["clu"]) for j in range(max(cores, 8) * 4)]
-    with mp.get_context("fork").Pool(cores) as pool:
-        pool.map(_cpu_frame, jobs[:cores])  # start-up and page-in outside the timed part
+    # about budget_s seconds of work per core (bounded: 1/8 .. 4 frames per core)
+    per_frame = t1 / max(1, n1)
+    n_jobs = int(min(4 * cores, max(cores // 8 + 1, cores * budget_s / max(per_frame, 1e-3) / 2)))
+    jobs = [(host_frames[j % len(host_frames)], wl["seg"], wl["clu"]) for j in range(n_jobs)]
+    with mp.get_context("fork").Pool(min(cores, n_jobs)) as pool:
+        pool.map(_cpu_frame, jobs[:min(cores, n_jobs, 16)])  # start-up and page-in outside the timed part
         a = time.perf_counter()
         pts_done = sum(pool.map(_cpu_frame, jobs, chunksize=1))
         t3 = time.perf_counter() - a

@@ -489,9 +489,8 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
 // was built and measured: it halves the latency of one component but costs 40 % more LDS and three mostly idle
 // wavefronts per workgroup; and splitting ONE search over several wavefronts is slower than not splitting it,
 // because the per-search setup, not the candidate tests, dominates.)
-// Point states: STATE_LDS keeps them as a 2-bit LDS bitmap; frames with more obstacle points than the small launch
-// covers are served by a second launch (larger bitmap, or one byte per point in HBM).  Each launch checks on the
-// device whether a frame is its own.
+// Point states: STATE_LDS keeps them as a 2-bit LDS bitmap (up to ~440k points); larger frames keep one byte per
+// point in HBM (a second launch; each launch checks on the device whether a frame is its own).
 // ------------------------------------------------------------------------------------------------
 #ifndef LPX_RS_WAVES
 #define LPX_RS_WAVES 8
@@ -503,7 +502,6 @@ constexpr int RS_THREADS = RS_WAVES * WAVE;
 #endif
 constexpr int RS_RING = LPX_RS_RING;         // queue entries mirrored in LDS, per wavefront
 constexpr int RS_BATCH = 8;                  // candidate chunks in flight per wavefront
-constexpr uint32_t RS_SMALL_PTS = 65536;     // obstacle points the small-LDS launch serves (16 KiB bitmap)
 
 struct RsShared  // fixed part of the LDS of replay_search_kernel (the bitmap follows)
 {
@@ -606,7 +604,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const uint32_t tid = threadIdx.x, w = tid / WAVE, lane = tid % WAVE;
     const uint32_t M = frame->n_obstacle;
     const uint32_t n_roots = frame->n_roots;
-    // this launch serves the frames with m_lo < M <= m_hi obstacle points (another launch takes the rest)
+    // frames outside (m_lo, m_hi] obstacle points belong to the other launch (an empty frame to none)
     if (M <= m_lo || M > m_hi || blockIdx.x * RS_WAVES >= n_roots)
         return;
     if (STATE_LDS)
@@ -1154,20 +1152,17 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (uint8_t *)ctx->state.p,          \
         (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, frame, (const uint32_t *)ctx->rpos.p,         \
         (uint32_t)(lo_), (uint32_t)(hi_), fv
-        // frames of up to RS_SMALL_PTS obstacle points: a 16 KiB bitmap, three workgroups per CU
-        const uint32_t small = m_max < RS_SMALL_PTS ? m_max : RS_SMALL_PTS;
+        // Point states as a 2-bit LDS bitmap sized for the host's bound (31 KiB for a 123k-point frame; the resident
+        // footprint is set by rgrid, not by this), capped at what LDS holds (~440k points).  When the bound exceeds
+        // the cap a second launch with one byte per point in HBM serves the frames that really are that large; each
+        // launch checks the frame's obstacle count on the device (a 1M-point cloud usually has < 440k obstacles).
+        const uint32_t lds_pts = (uint32_t)(((152 * 1024 - fixed) / sizeof(uint32_t) - 4) * 16);
+        const uint32_t m_lds = m_max < lds_pts ? m_max : lds_pts;
         hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS),
-                           fixed + bitmap_bytes(small), st, RS_ARGS(0u, small));
-        if (m_max > RS_SMALL_PTS)
-        {
-            // the host's bound allows more: a second launch serves those frames (the device decides per frame)
-            if (fixed + bitmap_bytes(m_max) <= 152 * 1024)
-                hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS),
-                                   fixed + bitmap_bytes(m_max), st, RS_ARGS(RS_SMALL_PTS, m_max));
-            else
-                hipLaunchKernelGGL(replay_search_kernel<false>, dim3(m_max < 1024u ? m_max : 1024u, 1, ctx->cur_b),
-                                   dim3(RS_THREADS), fixed, st, RS_ARGS(RS_SMALL_PTS, m_max));
-        }
+                           fixed + bitmap_bytes(m_lds), st, RS_ARGS(0u, m_lds));
+        if (m_max > m_lds)
+            hipLaunchKernelGGL(replay_search_kernel<false>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS), fixed, st,
+                               RS_ARGS(m_lds, m_max));
 #undef RS_ARGS
     }
     else
