@@ -33,9 +33,9 @@ import time
 import numpy as np
 
 # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
-# queue serialise.  The bench keeps many frames in flight on separate streams, so ask for 16 queues.
+# queue serialise.  The bench keeps many frames in flight on separate streams, so ask for 32 queues.
 # Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6
 WORKLOADS = {
     "kitti": dict(config="configs[1]: 120k-pt KITTI frames, 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                   seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
-                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=256, batch=32, contexts=8),
+                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=512, batch=32, contexts=16),
     "stream": dict(config="configs[3]: all 154 data/*.pcd frames in order, 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                    seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
                    clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=154, batch=32, contexts=5),
@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=0, help="frames in one step (per GPU); 0 = workload default")
     ap.add_argument("--batch", type=int, default=0, help="frames per launch chain; 0 = workload default")
     ap.add_argument("--contexts", type=int, default=0, help="concurrent lpx contexts (HIP streams) per GPU; 0 = default")
-    ap.add_argument("--threads", type=int, default=2, help="host threads that enqueue (ctypes releases the GIL)")
+    ap.add_argument("--threads", type=int, default=4, help="host threads that enqueue (ctypes releases the GIL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the one-core CPU baseline leg")

@@ -88,7 +88,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             {&ctx->d_counts, 64},
             {&ctx->hist, hist_bytes},
             {&ctx->blk_counts, blk_bytes},
-            {&ctx->X, n4},        {&ctx->Y, n4},        {&ctx->Z, n4},       {&ctx->XS, n4},      {&ctx->YS, n4},
+            {&ctx->pts4, 4 * n4}, {&ctx->XS, n4},      {&ctx->YS, n4},
             {&ctx->ZS, n4},       {&ctx->OX, n4},       {&ctx->OY, n4},      {&ctx->OZ, n4},      {&ctx->key_a, n4},
             {&ctx->key_b, n4},    {&ctx->val_a, n4},    {&ctx->val_b, n4},   {&ctx->lpos, n4},    {&ctx->rpos, n4},
             {&ctx->nb_len, n4},   {&ctx->nb_off, n4},   {&ctx->parent, n4},  {&ctx->cc_lo, n4},   {&ctx->cc_hi, n4},
@@ -97,7 +97,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             {&ctx->nodes, 4 * n4}, {&ctx->nodes_pre, 4 * n4}, {&ctx->flags, (size_t)n + 64}, {&ctx->state, (size_t)n + 64},
             {&ctx->grp_of, n4},   {&ctx->cell_of, n4},  {&ctx->chunks, chunk_bytes},
             {&ctx->cell_key, sizeof(uint64_t) * cell_cap}, {&ctx->cell_rep, sizeof(uint32_t) * cell_cap},
-            {&ctx->cell_parent, sizeof(uint32_t) * cell_cap},
+            {&ctx->cell_parent, sizeof(uint32_t) * cell_cap}, {&ctx->cell_xyz, sizeof(float4) * cell_cap},
         };
         size_t total = 0;
         for (const Item &it : items)

@@ -20,6 +20,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace
 {
@@ -1082,7 +1083,12 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     const FV fv = lpx_fv(ctx);
     if (m_max == 0)
         return d_counts ? lpx_write_counts(ctx, d_counts) : LPX_OK;
-    int rc = kd_ready ? LPX_OK : lpx_kd_build(ctx, m_max);
+    // diagnostics only (results are wrong when a stage is skipped): LPX_SKIP=kd,index,grid,sort,replay
+    static const char *skip_env = getenv("LPX_SKIP");
+    const bool skip_kd = skip_env && strstr(skip_env, "kd"), skip_index = skip_env && strstr(skip_env, "index");
+    const bool skip_grid = skip_env && strstr(skip_env, "grid"), skip_sort = skip_env && strstr(skip_env, "sort");
+    const bool skip_replay = skip_env && strstr(skip_env, "replay");
+    int rc = (kd_ready || skip_kd) ? LPX_OK : lpx_kd_build(ctx, m_max);
     if (rc)
         return rc;
     ReplayParams prm;
@@ -1109,8 +1115,8 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     else
     {
         // expansion-driven path: candidate chunks per kd group, components from the uniform grid
-        if ((rc = lpx_group_index(ctx, m_max, cfg->distance_squared)) ||
-            (rc = lpx_grid_components(ctx, m_max, cfg->distance_squared, root, iota)))
+        if ((!skip_index && (rc = lpx_group_index(ctx, m_max, cfg->distance_squared))) ||
+            (!skip_grid && (rc = lpx_grid_components(ctx, m_max, cfg->distance_squared, root, iota))))
             return rc;
     }
     {
@@ -1118,14 +1124,20 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         if (ctx->use_lists)
             hipLaunchKernelGGL(flatten_kernel, grd, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
                                (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, fv.fs);
-        rc = lpx_sort_pairs(ctx, root, (uint32_t *)ctx->key_b.p, iota, (uint32_t *)ctx->val_b.p, m_max,
-                            &frame->n_obstacle, bits_for_count(m_max), &sroot, &members);
+        if (skip_sort)
+        {
+            sroot = root;
+            members = iota;
+        }
+        else
+            rc = lpx_sort_pairs(ctx, root, (uint32_t *)ctx->key_b.p, iota, (uint32_t *)ctx->val_b.p, m_max,
+                                &frame->n_obstacle, bits_for_count(m_max), &sroot, &members);
         if (rc)
             return rc;
         hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, sroot, frame, cc_lo, cc_hi, (uint32_t *)ctx->rpos.p,
                            fv.fs);
     }
-    if (!ctx->use_lists)
+    if (!ctx->use_lists && !skip_replay)
     {
         StageTimer tm(ctx, ST_REPLAY);
         const size_t fixed = sizeof(RsShared);
@@ -1156,16 +1168,18 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // footprint is set by rgrid, not by this), capped at what LDS holds (~440k points).  When the bound exceeds
         // the cap a second launch with one byte per point in HBM serves the frames that really are that large; each
         // launch checks the frame's obstacle count on the device (a 1M-point cloud usually has < 440k obstacles).
-        const uint32_t lds_pts = (uint32_t)(((152 * 1024 - fixed) / sizeof(uint32_t) - 4) * 16);
+        static const int rs_state = getenv("LPX_RS_STATE") ? atoi(getenv("LPX_RS_STATE")) : 0;  // 1: states in HBM
+        const uint32_t lds_pts = rs_state == 1 ? 0u : (uint32_t)(((152 * 1024 - fixed) / sizeof(uint32_t) - 4) * 16);
         const uint32_t m_lds = m_max < lds_pts ? m_max : lds_pts;
-        hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS),
-                           fixed + bitmap_bytes(m_lds), st, RS_ARGS(0u, m_lds));
+        if (m_lds)
+            hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS),
+                               fixed + bitmap_bytes(m_lds), st, RS_ARGS(0u, m_lds));
         if (m_max > m_lds)
             hipLaunchKernelGGL(replay_search_kernel<false>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS), fixed, st,
                                RS_ARGS(m_lds, m_max));
 #undef RS_ARGS
     }
-    else
+    else if (ctx->use_lists)
     {
         StageTimer tm(ctx, ST_REPLAY);
         const size_t lds = sizeof(uint32_t) * (((((size_t)m_max + 15) / 16 + 3) & ~(size_t)3) + RP_RING);

@@ -129,7 +129,7 @@ struct lpx_ctx
     Buf in_aos;                // staging for host input
     Buf rec_out;               // staging for the coloured-cloud records handed to the host
     uint32_t last_n = 0;       // points of the last single-frame segmentation (bounds n_ground + n_obstacle)
-    Buf X, Y, Z;               // original order SoA
+    Buf pts4;                  // the cloud in original order, float4 {x, y, z, 0} per point
     Buf key_a, key_b;          // u32 keys ping-pong
     Buf val_a, val_b;          // u32 values ping-pong
     Buf key64_a, key64_b;      // u64 keys ping-pong
@@ -161,6 +161,7 @@ struct lpx_ctx
     Buf cell_key;              // u64 [cell_cap]: occupied cells of the component grid (open addressing)
     Buf cell_rep, cell_parent; // u32 [cell_cap]: head of the cell's point list / union-find over cells
     Buf cell_of;               // u32 per point: its cell slot
+    Buf cell_xyz;              // float4 [cell_cap]: the point that claimed the cell
     uint32_t cell_cap = 0;     // slots per frame slot (power of two >= 2 * cap_n)
     bool use_lists = false;    // lpx_dbg_use_lists: materialise every radius list (the round-1 path, kept for tests)
     Buf frame;                 // FrameState

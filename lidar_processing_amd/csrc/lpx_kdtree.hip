@@ -480,9 +480,12 @@ constexpr int BLK_CAP_MAX = 4096;  // most nodes staged in LDS: 64 KiB + 2 x 16 
 constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
 
 // one workgroup per range of `level`: std::nth_element(b, mid, e) on axis level % 3
+// BLK_CAP: the LDS capacity that decides which levels belong to kd_lds_kernel; STAGE_CAP: what THIS launch may
+// stage in LDS (0 for the top levels, whose ranges are far above the capacity: their workgroups then need no LDS
+// and find a CU at once even when other chains fill the device)
 __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
                                                           const FrameState *__restrict__ frame, int level,
-                                                          int BLK_CAP, size_t fs)
+                                                          int BLK_CAP, int STAGE_CAP, size_t fs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     nodes = lpx_slot(nodes, fs);
@@ -490,9 +493,9 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     rasc = lpx_slot(rasc, fs);
     frame = lpx_slot(frame, fs);
     Node *l_nodes = (Node *)smem;
-    uint32_t *l_lp = (uint32_t *)(smem + sizeof(Node) * BLK_CAP);
-    uint32_t *l_ra = l_lp + BLK_CAP;
-    uint32_t *cs = l_ra + BLK_CAP;
+    uint32_t *l_lp = (uint32_t *)(smem + sizeof(Node) * STAGE_CAP);
+    uint32_t *l_ra = l_lp + STAGE_CAP;
+    uint32_t *cs = l_ra + STAGE_CAP;
 
     const int tid = threadIdx.x;
     int b = 0, e = (int)frame->n_obstacle;
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     bool done = false;
     while (last - first > 3)
     {
-        if (!staged && last - first <= BLK_CAP)
+        if (!staged && last - first <= STAGE_CAP)
         {
             sb = first;
             se = last;
@@ -1787,14 +1790,20 @@ constexpr unsigned long long CELL_EMPTY = ~0ull;
 constexpr uint32_t CELL_NONE = 0xffffffffu;
 constexpr int CELL_STAGE = 32;  // points of the wavefront's own cell staged in LDS per pass
 
-__device__ __forceinline__ uint32_t cell_hash(unsigned long long k)
+// Home slot of a cell: the 2 x 2 x 2 block of cells it belongs to is hashed, the cell's position inside the block
+// picks one of the 8 slots of that 64-byte line -- the 124 partners a cell probes then lie in ~27 lines instead of
+// ~124 (the table is far larger than L2 once 256 frames are in flight, so every line is a fabric request).
+__device__ __forceinline__ uint32_t cell_hash(unsigned long long key)
 {
+    const unsigned long long blk = key & ~((1ull << 42) | (1ull << 21) | 1ull);  // low bit of every index cleared
+    unsigned long long k = blk;
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdull;
     k ^= k >> 33;
     k *= 0xc4ceb9fe1a85ec53ull;
     k ^= k >> 33;
-    return (uint32_t)k;
+    const uint32_t sub = (uint32_t)(((key >> 42) & 1ull) << 2 | ((key >> 21) & 1ull) << 1 | (key & 1ull));
+    return ((uint32_t)k << 3) | sub;
 }
 
 __device__ __forceinline__ uint32_t cell_cap_for(uint32_t M, uint32_t cap_max)
@@ -1837,9 +1846,10 @@ __global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long 
 __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *__restrict__ OX,
                                    const float *__restrict__ OY, const float *__restrict__ OZ, float d,
                                    unsigned long long *tkey, uint32_t *thead, uint32_t *__restrict__ next,
-                                   uint32_t *__restrict__ cells, uint32_t *__restrict__ cell_of, uint32_t cap_max,
-                                   size_t fs)
+                                   uint32_t *__restrict__ cells, uint32_t *__restrict__ cell_of,
+                                   float4 *__restrict__ trep, uint32_t cap_max, size_t fs)
 {
+    trep = lpx_slot(trep, fs);
     frame = lpx_slot(frame, fs);
     OX = lpx_slot(OX, fs);
     OY = lpx_slot(OY, fs);
@@ -1855,16 +1865,18 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
         return;
     const uint32_t mask = cell_cap_for(M, cap_max) - 1;
     const double inv_c = cell_inv_edge(d);
-    const unsigned long long key = ((unsigned long long)cell_coord(OX[i], inv_c) << 42) |
-                                   ((unsigned long long)cell_coord(OY[i], inv_c) << 21) |
-                                   (unsigned long long)cell_coord(OZ[i], inv_c);
+    const float px = OX[i], py = OY[i], pz = OZ[i];
+    const unsigned long long key = ((unsigned long long)cell_coord(px, inv_c) << 42) |
+                                   ((unsigned long long)cell_coord(py, inv_c) << 21) |
+                                   (unsigned long long)cell_coord(pz, inv_c);
     uint32_t h = cell_hash(key) & mask;
     for (;;)
     {
         const unsigned long long old = atomicCAS(tkey + h, CELL_EMPTY, key);
         if (old == CELL_EMPTY)
         {
-            cells[atomicAdd(&frame->n_cells, 1u)] = h;  // this point claimed the cell: list it
+            cells[atomicAdd(&frame->n_cells, 1u)] = h;  // this point claimed the cell: list it ...
+            trep[h] = make_float4(px, py, pz, 0.0f);     // ... and represents it in the quick test of the linking
             break;
         }
         if (old == key)
@@ -1881,10 +1893,12 @@ __global__ __launch_bounds__(256) void grid_link_kernel(const FrameState *__rest
                                                         const uint32_t *__restrict__ next,
                                                         const uint32_t *__restrict__ cells,
                                                         const float *__restrict__ OX, const float *__restrict__ OY,
-                                                        const float *__restrict__ OZ, float r2, uint32_t cap_max,
+                                                        const float *__restrict__ OZ,
+                                                        const float4 *__restrict__ trep, float r2, uint32_t cap_max,
                                                         uint32_t far_pass, size_t fs)
 {
     __shared__ float s_a[4][CELL_STAGE][3];
+    trep = lpx_slot(trep, fs);
     frame = lpx_slot(frame, fs);
     tkey = lpx_slot(tkey, fs);
     tparent = lpx_slot(tparent, fs);
@@ -1936,25 +1950,28 @@ __global__ __launch_bounds__(256) void grid_link_kernel(const FrameState *__rest
                 h = (h + 1) & mask;
             }
         }
-        if (partner != CELL_NONE && uf_find(tparent, s) == uf_find(tparent, partner))
-            partner = CELL_NONE;  // already in one set
+        // pass 1 first skips what pass 0 already united (pass 0 has nothing to skip yet: it goes straight to the test)
+        if (far_pass && partner != CELL_NONE && uf_find(tparent, s) == uf_find(tparent, partner))
+            partner = CELL_NONE;
         if (!__ballot(partner != CELL_NONE))
             continue;
-        // quick test: the first point of the cell against the first point of the partner.  Cells are a third of
-        // a radius wide, so for touching cells this pair is within d most of the time and nothing else is read.
+        // quick test: the point that claimed the cell against the one that claimed the partner (kept in the table).
+        // Cells are a third of a radius wide, so for touching cells this pair is within d most of the time and no
+        // point list is walked.
         {
-            const uint32_t a0 = thead[s];
-            const float ax = OX[a0], ay = OY[a0], az = OZ[a0];
+            const float4 ra = trep[s];
             if (partner != CELL_NONE)
             {
-                const uint32_t b0 = thead[partner];
-                const float d0 = ax - OX[b0], d1 = ay - OY[b0], d2 = az - OZ[b0];
+                const float4 rb = trep[partner];
+                const float d0 = ra.x - rb.x, d1 = ra.y - rb.y, d2 = ra.z - rb.z;
                 if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)
                 {
                     uf_unite(tparent, s, partner);
                     partner = CELL_NONE;
                 }
             }
+            if (!far_pass && partner != CELL_NONE && uf_find(tparent, s) == uf_find(tparent, partner))
+                partner = CELL_NONE;  // united meanwhile by another wavefront
             if (!__ballot(partner != CELL_NONE))
                 continue;
         }
@@ -2090,8 +2107,12 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     uint32_t size = m_max;
     while (size > (uint32_t)blk_cap)
     {
-        hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G), blk_lds, ctx->stream, nodes,
-                           lpos, rasc, frame, level, blk_cap, ctx->fstride);
+        // a batch stages nothing while the ranges are far above the LDS capacity (most rounds run in global memory
+        // anyway): those workgroups need 256 bytes of LDS instead of 48 KiB
+        const bool stage = ctx->cur_b == 1 || size <= 4u * (uint32_t)blk_cap;
+        hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G),
+                           stage ? blk_lds : 64 * sizeof(uint32_t), ctx->stream, nodes, lpos, rasc, frame, level, blk_cap,
+                           stage ? blk_cap : 0, ctx->fstride);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
@@ -2183,14 +2204,15 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
                        ctx->fstride);
     hipLaunchKernelGGL(grid_insert_kernel, gm, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells,
-                       (uint32_t *)ctx->cell_of.p, ctx->cell_cap, ctx->fstride);
+                       (uint32_t *)ctx->cell_of.p, (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fstride);
     // one wavefront per occupied cell, grid-stride (the device knows how many cells there are)
     const uint32_t lgrid = (m_max + 3) / 4 < 2048u ? (m_max + 3) / 4 : 2048u;
     for (uint32_t far_pass = 0; far_pass < 2; ++far_pass)
         hipLaunchKernelGGL(grid_link_kernel, dim3(lgrid, 1, ctx->cur_b), blk, 0, ctx->stream, (const FrameState *)frame,
                            (const unsigned long long *)tkey, tparent, (const uint32_t *)thead, (const uint32_t *)next,
                            (const uint32_t *)cells, (const float *)ctx->OX.p, (const float *)ctx->OY.p,
-                           (const float *)ctx->OZ.p, r2, ctx->cell_cap, far_pass, ctx->fstride);
+                           (const float *)ctx->OZ.p, (const float4 *)ctx->cell_xyz.p, r2, ctx->cell_cap, far_pass,
+                           ctx->fstride);
     hipLaunchKernelGGL(grid_flatten_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, tparent,
                        (const uint32_t *)thead, (const uint32_t *)ctx->cell_of.p, d_root, d_iota,
                        (uint8_t *)ctx->state.p, (uint32_t *)ctx->valid.p, (uint32_t *)ctx->cc_lo.p,

@@ -118,11 +118,12 @@ __device__ __forceinline__ float ld_f32(const char *p)
 
 template <bool ALIGNED>
 __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOff off, float *__restrict__ X,
-                              float *__restrict__ Y, float *__restrict__ Z, uint32_t *__restrict__ key,
-                              uint32_t *__restrict__ val, FrameState *__restrict__ frame,
-                              float4 *__restrict__ nodes, FV fv)
+                              float *__restrict__ Y, float *__restrict__ Z, float4 *__restrict__ P4,
+                              uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                              FrameState *__restrict__ frame, float4 *__restrict__ nodes, FV fv)
 {
     pts += (size_t)blockIdx.z * fv.upitch * stride;
+    P4 = lpx_slot(P4, fv.fs);
     X = lpx_slot(X, fv.fs);
     Y = lpx_slot(Y, fv.fs);
     Z = lpx_slot(Z, fv.fs);
@@ -139,9 +140,14 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
         x = ld_f32<ALIGNED>(p + off.x);
         y = ld_f32<ALIGNED>(p + off.y);
         z = ld_f32<ALIGNED>(p + off.z);
-        X[i] = x;
-        Y[i] = y;
-        Z[i] = z;
+        if (P4)
+            P4[i] = make_float4(x, y, z, 0.0f);  // one 16-byte record per point: whoever gathers it touches one line
+        else
+        {
+            X[i] = x;
+            Y[i] = y;
+            Z[i] = z;
+        }
         if (key)
         {
             key[i] = lpx_float_key(x);
@@ -167,15 +173,13 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
 // ------------------------------------------------------------------------------------------------
 // gather into x-sorted SoA + composite (segment, z) keys
 // ------------------------------------------------------------------------------------------------
-__global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float *__restrict__ X,
-                              const float *__restrict__ Y, const float *__restrict__ Z, float *__restrict__ XS,
-                              float *__restrict__ YS, float *__restrict__ ZS, uint64_t *__restrict__ zkey,
-                              SegParams prm, const FrameState *__restrict__ frame, size_t fs)
+__global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float4 *__restrict__ P4,
+                              float *__restrict__ XS, float *__restrict__ YS, float *__restrict__ ZS,
+                              uint64_t *__restrict__ zkey, SegParams prm, const FrameState *__restrict__ frame,
+                              size_t fs)
 {
     sidx = lpx_slot(sidx, fs);
-    X = lpx_slot(X, fs);
-    Y = lpx_slot(Y, fs);
-    Z = lpx_slot(Z, fs);
+    P4 = lpx_slot(P4, fs);
     XS = lpx_slot(XS, fs);
     YS = lpx_slot(YS, fs);
     ZS = lpx_slot(ZS, fs);
@@ -184,10 +188,10 @@ __global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float *__
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= prm.n)
         return;
-    const uint32_t i = sidx[p];
-    const float z = Z[i];
-    XS[p] = X[i];
-    YS[p] = Y[i];
+    const float4 q = P4[sidx[p]];  // one random 16-byte read per point
+    const float z = q.z;
+    XS[p] = q.x;
+    YS[p] = q.y;
     ZS[p] = z;
     uint32_t seg = prm.n_per ? p / prm.n_per : prm.P;
     if (seg > prm.P)
@@ -1435,14 +1439,12 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
 // Record = 32 bytes as pcl::PointXYZRGBL lays them out (PCL 1.12 point_types: float x, y, z, 1.0f | b, g, r, a = 255
 // | uint32 label | 8 bytes of padding, written as zero).  One thread per record, two 16-byte stores.
 // ------------------------------------------------------------------------------------------------
-__global__ void colour_kernel(const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+__global__ void colour_kernel(const float4 *__restrict__ P4,
                               const uint32_t *__restrict__ gidx, const uint32_t *__restrict__ oidx,
                               const FrameState *__restrict__ frame, float4 *__restrict__ grec,
                               float4 *__restrict__ orec, FV fv)
 {
-    X = lpx_slot(X, fv.fs);
-    Y = lpx_slot(Y, fv.fs);
-    Z = lpx_slot(Z, fv.fs);
+    P4 = lpx_slot(P4, fv.fs);
     frame = lpx_slot(frame, fv.fs);
     gidx = lpx_user(gidx, fv.upitch);
     oidx = lpx_user(oidx, fv.upitch);
@@ -1456,7 +1458,8 @@ __global__ void colour_kernel(const float *__restrict__ X, const float *__restri
     const uint32_t j = g ? i : i - ng;
     const uint32_t k = g ? gidx[j] : oidx[j];
     float4 *dst = (g ? grec : orec) + 2 * (size_t)j;
-    dst[0] = make_float4(X[k], Y[k], Z[k], 1.0f);
+    const float4 q = P4[k];
+    dst[0] = make_float4(q.x, q.y, q.z, 1.0f);
     const uint32_t rgba = g ? 0xffdcdcdcu : 0xff00ff00u;  // a r g b from the top byte down: bytes b, g, r, a in memory
     dst[1] = make_float4(__uint_as_float(rgba), __uint_as_float(g ? 0u : 1u), 0.0f, 0.0f);
 }
@@ -1509,16 +1512,16 @@ static uint32_t bits_for(uint32_t v)  // number of bits needed to represent valu
 }
 
 static void launch_ingest(lpx_ctx *ctx, dim3 grid, const void *d_pts, size_t stride, float *X, float *Y, float *Z,
-                          uint32_t *key, uint32_t *val, FrameState *frame, float4 *nodes)
+                          float4 *P4, uint32_t *key, uint32_t *val, FrameState *frame, float4 *nodes)
 {
     const XyzOff off = {ctx->in_off[0], ctx->in_off[1], ctx->in_off[2]};
     const bool aligned = (((uintptr_t)d_pts | stride | off.x | off.y | off.z) & 3u) == 0;
     if (aligned)
         hipLaunchKernelGGL(ingest_kernel<true>, grid, dim3(256), 0, ctx->stream, (const char *)d_pts, stride, off, X, Y,
-                           Z, key, val, frame, nodes, lpx_fv(ctx));
+                           Z, P4, key, val, frame, nodes, lpx_fv(ctx));
     else
         hipLaunchKernelGGL(ingest_kernel<false>, grid, dim3(256), 0, ctx->stream, (const char *)d_pts, stride, off, X, Y,
-                           Z, key, val, frame, nodes, lpx_fv(ctx));
+                           Z, P4, key, val, frame, nodes, lpx_fv(ctx));
 }
 
 int lpx_run_colour(lpx_ctx *ctx, uint32_t n_max, const uint32_t *d_gidx, const uint32_t *d_oidx, void *d_grec,
@@ -1527,7 +1530,7 @@ int lpx_run_colour(lpx_ctx *ctx, uint32_t n_max, const uint32_t *d_gidx, const u
     if (n_max == 0)
         return LPX_OK;
     hipLaunchKernelGGL(colour_kernel, dim3((n_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream,
-                       (const float *)ctx->X.p, (const float *)ctx->Y.p, (const float *)ctx->Z.p, d_gidx, d_oidx,
+                       (const float4 *)ctx->pts4.p, d_gidx, d_oidx,
                        (const FrameState *)ctx->frame.p, (float4 *)d_grec, (float4 *)d_orec, lpx_fv(ctx));
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
@@ -1576,7 +1579,7 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
     if (rc)
         return rc;
     if (n)
-        launch_ingest(ctx, dim3((n + 255) / 256), d_pts, 12, XS, YS, ZS, nullptr, nullptr, frame, nullptr);
+        launch_ingest(ctx, dim3((n + 255) / 256), d_pts, 12, XS, YS, ZS, nullptr, nullptr, nullptr, frame, nullptr);
     hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, acc, ticket);
     hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
                        0u, sst, acc, (long long *)ctx->seg_far.p, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr,
@@ -1595,7 +1598,7 @@ int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_
     if (m)
     {
         launch_ingest(ctx, dim3((m + 255) / 256), d_pts, stride, (float *)ctx->OX.p, (float *)ctx->OY.p,
-                      (float *)ctx->OZ.p, nullptr, nullptr, frame, (float4 *)ctx->nodes.p);
+                      (float *)ctx->OZ.p, nullptr, nullptr, nullptr, frame, (float4 *)ctx->nodes.p);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
@@ -1641,14 +1644,14 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     prm.odt = cfg->orthogonal_distance_threshold;
     prm.n_lpr = cfg->number_of_lower_point_representatives;
 
-    float *X = (float *)ctx->X.p, *Y = (float *)ctx->Y.p, *Z = (float *)ctx->Z.p;
+    float4 *P4 = (float4 *)ctx->pts4.p;  // the cloud in original order, 16-byte records
     float *XS = (float *)ctx->XS.p, *YS = (float *)ctx->YS.p, *ZS = (float *)ctx->ZS.p;
     const dim3 blk(256), grd((n + 255) / 256, 1, B);
 
     {
         StageTimer tm(ctx, ST_INGEST);
-        launch_ingest(ctx, grd, d_pts, stride, X, Y, Z, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->val_a.p, frame,
-                      nullptr);
+        launch_ingest(ctx, grd, d_pts, stride, nullptr, nullptr, nullptr, P4, (uint32_t *)ctx->key_a.p,
+                      (uint32_t *)ctx->val_a.p, frame, nullptr);
     }
     uint32_t *skeys = nullptr, *sidx = nullptr;
     {
@@ -1670,7 +1673,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     const bool select_seeds = prm.n_per <= SEL_MAX_POINTS && prm.n_lpr <= SEL_MAX_LPR;
     {
         StageTimer tm(ctx, ST_GATHER);
-        hipLaunchKernelGGL(gather_kernel, grd, blk, 0, st, sidx, X, Y, Z, XS, YS, ZS,
+        hipLaunchKernelGGL(gather_kernel, grd, blk, 0, st, sidx, (const float4 *)P4, XS, YS, ZS,
                            select_seeds ? (uint64_t *)nullptr : (uint64_t *)ctx->key64_a.p, prm,
                            (const FrameState *)frame, fv.fs);
     }
