@@ -55,7 +55,8 @@ WORKLOADS = {
                     clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=16, batch=4, contexts=4),
     "synth5m": dict(config="configs[4]: synthetic 5M-pt plane + boxes, 24 segments, 3 iters, FEC d=0.2 m q=0.5",
                     seg=dict(number_of_planar_partitions=24, number_of_iterations=3),
-                    clu=dict(distance_squared=0.04, cluster_quality=0.5), frames_per_step=4, batch=1, contexts=4),
+                    clu=dict(distance_squared=0.04, cluster_quality=0.5), frames_per_step=4, batch=1, contexts=4,
+                    lists=True),  # one frame per chain: LPX_NEIGHBOURS_AUTO picks the list path, 5x faster here
 }
 
 # stage -> kernel that dominates it (names as rocprofv3 prints them), for the PMC traffic lookup
@@ -210,8 +211,10 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the one-core CPU baseline leg")
     ap.add_argument("--lists", action="store_true", help="A/B: materialise every radius list (LPX_NEIGHBOURS_LISTS)")
+    ap.add_argument("--search", action="store_true", help="A/B: expansion-driven searches (LPX_NEIGHBOURS_SEARCH)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
+    args.lists = not args.search and (args.lists or wl.get("lists", False))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -369,6 +372,9 @@ def main():
                     "algorithmic_bytes_per_launch": int(algo), "achieved": round(ach, 2),
                     "frac": round(ach / HBM_PEAK_GBS, 5)}
 
+        if args.lists:
+            STAGE_KERNEL.update(cc_hook="cc_hook_kernel", neighbours="nb_group_kernel", replay="replay_lds_kernel",
+                                components="cc_flatten_kernel")
         row = stage_row(dom)
         step_ms = elapsed / args.steps * 1e3
         fb = frame_bytes(Nn, Mm, I)

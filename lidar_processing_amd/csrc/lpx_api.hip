@@ -98,6 +98,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             {&ctx->grp_of, n4},   {&ctx->cell_of, n4},  {&ctx->chunks, chunk_bytes},
             {&ctx->cell_key, sizeof(uint64_t) * cell_cap}, {&ctx->cell_rep, sizeof(uint32_t) * cell_cap},
             {&ctx->cell_parent, sizeof(uint32_t) * cell_cap}, {&ctx->cell_xyz, sizeof(float4) * cell_cap},
+            {&ctx->kd_state, 48 * 1024},  // 48-byte states of up to 1024 ranges (ten top levels)
         };
         size_t total = 0;
         for (const Item &it : items)
@@ -185,7 +186,21 @@ static int ensure_for(lpx_ctx *ctx, uint32_t n)
     uint64_t nb = (uint64_t)n * ctx->nb_per_point;
     if (nb > 0xfffffff0ull)
         nb = 0xfffffff0ull;  // offsets are 32-bit
-    return lpx_ensure_capacity(ctx, n, nb);
+    const int rc = lpx_ensure_capacity(ctx, n, nb);
+    // LPX_POISON=<byte>: before every new frame the per-point workspace (everything a call must write before it
+    // reads) and the neighbour lists are filled with that byte -- a test that passes with 0, 0xff and 0xa5 does not
+    // depend on what an earlier frame left behind
+    static const char *poison = getenv("LPX_POISON");
+    if (rc == LPX_OK && poison)
+    {
+        const int byte = (int)strtol(poison, nullptr, 0) & 0xff;
+        const size_t span = (size_t)((char *)ctx->kd_state.p - (char *)ctx->pts4.p);
+        for (uint32_t b = 0; b < ctx->batch; ++b)
+            LPX_HIP(ctx, hipMemsetAsync((char *)ctx->pts4.p + b * ctx->fstride, byte, span, ctx->stream));
+        if (ctx->nb_arena)
+            LPX_HIP(ctx, hipMemsetAsync(ctx->nb_arena, byte, ctx->nb_fstride * ctx->batch, ctx->stream));
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

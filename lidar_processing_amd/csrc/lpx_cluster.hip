@@ -48,7 +48,7 @@ __global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ 
     if (i >= frame->n_obstacle)
         return;
     uint32_t x = i;
-    for (;;)
+    for (; !frame->status;)  // (a frame whose lists did not fit has no forest: every point its own root)
     {
         const uint32_t p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (p == x)

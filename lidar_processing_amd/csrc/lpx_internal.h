@@ -146,6 +146,7 @@ struct lpx_ctx
     Buf nodes;                 // float4 kd nodes, array (in-order) layout
     Buf nodes_pre;             // the same nodes in pre-order rank layout
     Buf lpos, rpos;            // partition scratch
+    Buf kd_state;              // introselect state of the ranges of a top kd level (multi-workgroup rounds)
     Buf nb_len, nb_off;        // u32 len, u32 off (cap_n + 1)
     Buf nb_idx;                // cap_nb words: neighbour index | (within the absorb radius) << 31
     Buf parent;                // union-find

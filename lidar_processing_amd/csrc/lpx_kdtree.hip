@@ -20,6 +20,7 @@
 #include "lpx_internal.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace
 {
@@ -475,6 +476,21 @@ __device__ __forceinline__ void descend(int &b, int &e, uint32_t r, int level)
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+// state of one range in the multi-workgroup top-level rounds (kd_top_* below)
+struct KdTopState
+{
+    int first, last, nth, depth;  // introselect loop state of the range (bits/stl_algo.h:1964-1986)
+    int cntL, cntR, K;            // stop-list sizes and swaps of the round in flight
+    int active;                   // the range is still partitioned here (else kd_block_kernel finishes it)
+    int pending;                  // a cut is waiting to be applied
+    float pv;
+    int pad[2];
+};
+constexpr int TOP_TILE = 8192;        // positions per workgroup in the flag / list passes
+constexpr int TOP_THREADS = 256;
+constexpr int TOP_HAND = 4096;        // ranges at or below this are left to kd_block_kernel (they fit its LDS)
+constexpr uint32_t TOP_MIN = 131072;  // levels whose ranges can exceed this take the multi-workgroup rounds
+
 constexpr int BLK_G = 1024;
 constexpr int BLK_CAP_MAX = 4096;  // most nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch (blk_cap is a launch argument)
 constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
@@ -485,7 +501,8 @@ constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree o
 // and find a CU at once even when other chains fill the device)
 __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
                                                           const FrameState *__restrict__ frame, int level,
-                                                          int BLK_CAP, int STAGE_CAP, size_t fs)
+                                                          int BLK_CAP, int STAGE_CAP,
+                                                          const KdTopState *__restrict__ top, size_t fs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     nodes = lpx_slot(nodes, fs);
@@ -508,6 +525,14 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     const int nth = b + (e - b) / 2;
     int first = b, last = e;
     int depth_limit = 2 * floor_log2(e - b);
+    if (top)
+    {
+        // the multi-workgroup rounds (kd_top_*) have narrowed the range: continue the same introselect loop
+        const KdTopState st = lpx_slot(top, fs)[blockIdx.x];
+        first = st.first;
+        last = st.last;
+        depth_limit = st.depth;
+    }
     View v;
     v.a = nodes;
     v.lp = lpos;
@@ -554,6 +579,254 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     if (staged)
         for (int i = sb + tid; i < se; i += BLK_G)
             nodes[i] = l_nodes[i - sb];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Top levels of LARGE clouds: one std::nth_element shared by many workgroups.
+//
+// kd_block_kernel gives a whole range to ONE workgroup; at level 0 of a 2.3M-point obstacle cloud that single
+// workgroup sweeps 37 MB per Hoare round while 255 CUs idle (15 of the 37 ms of a 5M-point frame).  The same
+// data-parallel Hoare partition distributes over workgroups when its phases become launches: per round
+//   kd_top_pivot   one thread per range: applies the cut of the previous round (first / last), then
+//                  median-of-three to first, pivot value, counters reset            (bits/stl_algo.h:1878-1907)
+//   kd_top_flags   tiles of 8192 positions: how many keys stop the left / the right cursor   -> per-tile counts
+//   kd_top_lists   the same tiles, prefix over the tile counts, write the stop lists L (ascending), R (ascending)
+//   kd_top_swap    swaps L_k <-> R_k for k < min(|L|, |R|) with L_k < R_k, counts them (K)
+// and the cut = min(L_{K+1}, R_K) is taken by the next kd_top_pivot.  The introselect state of every range
+// (first, last, depth limit) lives in a small table; after a fixed number of rounds kd_block_kernel continues
+// from that state (the active range is then a few thousand nodes and fits its LDS), so the result is the same
+// permutation as before -- the rounds only run on more CUs.
+// ------------------------------------------------------------------------------------------------
+__global__ void kd_top_pivot(Node *nodes, const uint32_t *__restrict__ lpos, const uint32_t *__restrict__ rasc,
+                             const FrameState *__restrict__ frame, KdTopState *state, int level, int init, size_t fs)
+{
+    nodes = lpx_slot(nodes, fs);
+    lpos = lpx_slot(lpos, fs);
+    rasc = lpx_slot(rasc, fs);
+    frame = lpx_slot(frame, fs);
+    state = lpx_slot(state, fs);
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (1u << level))
+        return;
+    KdTopState st = state[r];
+    const int axis = level % 3;
+    View v;
+    v.a = nodes;
+    v.lp = nullptr;
+    v.ra = nullptr;
+    v.off = 0;
+    if (init == 1)
+    {
+        int b = 0, e = (int)frame->n_obstacle;
+        descend(b, e, r, level);
+        st.first = b;
+        st.last = e;
+        st.nth = b + (e - b) / 2;
+        st.depth = (e - b >= 2) ? 2 * floor_log2(e - b) : 0;
+        st.pending = 0;
+        st.active = 1;
+    }
+    else if (st.active && st.pending)
+    {
+        // cut of the round that just ran: min(L_{K+1}, R_K)
+        const int c1 = (st.K < st.cntL) ? (int)lpos[st.first + st.K] : INT_MAX;
+        const int c2 = (st.K > 0) ? (int)rasc[st.first + st.cntR - st.K] : INT_MAX;
+        const int cut = min(c1, c2);
+        if (cut <= st.nth)
+            st.first = cut;
+        else
+            st.last = cut;
+        st.pending = 0;
+    }
+    // the range stays here while it is large and the depth limit has not run out (heap_select, rare, is left to
+    // kd_block_kernel together with everything small)
+    if (st.active && (st.last - st.first <= TOP_HAND || st.depth == 0))
+        st.active = 0;
+    if (st.active && init != 2)  // init == 2: the last call only applies the last cut, it starts no round
+    {
+        --st.depth;
+        seq_median_to_first(v, st.first, st.last, axis);
+        st.pv = nkey(v, st.first, axis);
+        st.cntL = st.cntR = st.K = 0;
+        st.pending = 1;
+    }
+    state[r] = st;
+}
+
+// per tile: number of positions in (first, last) whose key stops the left cursor (>= pivot) / the right one (<= pivot)
+__global__ __launch_bounds__(TOP_THREADS) void kd_top_flags(const Node *__restrict__ nodes,
+                                                            const KdTopState *__restrict__ state,
+                                                            uint2 *__restrict__ tile_cnt, int level, int tiles, size_t fs)
+{
+    __shared__ uint32_t s_l[TOP_THREADS / WAVE], s_r[TOP_THREADS / WAVE];
+    nodes = lpx_slot(nodes, fs);
+    state = lpx_slot(state, fs);
+    tile_cnt = lpx_slot(tile_cnt, fs);
+    const uint32_t r = blockIdx.y;
+    const KdTopState st = state[r];
+    if (!st.active)
+        return;
+    const int axis = level % 3;
+    const int p0 = st.first + 1 + (int)blockIdx.x * TOP_TILE;
+    uint32_t cl = 0, cr = 0;
+    if (p0 < st.last)
+    {
+        const int p1 = min(p0 + TOP_TILE, st.last);
+        for (int p = p0 + (int)threadIdx.x; p < p1; p += TOP_THREADS)
+        {
+            const float k = ((const float *)(nodes + p))[axis];
+            cl += !(k < st.pv);
+            cr += !(st.pv < k);
+        }
+    }
+    cl = lpx_wave_sum_u32(cl);
+    cr = lpx_wave_sum_u32(cr);
+    if ((threadIdx.x % WAVE) == 0)
+    {
+        s_l[threadIdx.x / WAVE] = cl;
+        s_r[threadIdx.x / WAVE] = cr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t a = 0, b = 0;
+        for (int i = 0; i < TOP_THREADS / WAVE; ++i)
+        {
+            a += s_l[i];
+            b += s_r[i];
+        }
+        tile_cnt[(size_t)r * tiles + blockIdx.x] = make_uint2(a, b);
+    }
+}
+
+// the stop lists: lpos[first + i] = i-th position (ascending) with key >= pivot, rasc likewise for key <= pivot
+__global__ __launch_bounds__(TOP_THREADS) void kd_top_lists(const Node *__restrict__ nodes, KdTopState *state,
+                                                            const uint2 *__restrict__ tile_cnt,
+                                                            uint32_t *__restrict__ lpos, uint32_t *__restrict__ rasc,
+                                                            int level, int tiles, size_t fs)
+{
+    __shared__ uint32_t s_a[TOP_THREADS / WAVE], s_b[TOP_THREADS / WAVE];
+    __shared__ uint32_t s_base[2];
+    nodes = lpx_slot(nodes, fs);
+    state = lpx_slot(state, fs);
+    tile_cnt = lpx_slot(tile_cnt, fs);
+    lpos = lpx_slot(lpos, fs);
+    rasc = lpx_slot(rasc, fs);
+    const uint32_t r = blockIdx.y;
+    const KdTopState st = state[r];
+    if (!st.active)
+        return;
+    const int axis = level % 3;
+    const int span = st.last - st.first - 1;
+    const int used = (span + TOP_TILE - 1) / TOP_TILE;  // tiles that hold positions this round
+    if ((int)blockIdx.x >= used)
+        return;
+    // exclusive prefix of the tile counts before this tile (and, in the last tile, the totals)
+    uint32_t bl = 0, br = 0;
+    for (int t = (int)threadIdx.x; t < (int)blockIdx.x; t += TOP_THREADS)
+    {
+        const uint2 c = tile_cnt[(size_t)r * tiles + t];
+        bl += c.x;
+        br += c.y;
+    }
+    bl = lpx_wave_sum_u32(bl);
+    br = lpx_wave_sum_u32(br);
+    if ((threadIdx.x % WAVE) == 0)
+    {
+        s_a[threadIdx.x / WAVE] = bl;
+        s_b[threadIdx.x / WAVE] = br;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t a = 0, b = 0;
+        for (int i = 0; i < TOP_THREADS / WAVE; ++i)
+        {
+            a += s_a[i];
+            b += s_b[i];
+        }
+        s_base[0] = a;
+        s_base[1] = b;
+        if ((int)blockIdx.x == used - 1)
+        {
+            const uint2 c = tile_cnt[(size_t)r * tiles + blockIdx.x];
+            state[r].cntL = (int)(a + c.x);
+            state[r].cntR = (int)(b + c.y);
+        }
+    }
+    __syncthreads();
+    uint32_t runL = s_base[0], runR = s_base[1];
+    const int p0 = st.first + 1 + (int)blockIdx.x * TOP_TILE;
+    const int p1 = min(p0 + TOP_TILE, st.last);
+    const unsigned long long lt = lpx_lanemask_lt();
+    const uint32_t w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    // positions in ascending order: chunks of 256, wavefront w takes the w-th 64 of every chunk
+    for (int c0 = p0; c0 < p1; c0 += TOP_THREADS)
+    {
+        const int p = c0 + (int)threadIdx.x;
+        bool ge = false, le = false;
+        if (p < p1)
+        {
+            const float k = ((const float *)(nodes + p))[axis];
+            ge = !(k < st.pv);
+            le = !(st.pv < k);
+        }
+        const unsigned long long mg = __ballot(ge), ml = __ballot(le);
+        if (lane == 0)
+        {
+            s_a[w] = (uint32_t)__popcll(mg);
+            s_b[w] = (uint32_t)__popcll(ml);
+        }
+        __syncthreads();
+        uint32_t ol = runL, orr = runR, tl = 0, tr = 0;
+        for (uint32_t i = 0; i < TOP_THREADS / WAVE; ++i)
+        {
+            if (i < w)
+            {
+                ol += s_a[i];
+                orr += s_b[i];
+            }
+            tl += s_a[i];
+            tr += s_b[i];
+        }
+        if (ge)
+            lpos[st.first + ol + __popcll(mg & lt)] = (uint32_t)p;
+        if (le)
+            rasc[st.first + orr + __popcll(ml & lt)] = (uint32_t)p;
+        runL += tl;
+        runR += tr;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(TOP_THREADS) void kd_top_swap(Node *nodes, KdTopState *state,
+                                                           const uint32_t *__restrict__ lpos,
+                                                           const uint32_t *__restrict__ rasc, size_t fs)
+{
+    nodes = lpx_slot(nodes, fs);
+    state = lpx_slot(state, fs);
+    lpos = lpx_slot(lpos, fs);
+    rasc = lpx_slot(rasc, fs);
+    const uint32_t r = blockIdx.y;
+    const KdTopState st = state[r];
+    if (!st.active)
+        return;
+    const int kmax = min(st.cntL, st.cntR);
+    uint32_t my = 0;
+    for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < kmax; k += (int)(gridDim.x * blockDim.x))
+    {
+        const int sl = (int)lpos[st.first + k], sr = (int)rasc[st.first + st.cntR - 1 - k];
+        if (sl < sr)
+        {
+            const Node a = nodes[sl], b = nodes[sr];
+            nodes[sl] = b;
+            nodes[sr] = a;
+            ++my;
+        }
+    }
+    my = lpx_wave_sum_u32(my);
+    if ((threadIdx.x % WAVE) == 0 && my)
+        atomicAdd(&state[r].K, (int)my);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1462,6 +1735,11 @@ __global__ void cc_flatten_kernel(const FrameState *__restrict__ frame, uint32_t
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= frame->n_obstacle)
         return;
+    if (frame->status)  // the lists did not fit: groups returned before they wrote their parents (caller retries)
+    {
+        uf_st(parent + i, i);
+        return;
+    }
     uint32_t x = i, p = uf_ld(parent + x);
     while (p != x)
     {
@@ -2110,9 +2388,43 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
         // a batch stages nothing while the ranges are far above the LDS capacity (most rounds run in global memory
         // anyway): those workgroups need 256 bytes of LDS instead of 48 KiB
         const bool stage = ctx->cur_b == 1 || size <= 4u * (uint32_t)blk_cap;
+        const KdTopState *top = nullptr;
+        // LPX_KD_TOP_MIN overrides the size from which a level takes the multi-workgroup rounds (tests)
+        static const uint32_t top_min = getenv("LPX_KD_TOP_MIN") ? (uint32_t)atoi(getenv("LPX_KD_TOP_MIN")) : TOP_MIN;
+        if (size > top_min && size > (uint32_t)TOP_HAND && (sizeof(KdTopState) << level) <= ctx->kd_state.bytes)
+        {
+            // large ranges: the first rounds of every nth_element of this level on many workgroups
+            KdTopState *state = (KdTopState *)ctx->kd_state.p;
+            uint2 *tile_cnt = (uint2 *)ctx->key64_b.p;  // 64-bit key scratch of the segmentation: free here
+            const int tiles = (int)((size + TOP_TILE - 1) / TOP_TILE);
+            const uint32_t ranges = 1u << level;
+            if (sizeof(uint2) * (size_t)tiles * ranges <= ctx->key64_b.bytes)
+            {
+                int rounds = 6;  // the active range shrinks by ~0.6 per round; kd_block_kernel finishes the rest
+                for (uint32_t sz = size; sz > (uint32_t)TOP_HAND; sz = sz * 3 / 5)
+                    ++rounds;
+                const dim3 gp((ranges + 63) / 64, 1, ctx->cur_b), gt(tiles, ranges, ctx->cur_b);
+                const dim3 gs(tiles < 64 ? tiles : 64, ranges, ctx->cur_b);
+                for (int r = 0; r <= rounds; ++r)
+                {
+                    hipLaunchKernelGGL(kd_top_pivot, gp, dim3(64), 0, ctx->stream, nodes, (const uint32_t *)lpos,
+                                       (const uint32_t *)rasc, frame, state, level, r == 0 ? 1 : (r == rounds ? 2 : 0),
+                                       ctx->fstride);
+                    if (r == rounds)
+                        break;  // the last call only applies the last cut
+                    hipLaunchKernelGGL(kd_top_flags, gt, dim3(TOP_THREADS), 0, ctx->stream, (const Node *)nodes,
+                                       (const KdTopState *)state, tile_cnt, level, tiles, ctx->fstride);
+                    hipLaunchKernelGGL(kd_top_lists, gt, dim3(TOP_THREADS), 0, ctx->stream, (const Node *)nodes, state,
+                                       (const uint2 *)tile_cnt, lpos, rasc, level, tiles, ctx->fstride);
+                    hipLaunchKernelGGL(kd_top_swap, gs, dim3(TOP_THREADS), 0, ctx->stream, nodes, state,
+                                       (const uint32_t *)lpos, (const uint32_t *)rasc, ctx->fstride);
+                }
+                top = state;
+            }
+        }
         hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G),
                            stage ? blk_lds : 64 * sizeof(uint32_t), ctx->stream, nodes, lpos, rasc, frame, level, blk_cap,
-                           stage ? blk_cap : 0, ctx->fstride);
+                           stage ? blk_cap : 0, top, ctx->fstride);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }

@@ -216,3 +216,20 @@ def test_device_entry_point_matches_host_entry_point(ctx):
     assert np.array_equal(d_oidx[:no].cpu().numpy().view(np.uint32), ref["obstacle_idx"])
     assert np.array_equal(d_clab[:no].cpu().numpy(), ref["cluster_labels"])
     assert np.array_equal(d_planes.cpu().numpy().view(np.uint32).reshape(6, 4), ref["planes"].view(np.uint32))
+
+
+@pytest.mark.parametrize("byte", ["0xa5", "0xff"])
+def test_results_do_not_depend_on_what_an_earlier_frame_left_in_the_workspace(byte):
+    """LPX_POISON fills the per-point workspace and the neighbour lists before every new frame (read once per
+    process, hence the subprocess): the batch tests above and the capacity-retry tests must pass unchanged, and
+    a frame whose lists overflow must not chase the poison (it used to fault before the retry could run)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, LPX_POISON=byte)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_batch.py"), os.path.join(here, "test_gpu_pipeline.py"),
+                        "-k", "(test_batch and not earlier_frame) or workspace or real_frames or edge_cases"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

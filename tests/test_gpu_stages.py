@@ -72,6 +72,38 @@ def test_kd_layout_matches_reference_order(ctx, kind, m):
     assert np.array_equal(got, want), f"first mismatch at {np.argmax(got != want)}"
 
 
+@pytest.mark.parametrize("kind", ["uniform", "ties", "dups", "sorted"])
+@pytest.mark.parametrize("m", [140_000, 300_007, 1_000_003])
+def test_kd_layout_large_clouds_take_the_multi_workgroup_rounds(ctx, kind, m):
+    """above 131072 nodes the top levels of KDTree::rebuild run their nth_element rounds on many workgroups
+    (kd_top_*): same node array as the reference's std::nth_element, ties and duplicates included"""
+    xyz = _cloud(kind, m, m + len(kind))
+    got = ctx.dbg_kd_layout(xyz)
+    want = oracle.kd_layout(xyz)
+    assert np.array_equal(got, want), f"first mismatch at {np.argmax(got != want)}"
+
+
+def test_kd_layout_multi_workgroup_rounds_forced_on_small_levels():
+    """LPX_KD_TOP_MIN lowers the threshold so that several levels with many ranges each go through the
+    multi-workgroup rounds (a subprocess: the threshold is read once per process)"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle\nfrom lidar_processing_amd import Context\n"
+        "from test_gpu_stages import _cloud\n"
+        "c = Context(0)\n"
+        "for kind, m in (('ties', 70001), ('uniform', 99999), ('dups', 65537), ('sorted', 50000)):\n"
+        "    xyz = _cloud(kind, m, m)\n"
+        "    assert np.array_equal(c.dbg_kd_layout(xyz), oracle.kd_layout(xyz)), (kind, m)\n"
+        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                            os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LPX_KD_TOP_MIN="5000")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_kd_layout_real_frame(ctx):
     pts = load_frame("0000000000")
     r = oracle.segment(pts)
