@@ -1,5 +1,7 @@
 // lpx_api.hip -- C-ABI (include/lpx.h), context / workspace management, host staging, profiling.
 #include "lpx_internal.h"
+
+#include <atomic>
 #include "lpx_debug.h"
 
 #include <stdarg.h>
@@ -289,6 +291,15 @@ extern "C" int lpx_profile_read(lpx_ctx *ctx, float *ms, uint32_t *launches, int
 // ------------------------------------------------------------------------------------------------
 // lifetime
 // ------------------------------------------------------------------------------------------------
+// frame slots of the live contexts of a device: how many frames this process can have in flight there (the
+// replay sizes its resident footprint by it, lpx_cluster.hip)
+static std::atomic<uint32_t> g_live_slots[LPX_MAX_DEVICES];
+
+uint32_t lpx_live_frame_slots(int device)
+{
+    return g_live_slots[(unsigned)device % LPX_MAX_DEVICES].load(std::memory_order_relaxed);
+}
+
 static int create_common(int device, hipStream_t stream, bool own, uint32_t batch, lpx_ctx **out)
 {
     if (!out)
@@ -322,6 +333,8 @@ static int create_common(int device, hipStream_t stream, bool own, uint32_t batc
     else
         ctx->stream = stream;
     ctx->batch = batch;
+    g_live_slots[(unsigned)device % LPX_MAX_DEVICES] += batch;
+    ctx->counted = true;
     ctx->use_lists = batch == 1;  // LPX_NEIGHBOURS_AUTO
     int rc;
     if ((rc = lpx_ensure_capacity(ctx, 1024, 1024)))
@@ -372,6 +385,8 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
     free(ctx->pending);
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
+    if (ctx->counted)
+        g_live_slots[(unsigned)ctx->device % LPX_MAX_DEVICES] -= ctx->batch;
     delete ctx;
 }
 

@@ -1150,13 +1150,18 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             ctx->attr_search = true;
         }
-        // persistent: every wavefront pulls components from the work list; 1024 workgroups x 4 wavefronts per frame
-        // Workgroups per frame: a sequencer wavefront needs little of a CU but holds its LDS for milliseconds, so a
-        // chain keeps its resident footprint small (about 256 workgroups in all, at least 8 per frame: 64
-        // sequencers; proportionally more for frames beyond 128k points) and leaves the CUs to the short, wide kernels of the other chains in flight (measured: 1125 ->
-        // 1230 Mpts/s against 1024 workgroups per frame).  LPX_RS_GRID overrides the per-frame count.
+        // Persistent sequencers: every wavefront pulls components from the frame's work list.  A sequencer needs
+        // little of a CU but its workgroup holds LDS and wave slots for milliseconds (the largest component of the
+        // frame), so what counts is how many replay workgroups are resident on the DEVICE, over all chains in
+        // flight: about 1024 is the measured optimum (kitti, 16 contexts x 32 frames: 2 per frame 1413 Mpts/s,
+        // 8 per frame 1338, 16 per frame 1317; stream, 5 x 32: 8 per frame; synth1m, 4 x 4: 32-64 per frame).
+        // The frame slots of the live contexts of this device stand for "frames in flight".  LPX_RS_GRID overrides
+        // the per-frame count.
         static const uint32_t rg_env = getenv("LPX_RS_GRID") ? (uint32_t)atoi(getenv("LPX_RS_GRID")) : 0u;
-        uint32_t rg_cap = rg_env ? rg_env : (256u / ctx->cur_b > 8u ? 256u / ctx->cur_b : 8u) * (1u + m_max / 131072u);
+        uint32_t slots = lpx_live_frame_slots(ctx->device);
+        slots = slots < ctx->cur_b ? ctx->cur_b : slots;
+        uint32_t rg_cap = rg_env ? rg_env : 1024u / slots;
+        rg_cap = rg_cap < 1u ? 1u : (rg_cap > 64u && !rg_env ? 64u : rg_cap);
         const uint32_t rgrid = (m_max + RS_WAVES - 1) / RS_WAVES < rg_cap ? (m_max + RS_WAVES - 1) / RS_WAVES : rg_cap;
 #define RS_ARGS(lo_, hi_)                                                                                             \
     (const FrameState *)frame, (const uint32_t *)cc_lo, (const uint32_t *)cc_hi, (const uint32_t *)members,            \

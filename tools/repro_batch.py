@@ -24,7 +24,7 @@ stop = False
 def neighbour():
     nctx = Context(0)
     f = load_frame(FRAMES[0])
-    s, c = SegmentationConfiguration(6, 5), ClusteringConfiguration(0.25, 0.5)
+    s, c = SegmentationConfiguration(number_of_planar_partitions=6, number_of_iterations=5), ClusteringConfiguration(0.25, 0.5)
     while not stop:
         nctx.segment_cluster(f, s, c)
     nctx.close()
@@ -67,7 +67,7 @@ for rep in range(reps):
     ctxs = [long_ctx, Context(0)] if rep % 10 == 0 else [long_ctx]
     for cx in ctxs:
         if rep % 3 == 0:
-            cx.segment_cluster(kitti[: 20_000 + 997 * (rep % 50)], SegmentationConfiguration(6, 5), ccfg)  # other sizes in between
+            cx.segment_cluster(kitti[: 20_000 + 997 * (rep % 50)], SegmentationConfiguration(number_of_planar_partitions=6, number_of_iterations=5), ccfg)  # other sizes in between
         for b, (c, w) in enumerate(zip(clouds, want)):
             r = cx.segment_cluster(c, scfg, ccfg)
             if not np.array_equal(r["cluster_labels"], w):

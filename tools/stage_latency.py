@@ -1,0 +1,55 @@
+"""Per-stage device time of ONE frame on a single-frame context (the drop-in call pattern), lists and search mode.
+usage: stage_latency.py [frame-id | synth1m | synth5m] [reps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from lidar_processing_amd import ClusteringConfiguration, Context, SegmentationConfiguration
+from util import load_frame, synthetic_scene
+
+what = sys.argv[1] if len(sys.argv) > 1 else "0000000077"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+if what == "synth1m":
+    pts, seg, clu = synthetic_scene(700_000, 600, 500, seed=1), (12, 3), (0.09, 0.5)
+elif what == "synth5m":
+    pts, seg, clu = synthetic_scene(3_500_000, 3000, 500, seed=2), (24, 3), (0.04, 0.5)
+else:
+    pts, seg, clu = load_frame(what), (6, 5), (0.25, 0.5)
+scfg = SegmentationConfiguration(number_of_planar_partitions=seg[0], number_of_iterations=seg[1])
+ccfg = ClusteringConfiguration(distance_squared=clu[0], cluster_quality=clu[1])
+n = pts.shape[0]
+dev = torch.device("cuda:0")
+rec = np.zeros((n, 8), np.float32)
+rec[:, :4] = pts[:, :4]
+d_pts = torch.from_numpy(rec).to(dev)
+out = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)]
+d_planes = torch.empty(4 * seg[0], dtype=torch.float32, device=dev)
+d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+for mode in ("lists", "search"):
+    c = Context(0)
+    c.set_neighbour_mode(mode)
+    c.reserve(n)
+
+    def run():
+        c.segment_cluster_device(d_pts.data_ptr(), 32, n, scfg, ccfg, out[0].data_ptr(), out[1].data_ptr(),
+                                 out[2].data_ptr(), d_planes.data_ptr(), out[3].data_ptr(), d_counts.data_ptr())
+    for _ in range(5):
+        run()
+    c.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+        c.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    c.profile_enable(True)
+    for _ in range(reps):
+        run()
+        c.synchronize()
+    prof = c.profile_read()
+    c.profile_enable(False)
+    tot = sum(ms for ms, cnt in prof.values()) / reps
+    print(f"{what} {mode}: wall {wall:.3f} ms/frame, stages sum {tot:.3f} ms  counts {d_counts.cpu().numpy()}")
+    print("   " + "  ".join(f"{k} {ms / max(1, cnt):.3f}" for k, (ms, cnt) in prof.items() if cnt))
+    c.close()
