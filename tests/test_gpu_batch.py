@@ -234,3 +234,15 @@ def test_results_do_not_depend_on_what_an_earlier_frame_left_in_the_workspace(by
                               "or edge_cases)"],  # (never this test itself: it would recurse)
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_randomised_scenes_and_configurations_match_the_oracle():
+    """tools/fuzz.py for a quarter of a minute: random scenes x random configurations through the host path (both
+    neighbour modes) and through 3-frame chains on long-lived contexts, everything compared with the oracle"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "15", "11"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,5 +1,5 @@
 """Per-stage device time of ONE frame on a single-frame context (the drop-in call pattern), lists and search mode.
-usage: stage_latency.py [frame-id | synth1m | synth5m] [reps]"""
+usage: stage_latency.py [frame-id | synth1m | synth5m] [reps] [modes]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,7 +27,8 @@ d_pts = torch.from_numpy(rec).to(dev)
 out = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4)]
 d_planes = torch.empty(4 * seg[0], dtype=torch.float32, device=dev)
 d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
-for mode in ("lists", "search"):
+modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ("lists", "search")
+for mode in modes:
     c = Context(0)
     c.set_neighbour_mode(mode)
     c.reserve(n)
