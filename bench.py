@@ -52,10 +52,10 @@ WORKLOADS = {
                    clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=154, batch=32, contexts=5),
     "synth1m": dict(config="configs[2]: synthetic 1M-pt plane + boxes, 12 segments, 3 iters, FEC d=0.3 m q=0.5",
                     seg=dict(number_of_planar_partitions=12, number_of_iterations=3),
-                    clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=16, batch=4, contexts=4),
+                    clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=64, batch=8, contexts=8),
     "synth5m": dict(config="configs[4]: synthetic 5M-pt plane + boxes, 24 segments, 3 iters, FEC d=0.2 m q=0.5",
                     seg=dict(number_of_planar_partitions=24, number_of_iterations=3),
-                    clu=dict(distance_squared=0.04, cluster_quality=0.5), frames_per_step=4, batch=1, contexts=4,
+                    clu=dict(distance_squared=0.04, cluster_quality=0.5), frames_per_step=8, batch=1, contexts=8,
                     lists=True),  # one frame per chain: LPX_NEIGHBOURS_AUTO picks the list path, 5x faster here
 }
 
