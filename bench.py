@@ -465,13 +465,25 @@ def main():
                 for _ in range(passes):
                     feeder.run(ctxs[0], ids, scfg, ccfg, out)
                 tf = (time.perf_counter() - a) / passes
+                # all contexts of the bench, one pipeline each (lpx_feeder_run_multi), the stream three times over
+                ids3 = np.tile(ids, 3)
+                out3 = feeder.run(ctxs, ids3, scfg, ccfg)
+                a = time.perf_counter()
+                for _ in range(passes):
+                    feeder.run(ctxs, ids3, scfg, ccfg, out3)
+                tm = (time.perf_counter() - a) / passes
+                del out, out3
                 feeder.close()
             stream_info = {"frames": len(my_ids), "device_resident_frames_per_s": round(F * world * args.steps / elapsed, 1),
                            "feeder_frames_per_s": round(len(ids) / tf, 1),
                            "feeder_mpts_s": round(points_per_step / tf / 1e6, 2),
                            "feeder_what": "lpx_feeder_run on ONE batch context: pinned records H2D, chains of "
                                           f"{B}, exact-size D2H of labels / index lists / cluster labels / planes, "
-                                          "two buffer sets (PCIe-inclusive; never the headline value)"}
+                                          "two buffer sets (PCIe-inclusive; never the headline value)",
+                           "feeder_multi_frames_per_s": round(len(ids3) / tm, 1),
+                           "feeder_multi_mpts_s": round(3 * points_per_step / tm / 1e6, 2),
+                           "feeder_multi_what": f"lpx_feeder_run_multi on the {len(ctxs)} contexts of this run (one "
+                                                "pipeline and host thread per context), the stream three times over"}
 
     if rank == 0:
         value = total_points_per_step * args.steps / elapsed / 1e6

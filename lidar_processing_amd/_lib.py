@@ -99,6 +99,8 @@ def lib():
     L.lpx_feeder_last_error.argtypes = [vp]
     L.lpx_feeder_last_error.restype = C.c_char_p
     L.lpx_feeder_run.argtypes = [vp, vp, vp, u32, C.POINTER(SegCfg), C.POINTER(CluCfg), C.POINTER(StreamOut)]
+    L.lpx_feeder_run_multi.argtypes = [vp, C.POINTER(vp), u32, vp, u32, C.POINTER(SegCfg), C.POINTER(CluCfg),
+                                       C.POINTER(StreamOut)]
     L.lpx_segment_cluster_batch_fields_device.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, vp, C.POINTER(SegCfg),
                                                           C.POINTER(CluCfg), vp, vp, vp, vp, vp, vp]
     L.lpx_create_batch.argtypes = [C.c_int, u32, C.POINTER(vp)]

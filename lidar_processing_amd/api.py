@@ -421,8 +421,9 @@ class Feeder:
             inf.n_points, inf.point_step // 4)
 
     def run(self, ctx, frame_ids, seg_cfg, clu_cfg, out=None):
-        """lpx_feeder_run through the batch context `ctx`; returns the dict of pinned, pitched result arrays
-        (labels, ground_idx, obstacle_idx, cluster_labels (F, pitch); planes (F, 4P); counts (F, 4))"""
+        """lpx_feeder_run through the batch context `ctx` -- or lpx_feeder_run_multi through a list of batch
+        contexts of equal slot count (chain k on context k % len(ctx)); returns the dict of pinned, pitched result
+        arrays (labels, ground_idx, obstacle_idx, cluster_labels (F, pitch); planes (F, 4P); counts (F, 4))"""
         ids = np.ascontiguousarray(frame_ids, dtype=np.uint32)
         F = ids.shape[0]
         P = seg_cfg.number_of_planar_partitions
@@ -437,7 +438,11 @@ class Feeder:
         so = _lib.StreamOut(*[out[k].array.ctypes.data for k in ("labels", "ground_idx", "obstacle_idx", "cluster_labels",
                                                                  "planes", "counts")], out["pitch"])
         sc, cc = seg_cfg._c(), clu_cfg._c()
-        rc = self._L.lpx_feeder_run(self._h, ctx._h, _vp(ids), F, C.byref(sc), C.byref(cc), C.byref(so))
+        if isinstance(ctx, (list, tuple)):
+            hs = (C.c_void_p * len(ctx))(*[c._h for c in ctx])
+            rc = self._L.lpx_feeder_run_multi(self._h, hs, len(ctx), _vp(ids), F, C.byref(sc), C.byref(cc), C.byref(so))
+        else:
+            rc = self._L.lpx_feeder_run(self._h, ctx._h, _vp(ids), F, C.byref(sc), C.byref(cc), C.byref(so))
         if rc != 0:
             raise LpxError(rc, self._L.lpx_feeder_last_error(self._h).decode())
         return out

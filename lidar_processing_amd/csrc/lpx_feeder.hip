@@ -15,6 +15,8 @@
 //   chain k - 1: the host waits for it WHILE chain k runs, reads its 4-word counts and issues exact-size D2H
 //                copies of labels / index lists / cluster labels / planes on a second copy stream.
 // PCIe moves in both directions next to the compute; the device never waits for the host between chains.
+// lpx_feeder_run_multi runs one such pipeline per context (chain k belongs to context k % C, one host thread each), so
+// that several chains compute at once like in the device-resident case.
 #include "lpx_internal.h"
 
 #include <errno.h>
@@ -22,7 +24,22 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
+
+// device side of one pipeline: its copy streams, two buffer sets and their events
+struct FeederLane
+{
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_compute[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+    void *d_in[2] = {nullptr, nullptr};
+    void *d_out[2] = {nullptr, nullptr};
+    size_t in_bytes = 0, out_bytes = 0;
+    uint32_t *h_counts = nullptr;  // pinned, 2 sets x B x 4
+    uint32_t cap_b = 0, cap_pitch = 0, cap_P = 0;
+    int rc = 0;
+    char err[512] = {0};
+};
 
 struct lpx_feeder
 {
@@ -33,17 +50,17 @@ struct lpx_feeder
     size_t pinned_bytes = 0;
     uint32_t max_points = 0, max_step = 0;
     char err[512] = {0};
-    // device side of lpx_feeder_run (sized on first use)
-    hipStream_t h2d = nullptr, d2h = nullptr;
-    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_compute[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
-    void *d_in[2] = {nullptr, nullptr};
-    void *d_out[2] = {nullptr, nullptr};
-    size_t in_bytes = 0, out_bytes = 0;
-    uint32_t *h_counts = nullptr;  // pinned, 2 sets x B x 4
-    uint32_t cap_b = 0, cap_pitch = 0, cap_P = 0;
+    std::vector<FeederLane *> lanes;  // device side of lpx_feeder_run*, one lane per context (sized on first use)
 };
 
 static int ffail(lpx_feeder *f, int code, const char *fmt, const char *a, const char *b = "")
+{
+    if (f)
+        snprintf(f->err, sizeof f->err, fmt, a, b);
+    return code;
+}
+
+static int ffail(FeederLane *f, int code, const char *fmt, const char *a, const char *b = "")
 {
     if (f)
         snprintf(f->err, sizeof f->err, fmt, a, b);
@@ -247,7 +264,7 @@ extern "C" int lpx_feeder_create(int device, const char *const *paths, uint32_t 
     return LPX_OK;
 }
 
-static void feeder_release_device(lpx_feeder *f)
+static void lane_release(FeederLane *f)
 {
     for (int s = 0; s < 2; ++s)
     {
@@ -273,6 +290,16 @@ static void feeder_release_device(lpx_feeder *f)
         hipStreamDestroy(f->d2h);
     f->h2d = f->d2h = nullptr;
     f->cap_b = f->cap_pitch = f->cap_P = 0;
+}
+
+static void feeder_release_device(lpx_feeder *f)
+{
+    for (FeederLane *l : f->lanes)
+    {
+        lane_release(l);
+        delete l;
+    }
+    f->lanes.clear();
 }
 
 extern "C" void lpx_feeder_destroy(lpx_feeder *f)
@@ -337,15 +364,15 @@ static OutSet out_set(void *base, uint32_t B, uint32_t pitch, uint32_t P)
             return ffail((f), LPX_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                           \
     } while (0)
 
-static int feeder_prepare(lpx_feeder *f, uint32_t B, uint32_t pitch, uint32_t P)
+static int lane_prepare(FeederLane *f, uint32_t max_step, uint32_t B, uint32_t pitch, uint32_t P)
 {
     if (f->cap_b >= B && f->cap_pitch >= pitch && f->cap_P >= P && f->d_in[0])
         return LPX_OK;
     hipDeviceSynchronize();
-    feeder_release_device(f);
+    lane_release(f);
     FHIP(f, hipStreamCreateWithFlags(&f->h2d, hipStreamNonBlocking));
     FHIP(f, hipStreamCreateWithFlags(&f->d2h, hipStreamNonBlocking));
-    f->in_bytes = (size_t)B * pitch * f->max_step;
+    f->in_bytes = (size_t)B * pitch * max_step;
     f->out_bytes = sizeof(uint32_t) * ((size_t)B * pitch * 4 + (size_t)B * 4 * P + (size_t)B * 4) + 256;
     for (int s = 0; s < 2; ++s)
     {
@@ -362,22 +389,138 @@ static int feeder_prepare(lpx_feeder *f, uint32_t B, uint32_t pitch, uint32_t P)
     return LPX_OK;
 }
 
-// Frames frame_ids[0 .. n_frames) of the feeder through `ctx` (a batch context; its slot count is the chain
-// length), results to host arrays pitched by out->frame_pitch elements per frame (planes: 4 P floats, counts: 4
-// words {n_ground, n_obstacle, n_clusters, status}).  Synchronous at return.
-extern "C" int lpx_feeder_run(lpx_feeder *f, lpx_ctx *ctx, const uint32_t *frame_ids, uint32_t n_frames,
-                              const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, const lpx_stream_out *out)
+// The pipeline of one lane: chains first, first + stride, ... of the run through `ctx`.
+namespace
 {
-    if (!f || !ctx || !seg_cfg || !clu_cfg || !out || (!frame_ids && n_frames))
+struct RunArgs
+{
+    lpx_feeder *f;
+    const uint32_t *frame_ids;
+    uint32_t n_frames, B, P, step, n_chains;
+    uint32_t offs[3];
+    const lpx_seg_cfg *seg_cfg;
+    const lpx_clu_cfg *clu_cfg;
+    const lpx_stream_out *out;
+};
+
+int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint32_t stride)
+{
+    lpx_feeder *f = a.f;
+    const lpx_stream_out *out = a.out;
+    const uint32_t B = a.B, P = a.P, step = a.step;
+    const size_t up = out->frame_pitch;
+    FHIP(l, hipSetDevice(f->device));
+
+    // exact-size D2H of the results of the lane's j-th chain once it has computed (the host waits for it while the
+    // lane's next chain runs)
+    auto drain = [&](uint32_t j) -> int {
+        const int s = (int)(j & 1u);
+        const uint32_t k = first + j * stride;
+        const uint32_t lo = k * B, nb = (a.n_frames - lo < B) ? a.n_frames - lo : B;
+        const OutSet o = out_set(l->d_out[s], B, l->cap_pitch, l->cap_P);
+        uint32_t *hc = l->h_counts + (size_t)s * B * 4;
+        FHIP(l, hipEventSynchronize(l->ev_compute[s]));
+        FHIP(l, hipMemcpyAsync(hc, o.counts, sizeof(uint32_t) * 4 * nb, hipMemcpyDeviceToHost, l->d2h));
+        FHIP(l, hipStreamSynchronize(l->d2h));
+        for (uint32_t b = 0; b < nb; ++b)
+        {
+            const uint32_t fid = a.frame_ids[lo + b], n = f->info[fid].n_points;
+            const uint32_t ng = hc[4 * b], no = hc[4 * b + 1];
+            const size_t dst = (size_t)(lo + b) * up, src = (size_t)b * l->cap_pitch;
+            memcpy(out->counts + 4 * (size_t)(lo + b), hc + 4 * b, 16);
+            if (n)
+                FHIP(l, hipMemcpyAsync(out->labels + dst, o.labels + src, 4 * (size_t)n, hipMemcpyDeviceToHost, l->d2h));
+            if (ng)
+                FHIP(l, hipMemcpyAsync(out->ground_idx + dst, o.gidx + src, 4 * (size_t)ng, hipMemcpyDeviceToHost, l->d2h));
+            if (no)
+            {
+                FHIP(l, hipMemcpyAsync(out->obstacle_idx + dst, o.oidx + src, 4 * (size_t)no, hipMemcpyDeviceToHost, l->d2h));
+                FHIP(l, hipMemcpyAsync(out->cluster_labels + dst, o.clabels + src, 4 * (size_t)no, hipMemcpyDeviceToHost,
+                                       l->d2h));
+            }
+        }
+        if (out->planes)
+            FHIP(l, hipMemcpyAsync(out->planes + (size_t)lo * 4 * P, o.planes, sizeof(float) * 4 * P * nb,
+                                   hipMemcpyDeviceToHost, l->d2h));
+        FHIP(l, hipEventRecord(l->ev_d2h[s], l->d2h));
+        return LPX_OK;
+    };
+
+    uint32_t n_pts[LPX_MAX_BATCH];
+    uint32_t j = 0;
+    int rc;
+    for (uint32_t k = first; k < a.n_chains; k += stride, ++j)
+    {
+        const int s = (int)(j & 1u);
+        const uint32_t lo = k * B, nb = (a.n_frames - lo < B) ? a.n_frames - lo : B;
+        // inputs of set s are free once the lane's chain j - 2 has computed
+        if (j >= 2)
+            FHIP(l, hipStreamWaitEvent(l->h2d, l->ev_compute[s], 0));
+        for (uint32_t b = 0; b < nb; ++b)
+        {
+            const uint32_t fid = a.frame_ids[lo + b];
+            n_pts[b] = f->info[fid].n_points;
+            if (n_pts[b])
+                FHIP(l, hipMemcpyAsync((char *)l->d_in[s] + (size_t)b * l->cap_pitch * step, f->pinned + f->offset[fid],
+                                       (size_t)n_pts[b] * step, hipMemcpyHostToDevice, l->h2d));
+        }
+        FHIP(l, hipEventRecord(l->ev_h2d[s], l->h2d));
+        FHIP(l, hipStreamWaitEvent(ctx->stream, l->ev_h2d[s], 0));
+        if (j >= 2)
+            FHIP(l, hipStreamWaitEvent(ctx->stream, l->ev_d2h[s], 0));  // chain j - 2's results have left set s
+        const OutSet o = out_set(l->d_out[s], B, l->cap_pitch, l->cap_P);
+        rc = lpx_batch_impl(ctx, nb, l->d_in[s], step, a.offs, l->cap_pitch, n_pts, a.seg_cfg, a.clu_cfg, o.labels, o.gidx,
+                            o.oidx, o.planes, o.clabels, o.counts);
+        if (rc)
+            return ffail(l, rc, "%s", lpx_last_error(ctx));
+        FHIP(l, hipEventRecord(l->ev_compute[s], ctx->stream));
+        if (j >= 1 && (rc = drain(j - 1)))
+            return rc;
+    }
+    if (j && (rc = drain(j - 1)))
+        return rc;
+    FHIP(l, hipStreamSynchronize(l->d2h));
+    return LPX_OK;
+}
+}  // namespace
+
+// Frames frame_ids[0 .. n_frames) of the feeder through n_ctx batch contexts of equal slot count B (the chain
+// length): chain k -- frames [k B, (k+1) B) -- runs on context k % n_ctx, every context with its own copy streams
+// and buffer sets and its own host thread.  Results to host arrays pitched by out->frame_pitch elements per frame
+// (planes: 4 P floats, counts: 4 words {n_ground, n_obstacle, n_clusters, status}).  Synchronous at return.
+extern "C" int lpx_feeder_run_multi(lpx_feeder *f, lpx_ctx *const *ctxs, uint32_t n_ctx, const uint32_t *frame_ids,
+                                    uint32_t n_frames, const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
+                                    const lpx_stream_out *out)
+{
+    if (!f || !ctxs || n_ctx == 0 || !seg_cfg || !clu_cfg || !out || (!frame_ids && n_frames))
         return LPX_ERR_ARG;
     if (!out->labels || !out->ground_idx || !out->obstacle_idx || !out->cluster_labels || !out->counts)
         return ffail(f, LPX_ERR_ARG, "%s", "every output array except planes is required");
     if (n_frames == 0)
         return LPX_OK;
-    if (ctx->device != f->device)
-        return ffail(f, LPX_ERR_ARG, "%s", "feeder and context live on different devices");
-    const uint32_t B = ctx->batch, P = seg_cfg->number_of_planar_partitions;
-    uint32_t pitch = 0, step = 0;
+    for (uint32_t c = 0; c < n_ctx; ++c)
+    {
+        if (!ctxs[c])
+            return LPX_ERR_ARG;
+        if (ctxs[c]->device != f->device)
+            return ffail(f, LPX_ERR_ARG, "%s", "feeder and context live on different devices");
+        if (ctxs[c]->batch != ctxs[0]->batch)
+            return ffail(f, LPX_ERR_ARG, "%s", "the contexts of one run must have the same number of frame slots");
+        for (uint32_t e = 0; e < c; ++e)
+            if (ctxs[e] == ctxs[c])
+                return ffail(f, LPX_ERR_ARG, "%s", "the same context twice");
+    }
+    RunArgs a;
+    a.f = f;
+    a.frame_ids = frame_ids;
+    a.n_frames = n_frames;
+    a.B = ctxs[0]->batch;
+    a.P = seg_cfg->number_of_planar_partitions;
+    a.seg_cfg = seg_cfg;
+    a.clu_cfg = clu_cfg;
+    a.out = out;
+    uint32_t pitch = 0;
+    a.step = 0;
     for (uint32_t j = 0; j < n_frames; ++j)
     {
         if (frame_ids[j] >= f->info.size())
@@ -385,88 +528,53 @@ extern "C" int lpx_feeder_run(lpx_feeder *f, lpx_ctx *ctx, const uint32_t *frame
         const lpx_pcd_info &inf = f->info[frame_ids[j]];
         pitch = inf.n_points > pitch ? inf.n_points : pitch;
         if (j == 0)
-            step = inf.point_step;
+            a.step = inf.point_step;
         const lpx_pcd_info &i0 = f->info[frame_ids[0]];
-        if (inf.point_step != step || inf.off_x != i0.off_x || inf.off_y != i0.off_y || inf.off_z != i0.off_z)
+        if (inf.point_step != a.step || inf.off_x != i0.off_x || inf.off_y != i0.off_y || inf.off_z != i0.off_z)
             return ffail(f, LPX_ERR_ARG, "%s", "the frames of one run must share a record layout");
     }
     if (pitch > out->frame_pitch)
         return ffail(f, LPX_ERR_ARG, "%s", "a frame holds more points than out->frame_pitch");
-    FHIP(f, hipSetDevice(f->device));
-    int rc = feeder_prepare(f, B, pitch, P);
-    if (rc)
-        return rc;
-    if ((rc = lpx_reserve(ctx, pitch, 0)))
-        return ffail(f, rc, "%s", lpx_last_error(ctx));
     const lpx_pcd_info lay = f->info[frame_ids[0]];
-    const uint32_t offs[3] = {lay.off_x, lay.off_y, lay.off_z};
-    const uint32_t n_chains = (n_frames + B - 1) / B;
-    const size_t up = out->frame_pitch;
-
-    // exact-size D2H of chain k's results once it has computed (the host waits for it while chain k + 1 runs)
-    auto drain = [&](uint32_t k) -> int {
-        const int s = (int)(k & 1u);
-        const uint32_t lo = k * B, nb = (n_frames - lo < B) ? n_frames - lo : B;
-        const OutSet o = out_set(f->d_out[s], B, f->cap_pitch, f->cap_P);
-        uint32_t *hc = f->h_counts + (size_t)s * B * 4;
-        FHIP(f, hipEventSynchronize(f->ev_compute[s]));
-        FHIP(f, hipMemcpyAsync(hc, o.counts, sizeof(uint32_t) * 4 * nb, hipMemcpyDeviceToHost, f->d2h));
-        FHIP(f, hipStreamSynchronize(f->d2h));
-        for (uint32_t b = 0; b < nb; ++b)
-        {
-            const uint32_t fid = frame_ids[lo + b], n = f->info[fid].n_points;
-            const uint32_t ng = hc[4 * b], no = hc[4 * b + 1];
-            const size_t dst = (size_t)(lo + b) * up, src = (size_t)b * f->cap_pitch;
-            memcpy(out->counts + 4 * (size_t)(lo + b), hc + 4 * b, 16);
-            if (n)
-                FHIP(f, hipMemcpyAsync(out->labels + dst, o.labels + src, 4 * (size_t)n, hipMemcpyDeviceToHost, f->d2h));
-            if (ng)
-                FHIP(f, hipMemcpyAsync(out->ground_idx + dst, o.gidx + src, 4 * (size_t)ng, hipMemcpyDeviceToHost, f->d2h));
-            if (no)
-            {
-                FHIP(f, hipMemcpyAsync(out->obstacle_idx + dst, o.oidx + src, 4 * (size_t)no, hipMemcpyDeviceToHost, f->d2h));
-                FHIP(f, hipMemcpyAsync(out->cluster_labels + dst, o.clabels + src, 4 * (size_t)no, hipMemcpyDeviceToHost,
-                                       f->d2h));
-            }
-        }
-        if (out->planes)
-            FHIP(f, hipMemcpyAsync(out->planes + (size_t)lo * 4 * P, o.planes, sizeof(float) * 4 * P * nb,
-                                   hipMemcpyDeviceToHost, f->d2h));
-        FHIP(f, hipEventRecord(f->ev_d2h[s], f->d2h));
-        return LPX_OK;
-    };
-
-    uint32_t n_pts[LPX_MAX_BATCH];
-    for (uint32_t k = 0; k < n_chains; ++k)
+    a.offs[0] = lay.off_x;
+    a.offs[1] = lay.off_y;
+    a.offs[2] = lay.off_z;
+    a.n_chains = (n_frames + a.B - 1) / a.B;
+    const uint32_t lanes = n_ctx < a.n_chains ? n_ctx : a.n_chains;
+    if (hipSetDevice(f->device) != hipSuccess)
+        return ffail(f, LPX_ERR_HIP, "%s", "hipSetDevice failed");
+    while (f->lanes.size() < lanes)
+        f->lanes.push_back(new FeederLane());
+    int rc;
+    for (uint32_t c = 0; c < lanes; ++c)
     {
-        const int s = (int)(k & 1u);
-        const uint32_t lo = k * B, nb = (n_frames - lo < B) ? n_frames - lo : B;
-        // inputs of set s are free once chain k - 2 has computed
-        if (k >= 2)
-            FHIP(f, hipStreamWaitEvent(f->h2d, f->ev_compute[s], 0));
-        for (uint32_t b = 0; b < nb; ++b)
-        {
-            const uint32_t fid = frame_ids[lo + b];
-            n_pts[b] = f->info[fid].n_points;
-            if (n_pts[b])
-                FHIP(f, hipMemcpyAsync((char *)f->d_in[s] + (size_t)b * f->cap_pitch * step, f->pinned + f->offset[fid],
-                                       (size_t)n_pts[b] * step, hipMemcpyHostToDevice, f->h2d));
-        }
-        FHIP(f, hipEventRecord(f->ev_h2d[s], f->h2d));
-        FHIP(f, hipStreamWaitEvent(ctx->stream, f->ev_h2d[s], 0));
-        if (k >= 2)
-            FHIP(f, hipStreamWaitEvent(ctx->stream, f->ev_d2h[s], 0));  // chain k - 2's results have left set s
-        const OutSet o = out_set(f->d_out[s], B, f->cap_pitch, f->cap_P);
-        rc = lpx_batch_impl(ctx, nb, f->d_in[s], step, offs, f->cap_pitch, n_pts, seg_cfg, clu_cfg, o.labels, o.gidx, o.oidx,
-                            o.planes, o.clabels, o.counts);
-        if (rc)
-            return ffail(f, rc, "%s", lpx_last_error(ctx));
-        FHIP(f, hipEventRecord(f->ev_compute[s], ctx->stream));
-        if (k >= 1 && (rc = drain(k - 1)))
-            return rc;
+        if ((rc = lane_prepare(f->lanes[c], f->max_step, a.B, pitch, a.P)))
+            return ffail(f, rc, "%s", f->lanes[c]->err);
+        if ((rc = lpx_reserve(ctxs[c], pitch, 0)))
+            return ffail(f, rc, "%s", lpx_last_error(ctxs[c]));
     }
-    if ((rc = drain(n_chains - 1)))
-        return rc;
-    FHIP(f, hipStreamSynchronize(f->d2h));
+    if (lanes == 1)
+        rc = f->lanes[0]->rc = lane_run(f->lanes[0], ctxs[0], a, 0, 1);
+    else
+    {
+        std::vector<std::thread> th;
+        for (uint32_t c = 0; c < lanes; ++c)
+            th.emplace_back([&, c] { f->lanes[c]->rc = lane_run(f->lanes[c], ctxs[c], a, c, lanes); });
+        for (std::thread &t : th)
+            t.join();
+    }
+    for (uint32_t c = 0; c < lanes; ++c)
+        if (f->lanes[c]->rc)
+        {
+            // a lane that stopped early may have left work in flight on the others' streams: settle before returning
+            hipDeviceSynchronize();
+            return ffail(f, f->lanes[c]->rc, "%s", f->lanes[c]->err);
+        }
     return LPX_OK;
+}
+
+extern "C" int lpx_feeder_run(lpx_feeder *f, lpx_ctx *ctx, const uint32_t *frame_ids, uint32_t n_frames,
+                              const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, const lpx_stream_out *out)
+{
+    return lpx_feeder_run_multi(f, &ctx, ctx ? 1u : 0u, frame_ids, n_frames, seg_cfg, clu_cfg, out);
 }

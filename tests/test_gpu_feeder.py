@@ -113,3 +113,41 @@ def test_feeder_short_runs_and_single_frame_parity(pcd_dir, ctx):
     finally:
         bctx.close()
         feeder.close()
+
+
+@pytest.mark.parametrize("n_ctx,B", [(3, 8), (4, 16), (7, 32)])
+def test_feeder_over_several_contexts_gives_the_single_context_results(pcd_dir, n_ctx, B):
+    """lpx_feeder_run_multi: chain k on context k % n_ctx, one pipeline (copy streams, buffer sets, host thread) per
+    context; all 154 frames against the goldens, then a ragged second run on the same lanes (more contexts than
+    chains included) against the first"""
+    cname = "p6i5_d025q05"
+    skw, ckw = STREAM_CONFIGS[cname]
+    scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
+    names = stream_names()
+    feeder = Feeder([pcd_dir / f"{n}.pcd" for n in names])
+    ctxs = [Context(0, batch=B) for _ in range(n_ctx)]
+    try:
+        ids = np.arange(154)
+        out = feeder.run(ctxs, ids, scfg, ccfg)
+        few = np.array([153, 0, 77, 5, 5, 100, 31][: B + 3])
+        out2 = feeder.run(ctxs, few, scfg, ccfg)
+        with pytest.raises(LpxError):
+            feeder.run([ctxs[0], ctxs[0]], ids, scfg, ccfg)
+    finally:
+        for c in ctxs:
+            c.close()
+    g = stream_gold()
+    for j, fid in enumerate(ids):
+        ng, no, nc, status = (int(v) for v in out["counts"].array[j])
+        assert status == 0
+        res = dict(n_ground=ng, n_obstacle=no, n_clusters=nc,
+                   labels=out["labels"].array[j, :int(g["n"][fid])], obstacle_idx=out["obstacle_idx"].array[j, :no],
+                   cluster_labels=out["cluster_labels"].array[j, :no], planes=out["planes"].array[j].reshape(-1, 4))
+        assert golden_row(res) == [int(v) for v in g[cname][fid]], names[fid]
+    for j, fid in enumerate(few):
+        assert np.array_equal(out2["counts"].array[j], out["counts"].array[fid])
+        ng, no = int(out["counts"].array[fid, 0]), int(out["counts"].array[fid, 1])
+        for key, cnt in (("labels", int(g["n"][fid])), ("ground_idx", ng), ("obstacle_idx", no), ("cluster_labels", no)):
+            assert np.array_equal(out2[key].array[j, :cnt], out[key].array[fid, :cnt]), (key, fid)
+        assert np.array_equal(out2["planes"].array[j].view(np.uint32), out["planes"].array[fid].view(np.uint32))
+    feeder.close()
