@@ -373,8 +373,8 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 5)}
 
         if args.lists:
-            STAGE_KERNEL.update(cc_hook="cc_hook_kernel", neighbours="nb_group_kernel", replay="replay_lds_kernel",
-                                components="cc_flatten_kernel")
+            STAGE_KERNEL.update(cc_hook="cc_hook_kernel", neighbours="nb_group_kernel", components="cc_flatten_kernel",
+                                replay="replay_lds_kernel" if Mm <= 393216 else "replay_kernel")  # LDS bitmap limit
         row = stage_row(dom)
         step_ms = elapsed / args.steps * 1e3
         fb = frame_bytes(Nn, Mm, I)
