@@ -246,3 +246,30 @@ def test_randomised_scenes_and_configurations_match_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "15", "11"], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mode", ["search", "lists"])
+def test_batch_of_large_frames_takes_the_multi_workgroup_kd_rounds(mode):
+    """two frames of 1M and 0.7M points in ONE chain: obstacle clouds above 131 072 points send the top kd levels of
+    BOTH slots through kd_top_* (per-slot introselect state and tile counts), the radix tables through
+    hist_rows_kernel and the label scan through the tile-sum path; everything equals the oracle"""
+    clouds = [synthetic_scene(600_000, 2000, 200, 20240601), synthetic_scene(400_000, 1500, 200, 777)]
+    seg_kw = dict(number_of_planar_partitions=12, number_of_iterations=3)
+    clu_kw = dict(distance_squared=0.09, cluster_quality=0.5)
+    bctx = Context(0, batch=2)
+    bctx.set_neighbour_mode(mode)
+    try:
+        res = run_batch(bctx, clouds, seg_kw, clu_kw)
+        res2 = run_batch(bctx, clouds[::-1], seg_kw, clu_kw)[::-1]  # slots swapped
+    finally:
+        bctx.close()
+    for c, r, r2 in zip(clouds, res, res2):
+        o = oracle.segment(c, oracle.SegCfg(**seg_kw))
+        lab, nc = oracle.cluster(c[o["obstacle_idx"]], oracle.CluCfg(**clu_kw))
+        assert o["obstacle_idx"].shape[0] > 131_072
+        for rr in (r, r2):
+            assert rr["status"] == 0
+            assert np.array_equal(rr["labels"], o["labels"]) and np.array_equal(rr["obstacle_idx"], o["obstacle_idx"])
+            assert np.array_equal(rr["ground_idx"], o["ground_idx"])
+            assert np.array_equal(rr["planes"].view(np.uint32), o["planes"].view(np.uint32))
+            assert np.array_equal(rr["cluster_labels"], lab) and rr["n_clusters"] == nc
