@@ -100,6 +100,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             {&ctx->grp_of, n4},   {&ctx->cell_of, n4},  {&ctx->chunks, chunk_bytes},
             {&ctx->cell_key, sizeof(uint64_t) * cell_cap}, {&ctx->cell_rep, sizeof(uint32_t) * cell_cap},
             {&ctx->cell_parent, sizeof(uint32_t) * cell_cap}, {&ctx->cell_xyz, sizeof(float4) * cell_cap},
+            {&ctx->cell_start, sizeof(uint32_t) * cell_cap},
             {&ctx->kd_state, 48 * 1024},  // 48-byte states of up to 1024 ranges (ten top levels)
         };
         size_t total = 0;

@@ -50,7 +50,7 @@ struct FrameState
     uint64_t rs_total;        // words asked from the single-pass region [cap_nb, cap_nb + cap_rs)
     uint64_t cand_total;      // candidates distance-tested by the replay's searches (expansion-driven path)
     uint32_t n_cells;         // occupied cells of the component grid
-    uint32_t pad1;
+    uint32_t cell_cursor;     // points handed out to the cells' contiguous runs
     uint32_t n_windows;       // queue windows with at least one expansion (expansion-driven path)
     uint32_t n_overflow;      // searches redone by the sequencer because the list did not fit its LDS region
 };
@@ -161,7 +161,8 @@ struct lpx_ctx
     Buf grp_of;                // u32 per point: kd group (bucket or upper node) the point is a query of
     Buf chunks;                // ChunkRec [groups][LPX_GROUP_CHUNKS]: candidate chunks (pre-order rank, count, box) of a group
     Buf cell_key;              // u64 [cell_cap]: occupied cells of the component grid (open addressing)
-    Buf cell_rep, cell_parent; // u32 [cell_cap]: head of the cell's point list / union-find over cells
+    Buf cell_rep, cell_parent; // u32 [cell_cap]: points of the cell / union-find over cells
+    Buf cell_start;            // u32 [cell_cap]: where the cell's points begin in the cell-ordered copy
     Buf cell_of;               // u32 per point: its cell slot
     Buf cell_xyz;              // float4 [cell_cap]: the point that claimed the cell
     uint32_t cell_cap = 0;     // slots per frame slot (power of two >= 2 * cap_n)

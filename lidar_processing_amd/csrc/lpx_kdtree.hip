@@ -19,6 +19,8 @@
 // One workgroup (or one wavefront for ranges <= 512 nodes, staged in LDS) owns one range.
 #include "lpx_internal.h"
 
+#include <string.h>
+
 #include <limits.h>
 #include <stdlib.h>
 
@@ -2066,7 +2068,6 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned long long CELL_EMPTY = ~0ull;
 constexpr uint32_t CELL_NONE = 0xffffffffu;
-constexpr int CELL_STAGE = 32;  // points of the wavefront's own cell staged in LDS per pass
 
 // Home slot of a cell: the 2 x 2 x 2 block of cells it belongs to is hashed, the cell's position inside the block
 // picks one of the 8 slots of that 64-byte line -- the 124 partners a cell probes then lie in ~27 lines instead of
@@ -2113,12 +2114,15 @@ __global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long 
     thead = lpx_slot(thead, fs);
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0)
+    {
         frame->n_cells = 0;
+        frame->cell_cursor = 0;
+    }
     if (s >= cell_cap_for(frame->n_obstacle, cap_max) || frame->n_obstacle == 0)
         return;
     tkey[s] = CELL_EMPTY;
     tparent[s] = s;
-    thead[s] = CELL_NONE;
+    thead[s] = 0;  // points of the cell
 }
 
 __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *__restrict__ OX,
@@ -2162,156 +2166,170 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
         h = (h + 1) & mask;
     }
     cell_of[i] = h;
-    next[i] = atomicExch(thead + h, i);  // push on the cell's point list
+    next[i] = atomicAdd(thead + h, 1u);  // the point's position among the points of its cell
 }
 
-__global__ __launch_bounds__(256) void grid_link_kernel(const FrameState *__restrict__ frame,
-                                                        const unsigned long long *__restrict__ tkey,
-                                                        uint32_t *tparent, const uint32_t *__restrict__ thead,
-                                                        const uint32_t *__restrict__ next,
-                                                        const uint32_t *__restrict__ cells,
-                                                        const float *__restrict__ OX, const float *__restrict__ OY,
-                                                        const float *__restrict__ OZ,
-                                                        const float4 *__restrict__ trep, float r2, uint32_t cap_max,
-                                                        uint32_t far_pass, size_t fs)
+// The points of every cell as ONE contiguous run of {x, y, z, index} records (the linking then reads a cell's points
+// with independent loads instead of walking a list): a cell takes its run from a running cursor ...
+__global__ void grid_alloc_kernel(FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
+                                  const uint32_t *__restrict__ tcount, uint32_t *__restrict__ tstart, size_t fs)
 {
-    __shared__ float s_a[4][CELL_STAGE][3];
+    frame = lpx_slot(frame, fs);
+    cells = lpx_slot(cells, fs);
+    tcount = lpx_slot(tcount, fs);
+    tstart = lpx_slot(tstart, fs);
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= frame->n_cells)
+        return;
+    const uint32_t h = cells[c];
+    tstart[h] = atomicAdd(&frame->cell_cursor, tcount[h]);
+}
+
+// ... and every point goes to its position in the run of its cell
+__global__ void grid_scatter_kernel(const FrameState *__restrict__ frame, const float *__restrict__ OX,
+                                    const float *__restrict__ OY, const float *__restrict__ OZ,
+                                    const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ rank,
+                                    const uint32_t *__restrict__ tstart, float4 *__restrict__ cpts, size_t fs)
+{
+    frame = lpx_slot(frame, fs);
+    OX = lpx_slot(OX, fs);
+    OY = lpx_slot(OY, fs);
+    OZ = lpx_slot(OZ, fs);
+    cell_of = lpx_slot(cell_of, fs);
+    rank = lpx_slot(rank, fs);
+    tstart = lpx_slot(tstart, fs);
+    cpts = lpx_slot(cpts, fs);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame->n_obstacle)
+        return;
+    cpts[tstart[cell_of[i]] + rank[i]] = make_float4(OX[i], OY[i], OZ[i], __uint_as_float(i));
+}
+
+// The linking: one (cell, partner) PAIR per lane.  (One wavefront per cell, one partner per lane -- the first form of
+// this kernel -- keeps 13 or 49 of the 64 lanes busy and walks four or five dependent loads per cell (cell list ->
+// key -> probe -> representatives / roots), so it was latency-bound at full occupancy, about 80 cell iterations per
+// resident wavefront; flat pairs fill every lane -- 5 x fewer wavefront iterations in the touching pass, 1.3 x in
+// the far pass -- and the lanes of one cell read the same words: 1393 -> 1520 Mpts/s on the headline workload.)
+// Two passes (two launches): the 13 partners that touch the cell -- almost all of them are connected and the quick
+// test settles them -- then the 49 partners one cell further away, when every union of the first pass is visible:
+// most of those pairs already share a set through the cells between them and are skipped by the root comparison,
+// only pairs of different sets pay for a point-pair scan (every point of the partner against every point of the
+// cell, both contiguous runs of `cpts`, until the first pair within d).
+__constant__ uint8_t FAR_T[49] = {64,  65,  69,  70,  71,  72,  73,  74,  75,  76,  77,  78,  79,  80,  84,  85,  89,
+                                  90,  94,  95,  96,  97,  98,  99,  100, 101, 102, 103, 104, 105, 106, 107, 108, 109,
+                                  110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124};
+
+template <bool FAR>
+__global__ __launch_bounds__(256) void grid_pairs_kernel(const FrameState *__restrict__ frame,
+                                                         const unsigned long long *__restrict__ tkey,
+                                                         uint32_t *tparent, const uint32_t *__restrict__ tcount,
+                                                         const uint32_t *__restrict__ tstart,
+                                                         const uint32_t *__restrict__ cells,
+                                                         const float4 *__restrict__ cpts,
+                                                         const float4 *__restrict__ trep, float r2, uint32_t cap_max,
+                                                         int dbg, size_t fs)
+{
     trep = lpx_slot(trep, fs);
     frame = lpx_slot(frame, fs);
     tkey = lpx_slot(tkey, fs);
     tparent = lpx_slot(tparent, fs);
-    thead = lpx_slot(thead, fs);
-    next = lpx_slot(next, fs);
+    tcount = lpx_slot(tcount, fs);
+    tstart = lpx_slot(tstart, fs);
     cells = lpx_slot(cells, fs);
-    OX = lpx_slot(OX, fs);
-    OY = lpx_slot(OY, fs);
-    OZ = lpx_slot(OZ, fs);
+    cpts = lpx_slot(cpts, fs);
     const uint32_t M = frame->n_obstacle;
     if (M == 0)
         return;
     const uint32_t mask = cell_cap_for(M, cap_max) - 1;
-    const uint32_t n_cells = frame->n_cells;
-    const uint32_t w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    // lane l < 62: the l-th of the offsets in [-2, 2]^3 that follow (0, 0, 0) lexicographically
-    const int t = 63 + (int)lane;  // (0,0,0) has index 62 in the 5 x 5 x 5 enumeration
-    const int dx = t / 25 - 2, dy = (t / 5) % 5 - 2, dz = t % 5 - 2;
-    // Two passes (two launches).  Pass 0 handles the 13 partners that touch the cell: almost all of them are
-    // connected and the walk ends at its first tests.  Pass 1 handles the 49 partners one cell further away: by then
-    // every union of pass 0 is visible, most of these pairs already share a set through the cells between them and
-    // are skipped by the root comparison -- only pairs of different sets pay for a full point-pair scan.
-    const bool near = abs(dx) <= 1 && abs(dy) <= 1 && abs(dz) <= 1;
-    const bool my_pass = lane < 62 && (near == (far_pass == 0u));
-    const uint32_t stride = gridDim.x * (blockDim.x / WAVE);
-    for (uint32_t c = blockIdx.x * (blockDim.x / WAVE) + w; c < n_cells; c += stride)
+    constexpr uint32_t P = FAR ? 49u : 13u;
+    const unsigned long long total = (unsigned long long)frame->n_cells * P;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
     {
+        const uint32_t c = (uint32_t)(item / P), j = (uint32_t)(item % P);
+        int dx, dy, dz;
+        if (FAR)
+        {
+            const int t = FAR_T[j];
+            dx = t / 25 - 2, dy = (t / 5) % 5 - 2, dz = t % 5 - 2;
+        }
+        else
+        {
+            const int u = 14 + (int)j;  // the offsets of [-1, 1]^3 that follow (0, 0, 0) lexicographically
+            dx = u / 9 - 1, dy = (u / 3) % 3 - 1, dz = u % 3 - 1;
+        }
         const uint32_t s = cells[c];
         const unsigned long long key = tkey[s];
-        const int ix = (int)(key >> 42), iy = (int)((key >> 21) & 0x1fffffu), iz = (int)(key & 0x1fffffu);
-        // partner cell of this lane, if it is occupied
-        uint32_t partner = CELL_NONE;
-        const int nx = ix + dx, ny = iy + dy, nz = iz + dz;
-        if (my_pass && (unsigned)nx <= 0x1fffffu && (unsigned)ny <= 0x1fffffu && (unsigned)nz <= 0x1fffffu)
-        {
-            const unsigned long long nk = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) |
-                                          (unsigned long long)nz;
-            uint32_t h = cell_hash(nk) & mask;
-            for (;;)
-            {
-                const unsigned long long k2 = tkey[h];
-                if (k2 == CELL_EMPTY)
-                    break;
-                if (k2 == nk)
-                {
-                    partner = h;
-                    break;
-                }
-                h = (h + 1) & mask;
-            }
-        }
-        // pass 1 first skips what pass 0 already united (pass 0 has nothing to skip yet: it goes straight to the test)
-        if (far_pass && partner != CELL_NONE && uf_find(tparent, s) == uf_find(tparent, partner))
-            partner = CELL_NONE;
-        if (!__ballot(partner != CELL_NONE))
+        const int nx = (int)(key >> 42) + dx, ny = (int)((key >> 21) & 0x1fffffu) + dy, nz = (int)(key & 0x1fffffu) + dz;
+        if ((unsigned)nx > 0x1fffffu || (unsigned)ny > 0x1fffffu || (unsigned)nz > 0x1fffffu)
             continue;
-        // quick test: the point that claimed the cell against the one that claimed the partner (kept in the table).
-        // Cells are a third of a radius wide, so for touching cells this pair is within d most of the time and no
-        // point list is walked.
+        const unsigned long long nk = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) |
+                                      (unsigned long long)nz;
+        uint32_t partner = CELL_NONE;
+        for (uint32_t h = cell_hash(nk) & mask;; h = (h + 1) & mask)
         {
-            const float4 ra = trep[s];
-            if (partner != CELL_NONE)
+            const unsigned long long k2 = tkey[h];
+            if (k2 == CELL_EMPTY)
+                break;
+            if (k2 == nk)
             {
-                const float4 rb = trep[partner];
-                const float d0 = ra.x - rb.x, d1 = ra.y - rb.y, d2 = ra.z - rb.z;
-                if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)
-                {
-                    uf_unite(tparent, s, partner);
-                    partner = CELL_NONE;
-                }
+                partner = h;
+                break;
             }
-            if (!far_pass && partner != CELL_NONE && uf_find(tparent, s) == uf_find(tparent, partner))
-                partner = CELL_NONE;  // united meanwhile by another wavefront
-            if (!__ballot(partner != CELL_NONE))
+        }
+        if (partner == CELL_NONE || dbg == 1)
+            continue;
+        // the far pass first skips what the touching pass already united
+        if (FAR && uf_find(tparent, s) == uf_find(tparent, partner))
+            continue;
+        // quick test: the point that claimed the cell against the one that claimed the partner
+        const float4 ra = trep[s], rb = trep[partner];
+        {
+            const float d0 = ra.x - rb.x, d1 = ra.y - rb.y, d2 = ra.z - rb.z;
+            if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)
+            {
+                if (dbg != 2)
+                    uf_unite(tparent, s, partner);
                 continue;
+            }
         }
-        // the cell's own points, CELL_STAGE at a time, against every open partner
-        uint32_t pa = thead[s];
-        while (pa != CELL_NONE && __ballot(partner != CELL_NONE))
+        if (dbg == 3)
+            continue;
+        if (!FAR && uf_find(tparent, s) == uf_find(tparent, partner))
+            continue;  // united meanwhile through other pairs
+        // every point of the partner against every point of the cell, until the first pair within d
+        bool joined = false;
+        const float4 *A = cpts + tstart[s], *B = cpts + tstart[partner];
+        const uint32_t na = tcount[s], nb = tcount[partner];
+        for (uint32_t b = 0; b < nb && !joined; ++b)
         {
-            // lane i walks i links from pa: one dependent chain of CELL_STAGE short hops, then a parallel fetch
-            uint32_t mine = CELL_NONE, cur = pa;
-            uint32_t n_a = 0;
-            for (int i = 0; i < CELL_STAGE && cur != CELL_NONE; ++i)
+            const float4 pb = B[b];
+            for (uint32_t a = 0; a < na; ++a)
             {
-                if ((int)lane == i)
-                    mine = cur;
-                cur = next[cur];
-                ++n_a;
-            }
-            pa = cur;
-            if (mine != CELL_NONE)
-            {
-                s_a[w][lane][0] = OX[mine];
-                s_a[w][lane][1] = OY[mine];
-                s_a[w][lane][2] = OZ[mine];
-            }
-            Coop<WAVE>::sync();
-            if (partner != CELL_NONE)
-            {
-                bool joined = false;
-                for (uint32_t pb = thead[partner]; pb != CELL_NONE && !joined; pb = next[pb])
+                const float4 pa = A[a];
+                const float d0 = pa.x - pb.x, d1 = pa.y - pb.y, d2 = pa.z - pb.z;
+                if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)  // dist_sqr, src/kdtree.hpp:145-157, inclusive :315
                 {
-                    const float bx = OX[pb], by = OY[pb], bz = OZ[pb];
-                    for (uint32_t i = 0; i < n_a; ++i)
-                    {
-                        const float d0 = s_a[w][i][0] - bx, d1 = s_a[w][i][1] - by, d2 = s_a[w][i][2] - bz;
-                        if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)  // dist_sqr, src/kdtree.hpp:145-157, inclusive :315
-                        {
-                            joined = true;
-                            break;
-                        }
-                    }
-                }
-                if (joined)
-                {
-                    uf_unite(tparent, s, partner);
-                    partner = CELL_NONE;
+                    joined = true;
+                    break;
                 }
             }
-            Coop<WAVE>::sync();
         }
+        if (joined)
+            uf_unite(tparent, s, partner);
     }
 }
 
 // root[i] = a point of the root cell of point i's set (the same word for all its members), iota, state reset
 __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *tparent,
-                                    const uint32_t *__restrict__ thead, const uint32_t *__restrict__ cell_of,
+                                    const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ cell_of,
                                     uint32_t *__restrict__ root, uint32_t *__restrict__ iota,
                                     uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
                                     uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi, size_t fs)
 {
     frame = lpx_slot(frame, fs);
     tparent = lpx_slot(tparent, fs);
-    thead = lpx_slot(thead, fs);
+    tstart = lpx_slot(tstart, fs);
     cell_of = lpx_slot(cell_of, fs);
     root = lpx_slot(root, fs);
     iota = lpx_slot(iota, fs);
@@ -2330,7 +2348,7 @@ __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32
             break;
         x = p;
     }
-    root[i] = thead[x];
+    root[i] = tstart[x];  // where the points of the root cell begin: one word per set, below M
     iota[i] = i;
     state[i] = 0;
     valid[i] = 0;
@@ -2517,16 +2535,28 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     hipLaunchKernelGGL(grid_insert_kernel, gm, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells,
                        (uint32_t *)ctx->cell_of.p, (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fstride);
-    // one wavefront per occupied cell, grid-stride (the device knows how many cells there are)
-    const uint32_t lgrid = (m_max + 3) / 4 < 2048u ? (m_max + 3) / 4 : 2048u;
-    for (uint32_t far_pass = 0; far_pass < 2; ++far_pass)
-        hipLaunchKernelGGL(grid_link_kernel, dim3(lgrid, 1, ctx->cur_b), blk, 0, ctx->stream, (const FrameState *)frame,
-                           (const unsigned long long *)tkey, tparent, (const uint32_t *)thead, (const uint32_t *)next,
-                           (const uint32_t *)cells, (const float *)ctx->OX.p, (const float *)ctx->OY.p,
-                           (const float *)ctx->OZ.p, (const float4 *)ctx->cell_xyz.p, r2, ctx->cell_cap, far_pass,
-                           ctx->fstride);
+    uint32_t *tstart = (uint32_t *)ctx->cell_start.p;
+    float4 *cpts = (float4 *)ctx->nodes.p;  // the array-layout kd nodes are consumed by the build: free here
+    hipLaunchKernelGGL(grid_alloc_kernel, gm, blk, 0, ctx->stream, frame, (const uint32_t *)cells, (const uint32_t *)thead,
+                       tstart, ctx->fstride);
+    hipLaunchKernelGGL(grid_scatter_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, (const float *)ctx->OX.p,
+                       (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (const uint32_t *)ctx->cell_of.p,
+                       (const uint32_t *)next, (const uint32_t *)tstart, cpts, ctx->fstride);
+    // one (cell, partner) pair per lane, grid-stride (the device knows how many cells there are)
+    {
+        const uint32_t pg0 = (m_max * 13u + 255u) / 256u < 512u ? (m_max * 13u + 255u) / 256u : 512u;
+        const uint32_t pg1 = (m_max * 13u + 255u) / 256u < 2048u ? (m_max * 13u + 255u) / 256u : 2048u;
+#define GP_ARGS                                                                                                        \
+    (const FrameState *)frame, (const unsigned long long *)tkey, tparent, (const uint32_t *)thead,                    \
+        (const uint32_t *)tstart, (const uint32_t *)cells, (const float4 *)cpts, (const float4 *)ctx->cell_xyz.p, r2,  \
+        ctx->cell_cap, gp_dbg, ctx->fstride
+        static const int gp_dbg = getenv("LPX_GP_DBG") ? atoi(getenv("LPX_GP_DBG")) : 0;  // timing experiments only
+        hipLaunchKernelGGL(grid_pairs_kernel<false>, dim3(pg0, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
+        hipLaunchKernelGGL(grid_pairs_kernel<true>, dim3(pg1, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
+#undef GP_ARGS
+    }
     hipLaunchKernelGGL(grid_flatten_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, tparent,
-                       (const uint32_t *)thead, (const uint32_t *)ctx->cell_of.p, d_root, d_iota,
+                       (const uint32_t *)tstart, (const uint32_t *)ctx->cell_of.p, d_root, d_iota,
                        (uint8_t *)ctx->state.p, (uint32_t *)ctx->valid.p, (uint32_t *)ctx->cc_lo.p,
                        (uint32_t *)ctx->cc_hi.p, ctx->fstride);
     LPX_HIP(ctx, hipGetLastError());

@@ -73,7 +73,7 @@ __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacl
         f.pad0 = 0;
         f.cand_total = 0;
         f.n_cells = 0;
-        f.pad1 = 0;
+        f.cell_cursor = 0;
         f.n_windows = 0;
         f.n_overflow = 0;
         f.nb_entries = 0;
