@@ -114,7 +114,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             ctx->cap_n = 0;
         }
         LPX_HIP(ctx, hipMalloc(&ctx->arena, total * ctx->batch));
-        // zero once: frame states, and the ticket words at the head of every slot's histogram buffer
+        // zero once: frame states and scratch heads
         LPX_HIP(ctx, hipMemsetAsync(ctx->arena, 0, total * ctx->batch, ctx->stream));
         size_t off = 0;
         for (const Item &it : items)

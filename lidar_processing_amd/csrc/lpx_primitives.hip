@@ -18,21 +18,19 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 static_assert(SORT_TILE == (int)LPX_SORT_TILE, "the arena sizes the histogram table with LPX_SORT_TILE");
 constexpr int RADIX = 256;
 
-// Histogram of one digit per tile.  With `ticket` set, the last block to finish also turns the whole
-// [256][nblocks] table into exclusive offsets (thread d owns the contiguous row of digit d), which
-// saves the separate single-block scan launch of every pass for frame-sized inputs.
+// Histogram of one digit per tile.  Small tables (frame-sized inputs, <= FUSED_SCAN_MAX_BLOCKS tiles) are stored
+// block-major [nblocks][256] and never scanned: every scatter block sums the few rows it needs itself.  Large
+// tables are stored digit-major [256][nblocks] for hist_rows_kernel.
 template <typename KeyT>
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__restrict__ keys, uint32_t n_max,
                                                                    const uint32_t *__restrict__ d_n, uint32_t shift,
-                                                                   uint32_t *hist, uint32_t nblocks, uint32_t *ticket,
-                                                                   size_t fs)
+                                                                   uint32_t *__restrict__ hist, uint32_t nblocks,
+                                                                   int block_major, size_t fs)
 {
     __shared__ uint32_t h[RADIX];
-    __shared__ uint32_t s_last;
     keys = lpx_slot(keys, fs);
     d_n = lpx_slot(d_n, fs);
     hist = lpx_slot(hist, fs);
-    ticket = lpx_slot(ticket, fs);
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     const uint32_t tid = threadIdx.x;
     h[tid] = 0;
@@ -46,81 +44,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__
             atomicAdd(&h[(uint32_t)(keys[e] >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
-    if (!ticket)
-    {
+    if (block_major)
+        hist[blockIdx.x * RADIX + tid] = h[tid];
+    else
         hist[tid * nblocks + blockIdx.x] = h[tid];
-        return;
-    }
-    // hand-off without L2 write-back / invalidate fences: the column is stored write-through (agent-scope
-    // atomic store), drained, and the last block reads every column with agent-scope atomic loads
-    __hip_atomic_store(&hist[tid * nblocks + blockIdx.x], h[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-        s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last)
-        return;
-    // in-place exclusive scan of the flat [256 * nblocks] table: 4 groups x 256 threads x 4 entries per trip,
-    // coalesced, one barrier per trip
-    {
-        const uint32_t total_n = RADIX * nblocks;
-        const uint32_t lane = tid % WAVE, w = tid / WAVE;
-        uint32_t carry = 0, it = 0;
-        for (uint32_t base0 = 0; base0 < total_n; base0 += 4 * SORT_THREADS * 4, ++it)
-        {
-            uint32_t a[4][4], tsum[4], incl[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-            {
-                const uint32_t e = base0 + g * (SORT_THREADS * 4) + tid * 4;
-                tsum[g] = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                {
-                    a[g][i] = (e + i < total_n)
-                                  ? __hip_atomic_load(&hist[e + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                  : 0u;
-                    tsum[g] += a[g][i];
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-            {
-                incl[g] = lpx_wave_incl_scan_u32(tsum[g]);
-                if (lane == WAVE - 1)
-                    h[(it & 1) * 16 + g * SORT_WAVES + w] = incl[g];  // h[] is free again: reuse as scratch
-            }
-            __syncthreads();
-            uint32_t gbase = 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-            {
-                uint32_t wbase = 0, tot = 0;
-#pragma unroll
-                for (int i = 0; i < SORT_WAVES; ++i)
-                {
-                    const uint32_t sv = h[(it & 1) * 16 + g * SORT_WAVES + i];
-                    if (i < (int)w)
-                        wbase += sv;
-                    tot += sv;
-                }
-                const uint32_t e = base0 + g * (SORT_THREADS * 4) + tid * 4;
-                uint32_t run = carry + gbase + wbase + (incl[g] - tsum[g]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                {
-                    if (e + i < total_n)
-                        hist[e + i] = run;
-                    run += a[g][i];
-                }
-                gbase += tot;
-            }
-            carry += gbase;
-        }
-    }
-    if (tid == 0)
-        *ticket = 0;  // self-resetting for the next pass
 }
 
 template <typename KeyT, bool HAS_VALS>
@@ -130,7 +57,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
                                                                       uint32_t *__restrict__ vals_out, uint32_t n_max,
                                                                       const uint32_t *__restrict__ d_n, uint32_t shift,
                                                                       const uint32_t *__restrict__ offs,
-                                                                      uint32_t nblocks, int row_totals, size_t fs)
+                                                                      uint32_t nblocks, int large, size_t fs)
 {
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
     __shared__ uint32_t dsum[SORT_WAVES];
@@ -183,12 +110,34 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
         loc[r] = old + rank;
     }
     __syncthreads();
-    // large tables (hist_rows_kernel): offs holds per-digit exclusive prefixes over the blocks and, behind the table,
-    // the 256 digit totals; the base of digit `tid` is their exclusive prefix
-    uint32_t dbase = 0;
-    if (row_totals)
+    // Global offset of (digit tid, this block) = counts of the lower digits in all blocks + counts of this digit in
+    // the lower blocks.  Small tables hold raw counts, block-major: thread tid sums its column (coalesced rows, at
+    // most FUSED_SCAN_MAX_BLOCKS of them).  Large tables (hist_rows_kernel) hold per-digit exclusive prefixes over
+    // the blocks and, behind the table, the 256 digit totals.
+    uint32_t below = 0, t = 0;
+    if (large)
     {
-        const uint32_t t = offs[RADIX * nblocks + tid];
+        below = offs[tid * nblocks + blockIdx.x];
+        t = offs[RADIX * nblocks + tid];
+    }
+    else
+    {
+        for (uint32_t b0 = 0; b0 < nblocks; b0 += 8)
+        {
+            uint32_t c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                c[u] = (b0 + u < nblocks) ? offs[(b0 + u) * RADIX + tid] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                t += c[u];
+                below += (b0 + u < blockIdx.x) ? c[u] : 0u;
+            }
+        }
+    }
+    uint32_t dbase = 0;
+    {
         const uint32_t incl = lpx_wave_incl_scan_u32(t);
         if (lane == WAVE - 1)
             dsum[w] = incl;
@@ -199,7 +148,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
     }
     // digit `tid`: exclusive prefix over waves + global offset of this (digit, block)
     {
-        uint32_t run = dbase + offs[tid * nblocks + blockIdx.x];
+        uint32_t run = dbase + below;
 #pragma unroll
         for (int ww = 0; ww < SORT_WAVES; ++ww)
         {
@@ -420,8 +369,7 @@ static inline uint32_t sort_blocks(uint32_t n)
 
 constexpr uint32_t FUSED_SCAN_MAX_BLOCKS = 128;
 
-// hist buffer: bytes [0,8) scan-total scratch, [32,36) the ticket of the fused scan (zero between launches),
-// [64,...) the table.  Sized with the frame arena (lpx_ensure_capacity).
+// hist buffer: bytes [0,8) scan-total scratch, [64,...) the table.  Sized with the frame arena (lpx_ensure_capacity).
 static int ensure_hist(lpx_ctx *ctx, uint32_t nblocks)
 {
     const size_t need = 64 + (size_t)RADIX * (nblocks + 1) * sizeof(uint32_t);  // + the row of digit totals
@@ -463,18 +411,18 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     if (rc)
         return rc;
     uint32_t *hist = (uint32_t *)((char *)ctx->hist.p + 64);
-    uint32_t *ticket = (nblocks <= FUSED_SCAN_MAX_BLOCKS) ? (uint32_t *)((char *)ctx->hist.p + 32) : nullptr;
+    const int large = nblocks > FUSED_SCAN_MAX_BLOCKS;
     uint32_t *ka = keys_a, *kb = keys_b, *va = vals_a, *vb = vals_b;
     const uint32_t B = ctx->cur_b;
     const size_t fs = ctx->fstride;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
         hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
-                           d_n, shift, hist, nblocks, ticket, fs);
-        if (!ticket)
+                           d_n, shift, hist, nblocks, !large, fs);
+        if (large)
             hipLaunchKernelGGL(hist_rows_kernel, dim3(RADIX, 1, B), dim3(SORT_THREADS), 0, ctx->stream, hist, nblocks, fs);
         hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
-                           ctx->stream, ka, kb, va, vb, n, d_n, shift, hist, nblocks, ticket ? 0 : 1, fs);
+                           ctx->stream, ka, kb, va, vb, n, d_n, shift, hist, nblocks, large, fs);
         uint32_t *t = ka;
         ka = kb;
         kb = t;
@@ -496,19 +444,19 @@ int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n
     if (rc)
         return rc;
     uint32_t *hist = (uint32_t *)((char *)ctx->hist.p + 64);
-    uint32_t *ticket = (nblocks <= FUSED_SCAN_MAX_BLOCKS) ? (uint32_t *)((char *)ctx->hist.p + 32) : nullptr;
+    const int large = nblocks > FUSED_SCAN_MAX_BLOCKS;
     uint64_t *ka = keys_a, *kb = keys_b;
     const uint32_t B = ctx->cur_b;
     const size_t fs = ctx->fstride;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
         hipLaunchKernelGGL((radix_hist_kernel<uint64_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
-                           d_n, shift, hist, nblocks, ticket, fs);
-        if (!ticket)
+                           d_n, shift, hist, nblocks, !large, fs);
+        if (large)
             hipLaunchKernelGGL(hist_rows_kernel, dim3(RADIX, 1, B), dim3(SORT_THREADS), 0, ctx->stream, hist, nblocks, fs);
         hipLaunchKernelGGL((radix_scatter_kernel<uint64_t, false>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
                            ctx->stream, ka, kb, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, d_n, shift, hist,
-                           nblocks, ticket ? 0 : 1, fs);
+                           nblocks, large, fs);
         uint64_t *t = ka;
         ka = kb;
         kb = t;
