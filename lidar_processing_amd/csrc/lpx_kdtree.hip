@@ -2280,7 +2280,8 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(const FrameState *__res
         if (partner == CELL_NONE || dbg == 1)
             continue;
         // the far pass first skips what the touching pass already united
-        if (FAR && uf_find(tparent, s) == uf_find(tparent, partner))
+        // (grid_compress_kernel ran in between: one load per side answers it for all but the pairs of this pass)
+        if (FAR && (uf_ld(tparent + s) == uf_ld(tparent + partner) || uf_find(tparent, s) == uf_find(tparent, partner)))
             continue;
         // quick test: the point that claimed the cell against the one that claimed the partner
         const float4 ra = trep[s], rb = trep[partner];
@@ -2318,6 +2319,27 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(const FrameState *__res
         if (joined)
             uf_unite(tparent, s, partner);
     }
+}
+
+// between the two linking passes: every cell points straight at its root, so that the far pass recognises pairs of
+// one set with one load per side
+__global__ void grid_compress_kernel(const FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
+                                     uint32_t *tparent, size_t fs)
+{
+    frame = lpx_slot(frame, fs);
+    cells = lpx_slot(cells, fs);
+    tparent = lpx_slot(tparent, fs);
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= frame->n_cells)
+        return;
+    const uint32_t s = cells[c];
+    uint32_t x = s, p = uf_ld(tparent + x);
+    while (p != x)
+    {
+        x = p;
+        p = uf_ld(tparent + x);
+    }
+    uf_st(tparent + s, x);
 }
 
 // root[i] = a point of the root cell of point i's set (the same word for all its members), iota, state reset
@@ -2552,6 +2574,8 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
         ctx->cell_cap, gp_dbg, ctx->fstride
         static const int gp_dbg = getenv("LPX_GP_DBG") ? atoi(getenv("LPX_GP_DBG")) : 0;  // timing experiments only
         hipLaunchKernelGGL(grid_pairs_kernel<false>, dim3(pg0, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
+        hipLaunchKernelGGL(grid_compress_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, (const uint32_t *)cells,
+                           tparent, ctx->fstride);
         hipLaunchKernelGGL(grid_pairs_kernel<true>, dim3(pg1, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
 #undef GP_ARGS
     }
