@@ -1834,7 +1834,8 @@ constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B +
 __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__restrict__ PR,
                                                                const FrameState *__restrict__ frame, float rr,
                                                                ChunkRec *__restrict__ chunks,
-                                                               uint32_t *__restrict__ grp_of, FV fv)
+                                                               uint32_t *__restrict__ grp_of, uint32_t spine_max,
+                                                               FV fv)
 {
     __shared__ Item s_seq[NB_WAVES][2 * IX_CAPS];
     __shared__ uint32_t s_pre[NB_WAVES][IX_CAPS + 8];
@@ -1886,12 +1887,37 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
     }
     if (gb >= ge)
         return;
-    const uint32_t nq = __builtin_amdgcn_readfirstlane(gid < nbk ? (ge - gb) : 1u);
+    // A bucket also serves the upper nodes directly above it on its left spine (at most two: its parent when the
+    // bucket is a left child, and the grandparent when the parent is one too): in pre-order they are the ranks just
+    // before the bucket, and they lie on the boundary of its region, so the group's box barely grows -- while a group
+    // of their own would cost a whole traversal and a 2 KiB chunk table for ONE point each (they were 3/8 of all
+    // groups).  Upper nodes further up keep their single-node groups.
+    uint32_t spine = 0;
+    if (gid < nbk)
+    {
+        spine = path ? (uint32_t)__ffs(path) - 1u : D;
+        spine = spine < spine_max ? spine : spine_max;
+    }
+    else if (level + spine_max >= D)
+        return;  // served by the leftmost bucket below it
+    const uint32_t g0 = grank - spine;
+    const uint32_t nq = __builtin_amdgcn_readfirstlane(gid < nbk ? (ge - gb) + spine : 1u);  // <= 64 + 2
     const bool active = lane < nq;
-    const Node q = PR[grank + (active ? lane : 0u)];
+    const Node q = PR[g0 + (active ? lane : 0u)];
     if (active)
         grp_of[__float_as_uint(q.w)] = gid;
     float blo[3] = {q.x, q.y, q.z}, bhi[3] = {q.x, q.y, q.z};
+    if (nq > (uint32_t)WAVE)
+    {
+        const bool more = lane + WAVE < nq;
+        const Node q2 = PR[g0 + (more ? lane + WAVE : 0u)];
+        if (more)
+        {
+            grp_of[__float_as_uint(q2.w)] = gid;
+            blo[0] = fminf(blo[0], q2.x), blo[1] = fminf(blo[1], q2.y), blo[2] = fminf(blo[2], q2.z);
+            bhi[0] = fmaxf(bhi[0], q2.x), bhi[1] = fmaxf(bhi[1], q2.y), bhi[2] = fmaxf(bhi[2], q2.z);
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
     {
@@ -2532,9 +2558,10 @@ int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
     const uint32_t groups = (2u << dmax) - 1;
     if (sizeof(ChunkRec) * LPX_GROUP_CHUNKS * (size_t)groups > ctx->chunks.bytes)
         return lpx_fail(ctx, LPX_ERR_INTERNAL, "chunk table of %u groups does not fit the workspace", groups);
+    static const uint32_t ix_spine = getenv("LPX_IX_SPINE") ? (uint32_t)atoi(getenv("LPX_IX_SPINE")) : 2u;
     hipLaunchKernelGGL(nb_index_kernel, dim3((groups + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b), dim3(NB_THREADS), 0,
                        ctx->stream, (const Node *)ctx->nodes_pre.p, (const FrameState *)ctx->frame.p, rr,
-                       (ChunkRec *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, lpx_fv(ctx));
+                       (ChunkRec *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, ix_spine, lpx_fv(ctx));
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
