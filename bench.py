@@ -63,7 +63,7 @@ WORKLOADS = {
 STAGE_KERNEL = {"ingest": "ingest_kernel", "xsort": "radix_scatter_kernel<unsigned int, true>", "gather": "gather_kernel",
                 "zsort": "radix_scatter_kernel<unsigned long, false>", "seeds": "seed_select_kernel",
                 "plane_passes": "plane_single_kernel", "compact": "compact_kernel", "kd_build": "kd_block_kernel",
-                "cc_hook": "grid_link_kernel", "neighbours": "nb_index_kernel",
+                "cc_hook": "grid_pairs_kernel", "neighbours": "nb_index_kernel",
                 "components": "radix_scatter_kernel<unsigned int, true>", "replay": "replay_search_kernel",
                 "labels": "relabel_kernel"}
 STREAMING = ("ingest", "gather", "compact", "labels")  # stages whose kernels are plain coalesced streams
@@ -112,8 +112,9 @@ def pmc_traffic(stage, workload):
     path = os.path.join(ROOT, "profiles", f"r02_{workload}_pmc_fetch_write_per_kernel.json")
     try:
         d = json.load(open(path))
-        k = next(v for name, v in d.items() if name.startswith(STAGE_KERNEL[stage][:40]))
-        return int((2 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024)
+        # (template variants of one kernel: the one that moved the data)
+        return max(int((2 * v["FETCH_SIZE"]["avg"] + v["WRITE_SIZE"]["avg"]) * 1024)
+                   for name, v in d.items() if name.startswith(STAGE_KERNEL[stage][:40]))
     except Exception:
         return None
 
