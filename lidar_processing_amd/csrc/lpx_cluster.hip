@@ -502,7 +502,10 @@ constexpr int RS_THREADS = RS_WAVES * WAVE;
 #define LPX_RS_RING 256
 #endif
 constexpr int RS_RING = LPX_RS_RING;         // queue entries mirrored in LDS, per wavefront
-constexpr int RS_BATCH = 8;                  // candidate chunks in flight per wavefront
+#ifndef LPX_RS_BATCH
+#define LPX_RS_BATCH 8
+#endif
+constexpr int RS_BATCH = LPX_RS_BATCH;                  // candidate chunks in flight per wavefront
 
 struct RsShared  // fixed part of the LDS of replay_search_kernel (the bitmap follows)
 {
