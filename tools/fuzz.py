@@ -17,7 +17,24 @@ kitti = [load_frame(f) for f in FRAMES]
 
 
 def scene():
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 7)
+    if kind == 4:  # tiny clouds, fewer points than partitions included
+        n = int(rng.integers(0, 200))
+        c = np.zeros((n, 4), np.float32)
+        c[:, :3] = rng.normal(0.0, 2.0, (n, 3)).astype(np.float32)
+        c[:, 2] = c[:, 2] * 0.3 - 1.5
+        return c
+    if kind == 5:  # a frame slice with returns far outside the fixed-point range of the moments
+        f = kitti[rng.integers(0, len(kitti))]
+        c = f[: int(rng.integers(5_000, 60_000))].copy()
+        for _ in range(int(rng.integers(1, 6))):
+            c[rng.integers(0, c.shape[0]), rng.integers(0, 3)] = float(rng.choice([-1, 1])) * float(rng.uniform(2.1e3, 9.0e5))
+        return c
+    if kind == 6:  # heavy ties and exact duplicates: coordinates on a 0.1 m lattice
+        f = kitti[rng.integers(0, len(kitti))]
+        c = f[rng.random(f.shape[0]) < 0.3].copy()
+        c[:, :3] = np.round(c[:, :3] * 10.0) / 10.0
+        return c
     if kind == 0:
         n = int(rng.integers(2_000, 150_000))
         nb = int(rng.integers(1, 120))
