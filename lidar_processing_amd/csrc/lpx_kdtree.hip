@@ -494,6 +494,8 @@ constexpr int TOP_HAND = 4096;        // ranges at or below this are left to kd_
 constexpr uint32_t TOP_MIN = 131072;  // levels whose ranges can exceed this take the multi-workgroup rounds
 
 constexpr int BLK_G = 1024;
+constexpr int BLK_CAP_BATCH = 1984;  // batches: kd_lds_kernel needs 20 B x 1984 + 256 B = 39 936 B, four workgroups per CU
+                                     // (2032 nodes = 40 896 B measured as three per CU: 402 against 273 us per chain)
 constexpr int BLK_CAP_MAX = 4096;  // most nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch (blk_cap is a launch argument)
 constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
 
@@ -901,6 +903,7 @@ __device__ __forceinline__ uint32_t kd_rank_of(uint32_t p, uint32_t M)
 
 constexpr int LG = 256;  // threads of kd_lds_kernel: one wavefront per SIMD, little per-round overhead
 
+template <typename PosT>  // stop-list entries: uint16_t (batches: 20 B of LDS per node) or uint32_t (a single frame)
 __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restrict__ PR,
                                                     const FrameState *__restrict__ frame,
                                                     uint32_t *__restrict__ dbg, int BLK_CAP, size_t fs)
@@ -912,9 +915,11 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
     uint32_t n_rounds = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Node *l_nodes = (Node *)smem;
-    uint32_t *l_lp = (uint32_t *)(smem + sizeof(Node) * BLK_CAP);
-    uint32_t *l_ra = l_lp + BLK_CAP;
-    uint32_t *cs = l_ra + BLK_CAP;
+    // stop lists as positions inside the staged range (< 4096); 16-bit entries make it 20 bytes of LDS per node, so
+    // that four workgroups of a batch share a CU
+    PosT *l_lp = (PosT *)(smem + sizeof(Node) * BLK_CAP);
+    PosT *l_ra = l_lp + BLK_CAP;
+    uint32_t *cs = (uint32_t *)(l_ra + BLK_CAP);
     const int tid = threadIdx.x;
     const int M = (int)frame->n_obstacle;
     int lv = 0;
@@ -951,8 +956,8 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
         l_nodes[i] = nodes[b + i];
     View v;
     v.a = l_nodes;
-    v.lp = l_lp;
-    v.ra = l_ra;
+    v.lp = nullptr;  // (the sequential helpers only touch the nodes)
+    v.ra = nullptr;
     v.off = b;
     __syncthreads();
 
@@ -1031,14 +1036,14 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
                 {
                     const int q = __ffs(m) - 1;
                     m &= m - 1;
-                    v.lp[rL++] = (uint32_t)(p0 + q);
+                    l_lp[rL++] = (PosT)(p0 + q - v.off);
                 }
                 m = lem;
                 while (m)
                 {
                     const int q = __ffs(m) - 1;
                     m &= m - 1;
-                    v.ra[rR++] = (uint32_t)(p0 + q);
+                    l_ra[rR++] = (PosT)(p0 + q - v.off);
                 }
             }
             if (blockmode)
@@ -1056,8 +1061,8 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
                 {
                     const int k = k0 + q * gs;
                     const bool in = k < kmax;
-                    sl[q] = in ? (int)v.lp[first + k - v.off] : 0;
-                    sr[q] = in ? (int)v.ra[first + cntR - 1 - k - v.off] : -1;
+                    sl[q] = in ? (int)l_lp[first + k - v.off] + v.off : 0;
+                    sr[q] = in ? (int)l_ra[first + cntR - 1 - k - v.off] + v.off : -1;
                 }
                 Node nl[4], nr[4];
 #pragma unroll
@@ -1081,8 +1086,8 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
             if (part)
             {
                 const int K = (int)ktot;
-                const int c1 = (K < cntL) ? (int)v.lp[first + K - v.off] : INT_MAX;
-                const int c2 = (K > 0) ? (int)v.ra[first + cntR - K - v.off] : INT_MAX;
+                const int c1 = (K < cntL) ? (int)l_lp[first + K - v.off] + v.off : INT_MAX;
+                const int c2 = (K > 0) ? (int)l_ra[first + cntR - K - v.off] + v.off : INT_MAX;
                 const int cut = min(c1, c2);
                 if (cut <= nth)
                     first = cut;
@@ -2434,16 +2439,19 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     // the node array {x, y, z, index} was written by the producer of the obstacle cloud (compact / ingest)
     // A single frame stages up to 4096 nodes per workgroup (96 KiB of LDS: fewest global-memory rounds, best
     // latency).  A batch shares the device with the small-LDS workgroups of other chains' neighbour kernels,
-    // next to which a 96 KiB workgroup rarely finds room; half the capacity (48 KiB) schedules freely.
-    const int blk_cap = ctx->cur_b > 1 ? BLK_CAP_MAX / 2 : BLK_CAP_MAX;
+    // next to which a 96 KiB workgroup rarely finds room; half the capacity schedules freely.
+    const int blk_cap = ctx->cur_b > 1 ? BLK_CAP_BATCH : BLK_CAP_MAX;
     const size_t blk_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint32_t) * blk_cap + 64 * sizeof(uint32_t);
+    const size_t lds_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint16_t) * blk_cap + 64 * sizeof(uint32_t);  // batches
     if (!ctx->attr_kd)
     {
         const size_t max_lds = sizeof(Node) * BLK_CAP_MAX + 2 * sizeof(uint32_t) * BLK_CAP_MAX + 64 * sizeof(uint32_t);
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)max_lds));
-        LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)max_lds));
+        LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel<uint32_t>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+        LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel<uint16_t>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
         ctx->attr_kd = true;
     }
     // global-memory levels while a range can exceed the LDS capacity, then the whole rest in one launch
@@ -2494,8 +2502,12 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
-    hipLaunchKernelGGL(kd_lds_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(LG), blk_lds, ctx->stream, nodes,
-                       (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fstride);
+    if (ctx->cur_b > 1)
+        hipLaunchKernelGGL(kd_lds_kernel<uint16_t>, dim3(1u << level, 1, ctx->cur_b), dim3(LG), lds_lds, ctx->stream, nodes,
+                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fstride);
+    else
+        hipLaunchKernelGGL(kd_lds_kernel<uint32_t>, dim3(1u << level, 1, ctx->cur_b), dim3(LG), blk_lds, ctx->stream, nodes,
+                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fstride);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
