@@ -20,7 +20,7 @@ for k,v in d.items():
 for s,k,n in sorted(rows,reverse=True)[:24]:
     v=d[k]
     extra=""
-    if k in ("grid_link_kernel","replay_search_kernel<true>"):
+    if k in ("replay_search_kernel<true>",):
         ev=[x[1] for x in v[0::2]]; od=[x[1] for x in v[1::2]]
         extra=" even %.1f odd %.1f"%(sum(ev)/len(ev)/1e3,sum(od)/max(1,len(od))/1e3)
     print("%-44s n %5d avg_us %9.1f total_ms %8.2f%s"%(k[:44],n,s/n/1e3,s/1e6,extra))
