@@ -439,6 +439,14 @@ def main():
                                                      outs[3].array.ctypes.data, Cc.byref(nc)))
 
             pin_ms = med(pinned_call)
+
+            # what the UNCHANGED processor node does per message (src/processor.cpp:150 and :178): segment() on the host
+            # cloud, the obstacle cloud copied out on the host, then cluster() on that cloud -- two blocking calls
+            def two_calls():
+                _, _, oi, _ = one.segment(pageable, scfg)
+                one.cluster(pageable[oi], ccfg)
+
+            two_ms = med(two_calls)
             one.set_neighbour_mode("search")
             dev_search_ms = med(dev_call)
             one.close()
@@ -446,6 +454,9 @@ def main():
                        "device_resident_ms": round(dev_ms, 4), "device_resident_mpts_s": round(n0 / dev_ms / 1e3, 2),
                        "host_api_pageable_ms": round(host_ms, 4), "host_api_pinned_ms": round(pin_ms, 4),
                        "host_api_pinned_mpts_s": round(n0 / pin_ms / 1e3, 2),
+                       "dropin_segment_then_cluster_ms": round(two_ms, 4),
+                       "dropin_what": "lpx_segment, host copy of the obstacle cloud, lpx_cluster: the two blocking calls of "
+                                      "the unchanged processor node (pageable memory)",
                        "device_resident_ms_search_mode": round(dev_search_ms, 4),
                        "note": "single-frame contexts default to LPX_NEIGHBOURS_LISTS (shortest critical path); the "
                                "throughput figure uses LPX_NEIGHBOURS_SEARCH"}
