@@ -480,7 +480,7 @@ def main():
                 tf = (time.perf_counter() - a) / passes
                 # all contexts of the bench, one pipeline each (lpx_feeder_run_multi), the same frame list
                 ids3 = ids
-                lanes = ctxs[:5]  # PCIe is the limit from about five pipelines on; more only shorten each lane's queue
+                lanes = ctxs
                 out3 = feeder.run(lanes, ids3, scfg, ccfg)
                 a = time.perf_counter()
                 for _ in range(passes):
@@ -496,7 +496,7 @@ def main():
                                           "two buffer sets (PCIe-inclusive; never the headline value)",
                            "feeder_multi_frames_per_s": round(len(ids3) / tm, 1),
                            "feeder_multi_mpts_s": round(points_per_step / tm / 1e6, 2),
-                           "feeder_multi_what": f"lpx_feeder_run_multi on {min(5, len(ctxs))} contexts of this run (one "
+                           "feeder_multi_what": f"lpx_feeder_run_multi on the {len(ctxs)} contexts of this run (one "
                                                 "pipeline and host thread per context), the same frames"}
 
     if rank == 0:

@@ -2,6 +2,7 @@
 #include "lpx_internal.h"
 
 #include <atomic>
+#include <time.h>
 #include "lpx_debug.h"
 
 #include <stdarg.h>
@@ -190,6 +191,7 @@ static int ensure_for(lpx_ctx *ctx, uint32_t n)
     if (nb > 0xfffffff0ull)
         nb = 0xfffffff0ull;  // offsets are 32-bit
     const int rc = lpx_ensure_capacity(ctx, n, nb);
+    lpx_note_enqueue(ctx);  // a new frame (or chain of frames) is being enqueued on this context
     // LPX_POISON=<byte>: before every new frame the per-point workspace (everything a call must write before it
     // reads) and the neighbour lists are filled with that byte -- a test that passes with 0, 0xff and 0xa5 does not
     // depend on what an earlier frame left behind
@@ -292,13 +294,60 @@ extern "C" int lpx_profile_read(lpx_ctx *ctx, float *ms, uint32_t *launches, int
 // ------------------------------------------------------------------------------------------------
 // lifetime
 // ------------------------------------------------------------------------------------------------
-// frame slots of the live contexts of a device: how many frames this process can have in flight there (the
-// replay sizes its resident footprint by it, lpx_cluster.hip)
-static std::atomic<uint32_t> g_live_slots[LPX_MAX_DEVICES];
-
-uint32_t lpx_live_frame_slots(int device)
+// Frames in flight on a device, as far as this process can tell: the frame slots of the contexts that enqueued a
+// frame within the last 100 ms (the replay sizes its resident footprint by it, lpx_cluster.hip).  A small registry
+// of (device, slots, time of the last enqueue); contexts that sit idle do not count.
+namespace
 {
-    return g_live_slots[(unsigned)device % LPX_MAX_DEVICES].load(std::memory_order_relaxed);
+constexpr int REG_MAX = 1024;
+struct RegEntry
+{
+    std::atomic<int> device{-1};  // -1: free
+    std::atomic<uint32_t> slots{0};
+    std::atomic<long long> last_ns{0};
+};
+RegEntry g_reg[REG_MAX];
+
+long long now_ns()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+}  // namespace
+
+static int reg_claim(int device, uint32_t slots)
+{
+    for (int i = 0; i < REG_MAX; ++i)
+    {
+        int expected = -1;
+        if (g_reg[i].device.compare_exchange_strong(expected, device))
+        {
+            g_reg[i].slots = slots;
+            g_reg[i].last_ns = 0;
+            return i;
+        }
+    }
+    return -1;  // more than REG_MAX live contexts: this one is not counted
+}
+
+void lpx_note_enqueue(lpx_ctx *ctx)
+{
+    if (ctx->reg_index >= 0)
+        g_reg[ctx->reg_index].last_ns.store(now_ns(), std::memory_order_relaxed);
+}
+
+uint32_t lpx_active_frame_slots(int device)
+{
+    const long long t = now_ns();
+    uint32_t sum = 0;
+    for (int i = 0; i < REG_MAX; ++i)
+    {
+        const int d = g_reg[i].device.load(std::memory_order_relaxed);
+        if (d == device && t - g_reg[i].last_ns.load(std::memory_order_relaxed) < 100000000ll)
+            sum += g_reg[i].slots.load(std::memory_order_relaxed);
+    }
+    return sum;
 }
 
 static int create_common(int device, hipStream_t stream, bool own, uint32_t batch, lpx_ctx **out)
@@ -334,8 +383,7 @@ static int create_common(int device, hipStream_t stream, bool own, uint32_t batc
     else
         ctx->stream = stream;
     ctx->batch = batch;
-    g_live_slots[(unsigned)device % LPX_MAX_DEVICES] += batch;
-    ctx->counted = true;
+    ctx->reg_index = reg_claim(device, batch);
     ctx->use_lists = batch == 1;  // LPX_NEIGHBOURS_AUTO
     int rc;
     if ((rc = lpx_ensure_capacity(ctx, 1024, 1024)))
@@ -386,8 +434,8 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
     free(ctx->pending);
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
-    if (ctx->counted)
-        g_live_slots[(unsigned)ctx->device % LPX_MAX_DEVICES] -= ctx->batch;
+    if (ctx->reg_index >= 0)
+        g_reg[ctx->reg_index].device.store(-1);
     delete ctx;
 }
 

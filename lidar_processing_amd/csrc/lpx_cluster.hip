@@ -1158,10 +1158,10 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // frame), so what counts is how many replay workgroups are resident on the DEVICE, over all chains in
         // flight: about 1024 is the measured optimum (kitti, 16 contexts x 32 frames: 2 per frame 1413 Mpts/s,
         // 8 per frame 1338, 16 per frame 1317; stream, 5 x 32: 8 per frame; synth1m, 4 x 4: 32-64 per frame).
-        // The frame slots of the live contexts of this device stand for "frames in flight".  LPX_RS_GRID overrides
-        // the per-frame count.
+        // The frame slots of the contexts of this device that enqueued a frame in the last 100 ms stand for "frames in
+        // flight".  LPX_RS_GRID overrides the per-frame count.
         static const uint32_t rg_env = getenv("LPX_RS_GRID") ? (uint32_t)atoi(getenv("LPX_RS_GRID")) : 0u;
-        uint32_t slots = lpx_live_frame_slots(ctx->device);
+        uint32_t slots = lpx_active_frame_slots(ctx->device);
         slots = slots < ctx->cur_b ? ctx->cur_b : slots;
         uint32_t rg_cap = rg_env ? rg_env : 1024u / slots;
         rg_cap = rg_cap < 1u ? 1u : (rg_cap > 64u && !rg_env ? 64u : rg_cap);

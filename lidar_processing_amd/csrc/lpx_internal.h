@@ -146,7 +146,7 @@ struct lpx_ctx
     Buf nodes;                 // float4 kd nodes, array (in-order) layout
     Buf nodes_pre;             // the same nodes in pre-order rank layout
     Buf lpos, rpos;            // partition scratch
-    bool counted = false;      // this context's frame slots are in the per-device count (lpx_live_frame_slots)
+    int reg_index = -1;        // entry of this context in the registry behind lpx_active_frame_slots
     Buf kd_state;              // introselect state of the ranges of a top kd level (multi-workgroup rounds)
     Buf nb_len, nb_off;        // u32 len, u32 off (cap_n + 1)
     Buf nb_idx;                // cap_nb words: neighbour index | (within the absorb radius) << 31
@@ -272,8 +272,8 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max);
 // word; hook: also build the connected components
 int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hook);
 // expansion-driven path: candidate chunks per kd group + the point -> group map; components from a uniform grid
-constexpr int LPX_MAX_DEVICES = 64;
-uint32_t lpx_live_frame_slots(int device);  // frame slots of all live contexts of the device (this process)
+uint32_t lpx_active_frame_slots(int device);  // frame slots of the contexts of the device that enqueued work lately
+void lpx_note_enqueue(lpx_ctx *ctx);
 int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2);
 int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota);
 // the neighbour-list workspace is only allocated for the list path
