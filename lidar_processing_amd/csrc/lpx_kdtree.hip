@@ -2185,7 +2185,11 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
     uint32_t h = cell_hash(key) & mask;
     for (;;)
     {
-        const unsigned long long old = atomicCAS(tkey + h, CELL_EMPTY, key);
+        // look before the compare-and-swap: all but the first points of a cell find its key with a plain (L2) load,
+        // and atomics on one address serialise -- a dense cell near the sensor holds hundreds of points
+        unsigned long long old = __hip_atomic_load(tkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == CELL_EMPTY)
+            old = atomicCAS(tkey + h, CELL_EMPTY, key);
         if (old == CELL_EMPTY)
         {
             cells[atomicAdd(&frame->n_cells, 1u)] = h;  // this point claimed the cell: list it ...
