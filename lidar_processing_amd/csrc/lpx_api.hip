@@ -1087,13 +1087,15 @@ extern "C" int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *o
     out12[1] = fs.n_obstacle;
     out12[2] = fs.n_clusters;
     out12[3] = fs.status;
-    out12[4] = (uint32_t)fs.nb_entries;
-    out12[5] = (uint32_t)(fs.nb_entries >> 32);
+    out12[4] = (uint32_t)lpx_entries_written(fs);
+    out12[5] = (uint32_t)(lpx_entries_written(fs) >> 32);
     out12[6] = fs.n_roots;
     out12[7] = fs.n_expansions;
     out12[8] = (uint32_t)fs.replay_entries;
     out12[9] = (uint32_t)(fs.replay_entries >> 32);
-    const uint64_t words = fs.nb_total + (fs.rs_total < ctx->cap_rs ? fs.rs_total : ctx->cap_rs);
+    uint64_t words = fs.nb_total;
+    for (uint32_t i = 0; i < LPX_RS_STRIPES; ++i)
+        words += fs.rs_stripe[i] < ctx->cap_rs / LPX_RS_STRIPES ? fs.rs_stripe[i] : ctx->cap_rs / LPX_RS_STRIPES;
     out12[10] = (uint32_t)words;
     out12[11] = (uint32_t)(words >> 32);
     return LPX_OK;
@@ -1260,7 +1262,10 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     // device lists are grouped by kd bucket and hold index | absorb << 31; hand them back as a CSR ordered by
     // point index with the distance KDTree::radius_search reports (src/kdtree.hpp:145-157, :315)
     uint32_t *off32 = (uint32_t *)malloc(4 * (size_t)m), *len32 = (uint32_t *)malloc(4 * (size_t)m);
-    const uint64_t span = fs.rs_total ? ctx->cap_nb + (fs.rs_total < ctx->cap_rs ? fs.rs_total : ctx->cap_rs) : fs.nb_total;
+    bool reserved = false;  // single-pass lists lie anywhere in the striped region behind the exact one
+    for (uint32_t i = 0; i < LPX_RS_STRIPES; ++i)
+        reserved = reserved || fs.rs_stripe[i] != 0;
+    const uint64_t span = reserved ? ctx->cap_nb + ctx->cap_rs : fs.nb_total;
     uint32_t *didx = (uint32_t *)malloc(4 * (size_t)span + 4);
     LPX_HIP(ctx, hipMemcpyAsync(off32, ctx->nb_off.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipMemcpyAsync(len32, ctx->nb_len.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
@@ -1275,9 +1280,9 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     }
     offsets[m] = run;
     rc = LPX_OK;
-    if (run != fs.nb_entries || run > span)
+    if (run != lpx_entries_written(fs) || run > span)
         rc = lpx_fail(ctx, LPX_ERR_INTERNAL, "list lengths sum to %llu, %llu written, %llu words in use",
-                      (unsigned long long)run, (unsigned long long)fs.nb_entries, (unsigned long long)span);
+                      (unsigned long long)run, (unsigned long long)lpx_entries_written(fs), (unsigned long long)span);
     else if (run > capacity)
         rc = lpx_fail(ctx, LPX_ERR_CAPACITY, "caller buffers hold %llu entries, %llu needed",
                       (unsigned long long)capacity, (unsigned long long)run);

@@ -32,6 +32,7 @@ enum lpx_stage
 // ------------------------------------------------------------------------------------------------
 // device-side frame state (one per context, lives in HBM)
 // ------------------------------------------------------------------------------------------------
+#define LPX_RS_STRIPES 16u
 struct FrameState
 {
     uint32_t n_ground;
@@ -53,7 +54,19 @@ struct FrameState
     uint32_t cell_cursor;     // points handed out to the cells' contiguous runs
     uint32_t n_windows;       // queue windows with at least one expansion (expansion-driven path)
     uint32_t n_overflow;      // searches redone by the sequencer because the list did not fit its LDS region
+    // The single-pass region of the list workspace is handed out from LPX_RS_STRIPES sub-regions with a cursor each
+    // (group g bumps cursor g % LPX_RS_STRIPES): thousands of bumps of ONE word per frame serialise at L2.
+    uint64_t rs_stripe[16];
+    uint64_t ent_stripe[16];  // neighbour entries written, likewise striped (nb_entries = their sum)
 };
+
+static inline uint64_t lpx_entries_written(const FrameState &f)
+{
+    uint64_t s = f.nb_entries;
+    for (int i = 0; i < 16; ++i)
+        s += f.ent_stripe[i];
+    return s;
+}
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
 #define LPX_FAR_WORDS 24  // moments of the points beyond +-2048 m: n, sx, sy, sz, 6 x (hh, hl, ll) limbs, 2 spare

@@ -1476,7 +1476,8 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
         PH_COUNT,
         PH_FILL
     };
-    int phase = (frame->rs_total < cap_rs) ? PH_RESERVE : PH_COUNT;  // region exhausted: do not even try
+    int phase = (frame->rs_stripe[gid % LPX_RS_STRIPES] < cap_rs / LPX_RS_STRIPES) ? PH_RESERVE : PH_COUNT;  // sub-region
+                                                                                               // exhausted: do not try
     bool staged_once = false;
     for (;;)
     {
@@ -1636,7 +1637,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
             }
             const uint32_t wrote = lpx_wave_sum_u32(mine ? my_len : 0u);
             if (lane == 0 && wrote)
-                atomicAdd((unsigned long long *)&frame->nb_entries, (unsigned long long)wrote);
+                atomicAdd((unsigned long long *)&frame->ent_stripe[gid % LPX_RS_STRIPES], (unsigned long long)wrote);
             break;
         }
         // allocate the group's list storage: one 64-bit atomic bump of frame->nb_total per group
@@ -1653,13 +1654,16 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                 const uint32_t incl = lpx_wave_incl_scan_u32(c);
                 const uint32_t total = __shfl(incl, WAVE - 1, 64);
                 unsigned long long base = 0;
-                unsigned long long *counter = (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_total : &frame->nb_total);
+                const uint32_t stripe = gid % LPX_RS_STRIPES;
+                const unsigned long long stripe_cap = cap_rs / LPX_RS_STRIPES;
+                unsigned long long *counter =
+                    (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_stripe[stripe] : &frame->nb_total);
                 if (lane == 0)
                     base = atomicAdd(counter, (unsigned long long)total);
                 base = __shfl(base, 0, 64);
-                const bool fits = base + total <= (phase == PH_RESERVE ? cap_rs : cap);
+                const bool fits = base + total <= (phase == PH_RESERVE ? stripe_cap : cap);
                 if (phase == PH_RESERVE)
-                    base += cap;  // the single-pass region lies behind the exact one
+                    base += cap + stripe * stripe_cap;  // the single-pass region lies behind the exact one
                 if (fits && active)
                 {
                     const uint32_t o = (uint32_t)base + incl - c;
@@ -1689,13 +1693,16 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
         {
             const uint32_t total = __builtin_amdgcn_readlane((int)my_cnt, 0);
             unsigned long long base = 0;
-            unsigned long long *counter = (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_total : &frame->nb_total);
+            const uint32_t stripe = gid % LPX_RS_STRIPES;
+            const unsigned long long stripe_cap = cap_rs / LPX_RS_STRIPES;
+            unsigned long long *counter =
+                (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_stripe[stripe] : &frame->nb_total);
             if (lane == 0)
                 base = atomicAdd(counter, (unsigned long long)total);
             base = __shfl(base, 0, 64);
-            ok = base + total <= (phase == PH_RESERVE ? cap_rs : cap);
+            ok = base + total <= (phase == PH_RESERVE ? stripe_cap : cap);
             if (phase == PH_RESERVE)
-                base += cap;
+                base += cap + stripe * stripe_cap;
             if (ok)
             {
                 my_cursor = (uint32_t)base;

@@ -78,6 +78,11 @@ __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacl
         f.n_overflow = 0;
         f.nb_entries = 0;
         f.rs_total = 0;
+        for (int i = 0; i < (int)LPX_RS_STRIPES; ++i)
+        {
+            f.rs_stripe[i] = 0;
+            f.ent_stripe[i] = 0;
+        }
         *frame = f;
     }
 }
