@@ -657,15 +657,12 @@ static int upload(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n)
 static int reset_neighbour_state(lpx_ctx *ctx)
 {
     char *f = (char *)ctx->frame.p;
-    const size_t lo = offsetof(FrameState, status), nin = offsetof(FrameState, n_in);
-    const size_t nbe = offsetof(FrameState, nb_entries), hi = sizeof(FrameState);
+    const size_t st = offsetof(FrameState, status), cnt = offsetof(FrameState, nb_total);
     static_assert(offsetof(FrameState, nb_total) > offsetof(FrameState, status) &&
-                      offsetof(FrameState, n_obstacle) < offsetof(FrameState, status) &&
-                      offsetof(FrameState, nb_entries) > offsetof(FrameState, has_far),
-                  "FrameState layout");
-    // n_in and has_far sit between the counters: clear around them
-    LPX_HIP(ctx, hipMemsetAsync(f + lo, 0, nin - lo, ctx->stream));
-    LPX_HIP(ctx, hipMemsetAsync(f + nbe, 0, hi - nbe, ctx->stream));
+                      offsetof(FrameState, n_in) < offsetof(FrameState, status),
+                  "FrameState layout: sizes, then status, then the counters");
+    LPX_HIP(ctx, hipMemsetAsync(f + st, 0, sizeof(uint32_t), ctx->stream));
+    LPX_HIP(ctx, hipMemsetAsync(f + cnt, 0, sizeof(FrameState) - cnt, ctx->stream));
     return LPX_OK;
 }
 
@@ -1095,7 +1092,7 @@ extern "C" int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *o
     out12[9] = (uint32_t)(fs.replay_entries >> 32);
     uint64_t words = fs.nb_total;
     for (uint32_t i = 0; i < LPX_RS_STRIPES; ++i)
-        words += fs.rs_stripe[i] < ctx->cap_rs / LPX_RS_STRIPES ? fs.rs_stripe[i] : ctx->cap_rs / LPX_RS_STRIPES;
+        words += fs.rs_stripe[i].v < ctx->cap_rs / LPX_RS_STRIPES ? fs.rs_stripe[i].v : ctx->cap_rs / LPX_RS_STRIPES;
     out12[10] = (uint32_t)words;
     out12[11] = (uint32_t)(words >> 32);
     return LPX_OK;
@@ -1264,7 +1261,7 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
     uint32_t *off32 = (uint32_t *)malloc(4 * (size_t)m), *len32 = (uint32_t *)malloc(4 * (size_t)m);
     bool reserved = false;  // single-pass lists lie anywhere in the striped region behind the exact one
     for (uint32_t i = 0; i < LPX_RS_STRIPES; ++i)
-        reserved = reserved || fs.rs_stripe[i] != 0;
+        reserved = reserved || fs.rs_stripe[i].v != 0;
     const uint64_t span = reserved ? ctx->cap_nb + ctx->cap_rs : fs.nb_total;
     uint32_t *didx = (uint32_t *)malloc(4 * (size_t)span + 4);
     LPX_HIP(ctx, hipMemcpyAsync(off32, ctx->nb_off.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));

@@ -33,38 +33,45 @@ enum lpx_stage
 // device-side frame state (one per context, lives in HBM)
 // ------------------------------------------------------------------------------------------------
 #define LPX_RS_STRIPES 16u
-struct FrameState
+// Every word that kernels bump atomically sits on a 128-byte line of its own: atomics serialise per line at L2, and
+// the sizes in the first line are read by every workgroup of every kernel -- they must not queue behind the bumps of
+// a counter that happens to share their line.
+struct alignas(128) FrameStripe
 {
+    uint64_t v;
+};
+struct alignas(128) FrameState
+{
+    // line 0: sizes and status, written a handful of times per frame
     uint32_t n_ground;
     uint32_t n_obstacle;  // M: number of points handed to clustering
     uint32_t n_clusters;
+    uint32_t n_in;        // points of the input cloud of this frame slot
+    uint32_t has_far;     // some coordinate has |v| >= 2048 m: the plane kernels take the wide-moment path for it
     uint32_t status;      // 0 ok, else -LPX_ERR_*
-    uint64_t nb_total;    // words of exact-length list storage required (workspace region [0, cap_nb))
-    uint32_t n_roots;     // connected components of the d-graph
-    uint32_t root_cursor; // work queue head of the replay
-    uint64_t replay_entries;  // neighbour entries read by the replay (lists of expanded points)
-    uint32_t n_expansions;    // radius_search calls the reference would have made
-    uint32_t n_in;            // points of the input cloud of this frame slot
-    uint32_t has_far;         // some coordinate has |v| >= 2048 m: the plane kernels take the wide-moment path for it
-    uint32_t pad0;
-    uint64_t nb_entries;      // neighbour entries written (sum of the list lengths)
-    uint64_t rs_total;        // words asked from the single-pass region [cap_nb, cap_nb + cap_rs)
+    alignas(128) uint64_t nb_total;     // words of exact-length list storage required (workspace region [0, cap_nb))
+    alignas(128) uint32_t n_roots;      // connected components of the d-graph
+    alignas(128) uint32_t root_cursor;  // work queue head of the replay
+    alignas(128) uint32_t n_cells;      // occupied cells of the component grid
+    alignas(128) uint32_t cell_cursor;  // points handed out to the cells' contiguous runs
+    // statistics (a few bumps per wavefront at the end of a kernel)
+    alignas(128) uint64_t replay_entries;  // neighbour entries read by the replay (lists of expanded points)
+    uint64_t nb_entries;                   // (unstriped remainder of the entries written, see ent_stripe)
     uint64_t cand_total;      // candidates distance-tested by the replay's searches (expansion-driven path)
-    uint32_t n_cells;         // occupied cells of the component grid
-    uint32_t cell_cursor;     // points handed out to the cells' contiguous runs
+    uint32_t n_expansions;    // radius_search calls the reference would have made
     uint32_t n_windows;       // queue windows with at least one expansion (expansion-driven path)
     uint32_t n_overflow;      // searches redone by the sequencer because the list did not fit its LDS region
     // The single-pass region of the list workspace is handed out from LPX_RS_STRIPES sub-regions with a cursor each
     // (group g bumps cursor g % LPX_RS_STRIPES): thousands of bumps of ONE word per frame serialise at L2.
-    uint64_t rs_stripe[16];
-    uint64_t ent_stripe[16];  // neighbour entries written, likewise striped (nb_entries = their sum)
+    FrameStripe rs_stripe[LPX_RS_STRIPES];
+    FrameStripe ent_stripe[LPX_RS_STRIPES];  // neighbour entries written, likewise striped
 };
 
 static inline uint64_t lpx_entries_written(const FrameState &f)
 {
     uint64_t s = f.nb_entries;
     for (int i = 0; i < 16; ++i)
-        s += f.ent_stripe[i];
+        s += f.ent_stripe[i].v;
     return s;
 }
 

@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
         PH_COUNT,
         PH_FILL
     };
-    int phase = (frame->rs_stripe[gid % LPX_RS_STRIPES] < cap_rs / LPX_RS_STRIPES) ? PH_RESERVE : PH_COUNT;  // sub-region
+    int phase = (frame->rs_stripe[gid % LPX_RS_STRIPES].v < cap_rs / LPX_RS_STRIPES) ? PH_RESERVE : PH_COUNT;  // sub-region
                                                                                                // exhausted: do not try
     bool staged_once = false;
     for (;;)
@@ -1637,7 +1637,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
             }
             const uint32_t wrote = lpx_wave_sum_u32(mine ? my_len : 0u);
             if (lane == 0 && wrote)
-                atomicAdd((unsigned long long *)&frame->ent_stripe[gid % LPX_RS_STRIPES], (unsigned long long)wrote);
+                atomicAdd((unsigned long long *)&frame->ent_stripe[gid % LPX_RS_STRIPES].v, (unsigned long long)wrote);
             break;
         }
         // allocate the group's list storage: one 64-bit atomic bump of frame->nb_total per group
@@ -1657,7 +1657,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                 const uint32_t stripe = gid % LPX_RS_STRIPES;
                 const unsigned long long stripe_cap = cap_rs / LPX_RS_STRIPES;
                 unsigned long long *counter =
-                    (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_stripe[stripe] : &frame->nb_total);
+                    (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_stripe[stripe].v : &frame->nb_total);
                 if (lane == 0)
                     base = atomicAdd(counter, (unsigned long long)total);
                 base = __shfl(base, 0, 64);
@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
             const uint32_t stripe = gid % LPX_RS_STRIPES;
             const unsigned long long stripe_cap = cap_rs / LPX_RS_STRIPES;
             unsigned long long *counter =
-                (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_stripe[stripe] : &frame->nb_total);
+                (unsigned long long *)(phase == PH_RESERVE ? &frame->rs_stripe[stripe].v : &frame->nb_total);
             if (lane == 0)
                 base = atomicAdd(counter, (unsigned long long)total);
             base = __shfl(base, 0, 64);

@@ -56,34 +56,14 @@ __device__ __forceinline__ void seg_bind(SegParams &prm, const FrameState *frame
 __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacles, size_t fs)
 {
     frame = lpx_slot(frame, fs);
+    uint32_t *w = (uint32_t *)frame;
+    for (uint32_t i = threadIdx.x; i < sizeof(FrameState) / sizeof(uint32_t); i += blockDim.x)
+        w[i] = 0;
+    __syncthreads();
     if (threadIdx.x == 0)
     {
-        FrameState f;
-        f.n_ground = 0;
-        f.n_obstacle = as_obstacles ? n.v[blockIdx.z] : 0u;
-        f.n_clusters = 0;
-        f.status = 0;
-        f.nb_total = 0;
-        f.n_roots = 0;
-        f.root_cursor = 0;
-        f.replay_entries = 0;
-        f.n_expansions = 0;
-        f.n_in = n.v[blockIdx.z];
-        f.has_far = 0;
-        f.pad0 = 0;
-        f.cand_total = 0;
-        f.n_cells = 0;
-        f.cell_cursor = 0;
-        f.n_windows = 0;
-        f.n_overflow = 0;
-        f.nb_entries = 0;
-        f.rs_total = 0;
-        for (int i = 0; i < (int)LPX_RS_STRIPES; ++i)
-        {
-            f.rs_stripe[i] = 0;
-            f.ent_stripe[i] = 0;
-        }
-        *frame = f;
+        frame->n_obstacle = as_obstacles ? n.v[blockIdx.z] : 0u;
+        frame->n_in = n.v[blockIdx.z];
     }
 }
 
