@@ -73,7 +73,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         const size_t blk_bytes = sizeof(uint32_t) * (2 * ((size_t)n / 4096 + LPX_MAX_PARTITIONS + 2) + 2);
         // expansion-driven search: at most n / 16 + 2 kd groups (2^(D+1) with n >> D <= 64), a cell table of the
         // next power of two >= 2 n slots
-        const size_t chunk_bytes = sizeof(ChunkRec) * LPX_GROUP_CHUNKS * ((size_t)n / 16 + 64);
+        const size_t chunk_bytes = sizeof(ChunkRec) * LPX_GROUP_CHUNKS * ((size_t)n / 8 + 64);  // groups of >= 32 nodes: fewer than n / 8
         uint32_t cell_cap = 64;
         while ((size_t)cell_cap < 2 * (size_t)n)
             cell_cap <<= 1;
@@ -383,6 +383,10 @@ static int create_common(int device, hipStream_t stream, bool own, uint32_t batc
     else
         ctx->stream = stream;
     ctx->batch = batch;
+    if (hipHostMalloc((void **)&ctx->h_search, 4 * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess)
+        memset(ctx->h_search, 0, 4 * sizeof(uint64_t));
+    else
+        ctx->h_search = nullptr;
     ctx->reg_index = reg_claim(device, batch);
     ctx->use_lists = batch == 1;  // LPX_NEIGHBOURS_AUTO
     int rc;
@@ -434,6 +438,8 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
     free(ctx->pending);
     if (ctx->own_stream)
         hipStreamDestroy(ctx->stream);
+    if (ctx->h_search)
+        hipHostFree(ctx->h_search);
     if (ctx->reg_index >= 0)
         g_reg[ctx->reg_index].device.store(-1);
     delete ctx;

@@ -1186,6 +1186,10 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
             hipLaunchKernelGGL(replay_search_kernel<false>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS), fixed, st,
                                RS_ARGS(m_lds, m_max));
 #undef RS_ARGS
+        // what the searches of this call cost per hit, for the group size of the next call (read when it is there)
+        if (ctx->h_search)
+            LPX_HIP(ctx, hipMemcpyAsync(ctx->h_search, (const char *)frame + offsetof(FrameState, replay_entries),
+                                        4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     }
     else if (ctx->use_lists)
     {

@@ -110,6 +110,7 @@ struct Buf
 // A launch covers the slots of a call with gridDim.z; caller-provided arrays are pitched by
 // `upitch` elements per frame.  With one frame everything is offset 0.
 // ------------------------------------------------------------------------------------------------
+#define LPX_NB_BUCKET_DEFAULT 64u
 #define LPX_SORT_TILE 2048u  // keys per radix-sort block (lpx_primitives.hip)
 #define LPX_GROUP_CHUNKS 64u // candidate chunks kept per kd group: one per lane of the searching wavefront
 
@@ -166,6 +167,9 @@ struct lpx_ctx
     Buf nodes;                 // float4 kd nodes, array (in-order) layout
     Buf nodes_pre;             // the same nodes in pre-order rank layout
     Buf lpos, rpos;            // partition scratch
+    uint32_t ix_bucket = LPX_NB_BUCKET_DEFAULT;  // most nodes of a kd group of the search tables: 64, or 32 on scenes whose
+                                                 // searches test many candidates per hit (adapted from h_search)
+    uint64_t *h_search = nullptr;  // pinned: {hits, -, candidates, expansions} of the previous search-mode call (slot 0)
     int reg_index = -1;        // entry of this context in the registry behind lpx_active_frame_slots
     Buf kd_state;              // introselect state of the ranges of a top kd level (multi-workgroup rounds)
     Buf nb_len, nb_off;        // u32 len, u32 off (cap_n + 1)

@@ -1847,7 +1847,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
                                                                const FrameState *__restrict__ frame, float rr,
                                                                ChunkRec *__restrict__ chunks,
                                                                uint32_t *__restrict__ grp_of, uint32_t spine_max,
-                                                               FV fv)
+                                                               uint32_t bucket, FV fv)
 {
     __shared__ Item s_seq[NB_WAVES][2 * IX_CAPS];
     __shared__ uint32_t s_pre[NB_WAVES][IX_CAPS + 8];
@@ -1862,7 +1862,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
     if (M == 0)
         return;
     uint32_t D = 0;
-    while ((M >> D) > (uint32_t)NB_BUCKET)
+    while ((M >> D) > bucket)
         ++D;
     const uint32_t nbk = 1u << D;
     const uint32_t gid = blockIdx.x * NB_WAVES + w;  // [0, nbk): buckets; [nbk, 2 nbk - 1): upper nodes
@@ -2575,8 +2575,29 @@ int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
         return LPX_OK;
     StageTimer tm(ctx, ST_NB_FILL);
     const float rr = sqrtf(r2) * 1.0001f + 1.0e-3f;
+    // Group size: 64 nodes, or 32 when the searches of the previous call on this context tested many candidates per
+    // hit (dense surfaces: BASELINE's synthetic box clouds test 200 candidates per neighbour with 64-node groups and
+    // run 36 % faster with 32; KITTI frames test 12 and lose 4 %).  Hysteresis between 20 and 40 candidates per hit.
+    // The choice changes the work, never a result.  LPX_IX_BUCKET fixes it.
+    static const uint32_t env_bucket = getenv("LPX_IX_BUCKET") ? (uint32_t)atoi(getenv("LPX_IX_BUCKET")) : 0u;
+    uint32_t bucket = ctx->ix_bucket;
+    if (env_bucket >= 32 && env_bucket <= 64)
+        bucket = env_bucket;
+    else if (ctx->h_search)
+    {
+        const uint64_t hits = ctx->h_search[0], cand = ctx->h_search[2], exps = ctx->h_search[3] & 0xffffffffull;
+        if (hits > 0 && exps >= 1000)
+        {
+            const uint64_t per_hit = cand / hits;
+            if (per_hit > 40)
+                bucket = 32;
+            else if (per_hit < 20)
+                bucket = 64;
+        }
+    }
+    ctx->ix_bucket = bucket;
     uint32_t dmax = 0;
-    while ((m_max >> dmax) > (uint32_t)NB_BUCKET)
+    while ((m_max >> dmax) > bucket)
         ++dmax;
     const uint32_t groups = (2u << dmax) - 1;
     if (sizeof(ChunkRec) * LPX_GROUP_CHUNKS * (size_t)groups > ctx->chunks.bytes)
@@ -2584,7 +2605,7 @@ int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
     static const uint32_t ix_spine = getenv("LPX_IX_SPINE") ? (uint32_t)atoi(getenv("LPX_IX_SPINE")) : 2u;
     hipLaunchKernelGGL(nb_index_kernel, dim3((groups + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b), dim3(NB_THREADS), 0,
                        ctx->stream, (const Node *)ctx->nodes_pre.p, (const FrameState *)ctx->frame.p, rr,
-                       (ChunkRec *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, ix_spine, lpx_fv(ctx));
+                       (ChunkRec *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, ix_spine, bucket, lpx_fv(ctx));
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

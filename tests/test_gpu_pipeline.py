@@ -543,3 +543,27 @@ def test_cluster_groups_edge_cases(ctx):
     clu.cluster(one)
     g = clu.grouped(one)
     assert len(g) == 3 and np.array_equal(g[1], one[1:2, :3])
+
+
+def test_search_tables_adapt_their_group_size_to_the_scene():
+    """a context in search mode sizes the kd groups of its chunk tables by what the searches of its previous call
+    cost per hit: the synthetic box cloud (about 200 candidates per neighbour with 64-node groups) switches to
+    32-node groups on the second call, a KITTI frame switches back; every call equals the oracle"""
+    from lidar_processing_amd import Context
+    c = Context(0)
+    c.set_neighbour_mode("search")
+    dense = synthetic_scene(150_000, 500, 200, 4242)
+    skw = dict(number_of_planar_partitions=4, number_of_iterations=3)
+    kitti = load_frame("0000000077")
+    kkw = dict(number_of_planar_partitions=6, number_of_iterations=5)
+    cand = []
+    try:
+        for pts, kw, clu in ((dense, skw, (0.09, 0.5)), (dense, skw, (0.09, 0.5)), (dense, skw, (0.09, 0.5)),
+                             (kitti, kkw, (0.25, 0.5)), (kitti, kkw, (0.25, 0.5)), (kitti, kkw, (0.25, 0.5))):
+            out = c.segment_cluster(pts, SegmentationConfiguration(**kw), ClusteringConfiguration(*clu))
+            check_against_oracle(out, pts, oracle.SegCfg(**kw), oracle.CluCfg(*clu))
+            cand.append(c.frame_stats(0)["candidates"])
+    finally:
+        c.close()
+    assert cand[1] < 0.9 * cand[0] and cand[2] == cand[1], cand  # 64 -> 32 nodes after the first dense call
+    assert cand[3] < 0.9 * cand[4] and cand[5] == cand[4], cand  # the first frame still with 32, then back to 64
