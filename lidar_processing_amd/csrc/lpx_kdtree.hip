@@ -374,25 +374,38 @@ struct Coop<1024>
 
 // __unguarded_partition_pivot(first, last) by a group of G threads; returns the cut
 template <int G>
-__device__ int coop_partition_pivot(const View &v, int first, int last, int axis, int tid, uint32_t *cs)
+__device__ int coop_partition_pivot(const View &v, int first, int last, int axis, int tid, uint32_t *cs, float *kb)
 {
     if (tid == 0)
         seq_median_to_first(v, first, last, axis);
     Coop<G>::sync();
     const float pv = nkey(v, first, axis);
     int cntL = 0, cntR = 0;
-    // flag pass, PE consecutive positions per thread: their loads overlap and there is one scan per G*PE keys
+    // flag pass, PE consecutive positions per thread (one scan per G*PE keys).  The keys come through LDS: the group
+    // reads them with consecutive lanes on consecutive nodes (a thread fetching its own four 16-byte nodes makes
+    // every lane a separate 64-byte request -- or a 16-way bank conflict once the nodes are staged -- and that was
+    // two thirds of this kernel's time), then every thread takes its four as one 16-byte LDS read.
     constexpr int PE = 4;
     for (int base = first + 1; base < last; base += G * PE)
     {
+#pragma unroll
+        for (int j = 0; j < PE; ++j)
+        {
+            const int p = base + j * G + tid;
+            if (p < last)
+                kb[j * G + tid] = nkey(v, p, axis);
+        }
+        Coop<G>::sync();
         const int p0 = base + tid * PE;
         uint32_t gem = 0, lem = 0;
         if (p0 < last)
         {
             float kk[PE];
+            const float4 k4 = *(const float4 *)&kb[tid * PE];
+            kk[0] = k4.x, kk[1] = k4.y, kk[2] = k4.z, kk[3] = k4.w;
 #pragma unroll
             for (int e = 0; e < PE; ++e)
-                kk[e] = (p0 + e < last) ? nkey(v, p0 + e, axis) : pv;
+                kk[e] = (p0 + e < last) ? kk[e] : pv;
 #pragma unroll
             for (int e = 0; e < PE; ++e)
             {
@@ -517,6 +530,7 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     uint32_t *l_lp = (uint32_t *)(smem + sizeof(Node) * STAGE_CAP);
     uint32_t *l_ra = l_lp + STAGE_CAP;
     uint32_t *cs = l_ra + STAGE_CAP;
+    float *kb = (float *)(cs + 64);  // BLK_G x 4 keys of a flag-pass step (16-byte aligned: cs is)
 
     const int tid = threadIdx.x;
     int b = 0, e = (int)frame->n_obstacle;
@@ -571,7 +585,7 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
             break;
         }
         --depth_limit;
-        const int cut = coop_partition_pivot<BLK_G>(v, first, last, axis, tid, cs);
+        const int cut = coop_partition_pivot<BLK_G>(v, first, last, axis, tid, cs, kb);
         if (cut <= nth)
             first = cut;
         else
@@ -2452,13 +2466,14 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     // latency).  A batch shares the device with the small-LDS workgroups of other chains' neighbour kernels,
     // next to which a 96 KiB workgroup rarely finds room; half the capacity schedules freely.
     const int blk_cap = ctx->cur_b > 1 ? BLK_CAP_BATCH : BLK_CAP_MAX;
+    const size_t key_lds = sizeof(float) * BLK_G * 4;  // key buffer of kd_block_kernel's flag pass
     const size_t blk_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint32_t) * blk_cap + 64 * sizeof(uint32_t);
     const size_t lds_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint16_t) * blk_cap + 64 * sizeof(uint32_t);  // batches
     if (!ctx->attr_kd)
     {
         const size_t max_lds = sizeof(Node) * BLK_CAP_MAX + 2 * sizeof(uint32_t) * BLK_CAP_MAX + 64 * sizeof(uint32_t);
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)max_lds));
+                                         (int)(max_lds + key_lds)));
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel<uint32_t>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel<uint16_t>,
@@ -2508,7 +2523,8 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
             }
         }
         hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G),
-                           stage ? blk_lds : 64 * sizeof(uint32_t), ctx->stream, nodes, lpos, rasc, frame, level, blk_cap,
+                           (stage ? blk_lds : 64 * sizeof(uint32_t)) + key_lds, ctx->stream, nodes, lpos, rasc, frame, level,
+                           blk_cap,
                            stage ? blk_cap : 0, top, ctx->fstride);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
