@@ -94,7 +94,9 @@ int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point);
  *                          the neighbour work and a large list workspace (lpx_reserve's neighbours_per_point).
  *   LPX_NEIGHBOURS_SEARCH: expansion-driven -- point sets from a uniform grid, and a radius search only when the
  *                          greedy loop expands a point; nothing is materialised, no list workspace.  Highest
- *                          throughput when many frames share the device.
+ *                          throughput when many frames share the device.  Serves clouds of fewer than 2^30
+ *                          obstacle points like the list path; very dense multi-million-point clouds are
+ *                          faster with LISTS.
  *   LPX_NEIGHBOURS_AUTO  : (default) LISTS for a single-frame context (lpx_create), SEARCH for lpx_create_batch. */
 #define LPX_NEIGHBOURS_AUTO 0
 #define LPX_NEIGHBOURS_LISTS 1
