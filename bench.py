@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the segmentation + clustering hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kitti|synth1m|synth5m|stream]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload stream|kitti|synth1m|synth5m]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child
+process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE anything touches
+the GPU in the parent, waits for them and relays rank 0's JSON line; under torch.distributed.run the ranks exist
+already and nothing is spawned.  `--dry-run --backend gloo` walks the same code path without a GPU (no hot-path
+work, `value` 0, `"dry_run": true`): what the CPU test of the N > 1 launch uses.
 
 A "step" is one pass of the hot path (lpx_segment_cluster_batch_device: Segmenter::segment followed by
 Clusterer::cluster with the obstacle cloud kept on the device, `--batch` frames per launch chain) over one batch
 of frames whose points are already resident in HBM.  Workloads (BASELINE.json configs):
-  kitti   (default, configs[1]) real 120k-point KITTI frames (committed fixtures of the reference's data/*.pcd),
-          6 segments, 5 plane-fit iterations, FEC d = 0.5 m (distance_squared 0.25), quality 0.5 -- the headline.
+  stream  (default: configs[1]'s parameters on configs[3]'s frames) all 154 data/*.pcd frames in filename order,
+          6 segments, 5 plane-fit iterations, FEC d = 0.5 m (distance_squared 0.25), quality 0.5; frame i -> GPU
+          i mod N; frames/s; also the PCIe-inclusive rate of the double-buffered feeder (files -> pinned -> H2D ->
+          chains -> D2H).  The headline: 154 DISTINCT 120k-point KITTI frames.
+  kitti   (configs[1] on three frames cycled: the round-1/2 headline, kept as `kitti_3_frames_cycled` of the line)
   synth1m (configs[2]) the 1M-point plane + boxes cloud, 12 segments, d = 0.3 m -- BASELINE's roofline run.
   synth5m (configs[4]) the 5M-point cloud, 24 segments, d = 0.2 m.
-  stream  (configs[3]) all 154 frames in filename order, frame i -> GPU i mod N, frames/s; also reports the
-          PCIe-inclusive rate of the double-buffered feeder (files -> pinned -> H2D -> chains -> D2H).
 Frames are independent, so with N GPUs every rank runs its own frames ("weak" scaling) and there is no data-path
 collective; RCCL is used only for the barrier and the max-over-ranks time.
 
@@ -41,14 +48,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md:36; a float4 copy measures 6.29 TB/s there)
+PROFILE_ROUND = "r03"  # committed rocprofv3 summaries this line points at: profiles/<round>_<workload>_*
 
 WORKLOADS = {
-    "kitti": dict(config="configs[1]: 120k-pt KITTI frames, 6 segments, 5 iters, FEC d=0.5 m q=0.5",
+    "kitti": dict(config="configs[1]: 120k-pt KITTI frames (three frames cycled), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                   seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
                   clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=512, batch=32, contexts=16),
-    "stream": dict(config="configs[3]: all 154 data/*.pcd frames in order (three passes over the sequence per step), "
-                          "6 segments, 5 iters, FEC d=0.5 m q=0.5",
+    "stream": dict(config="configs[1] parameters on configs[3]'s frames: all 154 data/*.pcd 120k-pt KITTI frames in order "
+                          "(three passes over the sequence per step), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                    seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
                    clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=462, batch=32, contexts=15),
     "synth1m": dict(config="configs[2]: synthetic 1M-pt plane + boxes, 12 segments, 3 iters, FEC d=0.3 m q=0.5",
@@ -75,7 +83,7 @@ def frame_bytes(N, M, I):
     return N * (44 + 12 * I) + 80 * M
 
 
-def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=None):
+def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=None, plane_per_pass=True):
     """Algorithmic HBM bytes of `stage` for ONE frame with N points, M obstacle points (kernel table).
     Expansion-driven path: `cand` candidates distance-tested by the replay's searches, `groups` kd groups.  List
     path (E neighbour-list entries, E_replay of them read by the replay) when cand is None."""
@@ -90,7 +98,9 @@ def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=Non
         "gather": N * (4 + 12 + 12),                 # index, gather, x-sorted SoA
         "zsort": 5 * N * (8 + 8 + 8),
         "seeds": N * 4 + P * 64,                     # the selection kernel reads the x-sorted z once
-        "plane_passes": N * 12 + N,                  # the SoA is read once and stays in registers; flag write
+        # one launch per pass (batches, large segments): the x-sorted SoA is read by every pass (12 B per
+        # point per pass, I + 1 passes); plane_single_kernel (one frame) reads it once and keeps it in registers
+        "plane_passes": (N * 12 * (I + 1) + N) if plane_per_pass else (N * 12 + N),
         "compact": N * (1 + 4 + 4 + 4) + M * (12 + 16),  # flag, index, label, list, obstacle SoA + kd nodes
         "kd_build": M * 16 * 2 * 17,                 # ~log2(M) levels, each reads + writes the node array
         # components: (search) cell table insert + 13 lookups per cell + root per point / (lists) every list re-read
@@ -107,10 +117,10 @@ def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=Non
 
 def pmc_traffic(stage, workload):
     """HBM bytes per launch of the stage's dominant kernel from the COMMITTED rocprofv3 --pmc summary of this same
-    command (profiles/r02_<workload>_pmc_fetch_write_per_kernel.json): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 --
+    command (profiles/<round>_<workload>_pmc_fetch_write_per_kernel.json): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 --
     FETCH_SIZE counts half of a coalesced read on gfx950 (guides/MI355X_MICROARCH.md, HBM).  None when no summary
     is committed for this workload: the value is never measured inside this run."""
-    path = os.path.join(ROOT, "profiles", f"r02_{workload}_pmc_fetch_write_per_kernel.json")
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_pmc_fetch_write_per_kernel.json")
     try:
         d = json.load(open(path))
         # (template variants of one kernel: the one that moved the data)
@@ -126,16 +136,18 @@ def frame_ids_for_rank(rank, world, frames_per_step, n_frames):
     return [(rank + world * j) % n_frames for j in range(frames_per_step)]
 
 
-def aggregate(elapsed_s, points_per_step, device, world):
-    """MAX of the per-rank time and SUM of the per-rank points (the only cross-rank exchange)."""
+def aggregate(elapsed_s, points_per_step, device, world, frames_per_step=0):
+    """MAX of the per-rank time and SUM of the per-rank points and frames (the only cross-rank exchange)."""
     import torch
     import torch.distributed as dist
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
-    pts = torch.tensor([float(points_per_step)], dtype=torch.float64, device=device)
+    pts = torch.tensor([float(points_per_step), float(frames_per_step)], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(pts, op=dist.ReduceOp.SUM)
-    return float(t.item()), float(pts.item())
+    if frames_per_step:
+        return float(t.item()), float(pts[0].item()), float(pts[1].item())
+    return float(t.item()), float(pts[0].item())
 
 
 def load_workload(name):
@@ -199,311 +211,507 @@ def cpu_baselines(host_frames, wl, budget_s):
                                          "what": f"one frame per core, {len(jobs)} frames in {t3:.1f} s"}}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one process per GPU); > 1 without WORLD_SIZE: spawned here")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="stream")
     ap.add_argument("--frames-per-step", type=int, default=0, help="frames in one step (per GPU); 0 = workload default")
     ap.add_argument("--batch", type=int, default=0, help="frames per launch chain; 0 = workload default")
     ap.add_argument("--contexts", type=int, default=0, help="concurrent lpx contexts (HIP streams) per GPU; 0 = default")
     ap.add_argument("--threads", type=int, default=4, help="host threads that enqueue (ctypes releases the GIL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-inflight", action="store_true", help="skip the frames-in-flight curve")
+    ap.add_argument("--no-sub", action="store_true", help="skip the three-frames-cycled sub-measurement of the stream line")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the one-core CPU baseline leg")
     ap.add_argument("--lists", action="store_true", help="A/B: materialise every radius list (LPX_NEIGHBOURS_LISTS)")
     ap.add_argument("--search", action="store_true", help="A/B: expansion-driven searches (LPX_NEIGHBOURS_SEARCH)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default=None,
+                    help="torch.distributed backend of the barrier / MAX / SUM (default nccl = RCCL; gloo with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: launch, rendezvous, frame sharding and aggregation only; value 0, dry_run true in the line")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` outside a launcher: N child processes, one per GPU, started before THIS process has made
+    any HIP / torch.cuda call (a process that has initialised the GPU must not fork or exec workers).  The parent
+    only waits; rank 0's stdout (the one JSON line) is relayed, the other ranks' goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", LPX_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+class Plan:
+    """Device-resident inputs / outputs and the contexts of one workload on one rank."""
+
+    def __init__(self, name, host_frames, args, rank, world, local_rank, torch, lpx):
+        wl = WORKLOADS[name]
+        self.name, self.wl, self.torch = name, wl, torch
+        self.lists = not args.search and (args.lists or wl.get("lists", False))
+        self.scfg = lpx.SegmentationConfiguration(**wl["seg"])
+        self.ccfg = lpx.ClusteringConfiguration(**wl["clu"])
+        self.P, self.I = wl["seg"]["number_of_planar_partitions"], wl["seg"]["number_of_iterations"]
+        dev = torch.device("cuda", local_rank)
+        self.dev, self.local_rank = dev, local_rank
+        # ---- inputs: resident in HBM before the timed region (32-byte PointXYZI records, one pitched array) ----
+        F = self.F = args.frames_per_step or wl["frames_per_step"]
+        B = self.B = max(1, min(args.batch or wl["batch"], F))
+        self.my_ids = frame_ids_for_rank(rank, world, F, len(host_frames))
+        pitch = self.pitch = max(hf.shape[0] for hf in host_frames)
+        host_in = np.zeros((F, pitch, 8), np.float32)
+        for j, fid in enumerate(self.my_ids):
+            host_in[j, :host_frames[fid].shape[0], :4] = host_frames[fid]
+        self.d_pts = torch.from_numpy(host_in).to(dev)
+        del host_in
+        self.n_points = np.array([host_frames[fid].shape[0] for fid in self.my_ids], np.uint32)
+        self.chains = [(k, min(k + B, F)) for k in range(0, F, B)]  # frames [lo, hi) of every launch chain
+        C = self.C = max(1, min(args.contexts or wl["contexts"], len(self.chains)))
+        self.ctxs = [self.new_context(lpx, B) for _ in range(C)]
+        self.d_labels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
+        self.d_gidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
+        self.d_oidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
+        self.d_planes = torch.empty((F, 4 * self.P), dtype=torch.float32, device=dev)
+        self.d_clabels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
+        self.d_counts = torch.zeros((F, 4), dtype=torch.int32, device=dev)
+        self.points_per_step = int(self.n_points.sum())
+        import concurrent.futures
+        self.T = max(1, min(args.threads, C))
+        self.pool = concurrent.futures.ThreadPoolExecutor(self.T) if self.T > 1 else None
+
+    def new_context(self, lpx, batch, mode=None):
+        c = lpx.Context(self.local_rank, batch=batch)
+        c.set_neighbour_mode(mode or ("lists" if self.lists else "search"))  # a batch=1 context would default to lists
+        c.reserve(self.pitch)
+        return c
+
+    def enqueue_frames(self, ctx, lo, hi):
+        ctx.segment_cluster_batch_device(self.n_points[lo:hi], self.d_pts[lo].data_ptr(), 32, self.pitch, self.scfg,
+                                         self.ccfg, self.d_labels[lo].data_ptr(), self.d_gidx[lo].data_ptr(),
+                                         self.d_oidx[lo].data_ptr(), self.d_planes[lo].data_ptr(),
+                                         self.d_clabels[lo].data_ptr(), self.d_counts[lo].data_ptr())
+
+    def enqueue_chain(self, k):
+        lo, hi = self.chains[k]
+        self.enqueue_frames(self.ctxs[k % self.C], lo, hi)
+
+    def _enqueue(self, tid):
+        # thread tid owns contexts tid, tid + T, ... and therefore chains k with (k % C) % T == tid
+        self.torch.cuda.set_device(self.local_rank)
+        for k in range(len(self.chains)):
+            if (k % self.C) % self.T == tid:
+                self.enqueue_chain(k)
+
+    def step(self):
+        if self.pool is None:
+            self._enqueue(0)
+        else:
+            list(self.pool.map(self._enqueue, range(self.T)))
+
+    def sync(self):
+        for c in self.ctxs:
+            c.synchronize()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, barrier):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides"""
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        barrier()
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        barrier()
+        self.torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        counts = self.d_counts.cpu().numpy().view(np.uint32)
+        if (counts[:, 3] != 0).any():
+            raise SystemExit(f"device status != 0: {counts[:, 3].tolist()}")
+        return elapsed, counts
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown()
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+
+
+def stage_profile(plan, steps):
+    """HIP-event pairs around every stage (lpx_profile_*), on the streams the kernels run on: (1) the same K steps
+    under the same load as the timed region; (2) every chain of one step alone on the device -- the launch duration of
+    the kernels themselves."""
+    def profiled(run):
+        for c in plan.ctxs:
+            c.profile_enable(True)
+        run()
+        plan.sync()
+        ms_tot, n_tot = {}, {}
+        for c in plan.ctxs:
+            for k, (ms, cnt) in c.profile_read().items():
+                ms_tot[k] = ms_tot.get(k, 0.0) + ms
+                n_tot[k] = n_tot.get(k, 0) + cnt
+            c.profile_enable(False)
+        return ms_tot, n_tot
+
+    def loaded():
+        for _ in range(steps):
+            plan.step()
+
+    def isolated():
+        for k in range(len(plan.chains)):
+            plan.enqueue_chain(k)
+            plan.ctxs[k % plan.C].synchronize()
+
+    stage_ms, launches = profiled(loaded)
+    iso_ms, iso_launches = profiled(isolated)
+    per_launch = {k: iso_ms[k] / max(1, iso_launches[k]) for k in iso_ms}
+    return stage_ms, launches, per_launch
+
+
+def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_launch):
+    """`achieved` = the frame's algorithmic bytes B = N (44 + 12 I) + 80 M, times the frames one launch of
+    the dominant kernel covers, over that kernel's launch duration alone on the device (HIP events on its stream)."""
+    I, P, B, F = plan.I, plan.P, plan.B, plan.F
+    dom = max(per_launch, key=per_launch.get)
+    frames_per_launch = float(np.mean([hi - lo for lo, hi in plan.chains]))
+    Nn, Mm = float(plan.n_points.mean()), float(counts[:, 1].mean())
+    fst = [c.frame_stats(slot) for c in plan.ctxs for slot in range(B)]
+    E = float(np.mean([f["neighbour_entries"] for f in fst]))
+    E_replay = float(np.mean([f["replay_entries"] for f in fst]))
+    cand = None if plan.lists else float(np.mean([f["candidates"] for f in fst]))
+    D = 0
+    while (int(Mm) >> D) > 64:
+        D += 1
+    groups = float((2 << D) - 1)
+    kern = dict(STAGE_KERNEL)
+    if plan.lists:
+        kern.update(cc_hook="cc_hook_kernel", neighbours="nb_group_kernel", components="cc_flatten_kernel",
+                    replay="replay_lds_kernel" if Mm <= 393216 else "replay_kernel")  # LDS bitmap limit
+    per_pass = B > 1 or Nn / P > 24576  # which plane kernel ran (csrc/lpx_segment.hip)
+    if not per_pass:
+        kern["plane_passes"] = "plane_single_kernel"
+    else:
+        kern["plane_passes"] = "plane_pass_kernel"
+
+    def stage_row(stage):
+        algo = frames_per_launch * algorithmic_bytes(stage, Nn, Mm, E, I, P, E_replay, cand, groups, per_pass)
+        ms = per_launch[stage]
+        ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel": kern.get(stage, stage), "avg_launch_ms": round(ms, 5),
+                "algorithmic_bytes_per_launch": int(algo), "achieved": round(ach, 2),
+                "frac": round(ach / HBM_PEAK_GBS, 5)}
+
+    step_ms = elapsed / steps * 1e3
+    fb = frame_bytes(Nn, Mm, I)
+    frame_gbs = fb * F * world / (step_ms * 1e-3) / 1e9
+    copy_gbs = plan.ctxs[0].copy_bandwidth(1 << 30, 10)
+    dom_ms = per_launch[dom]
+    dom_gbs = fb * frames_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    own = stage_row(dom)
+    return {"bound": "hbm", "kernel": kern.get(dom, dom), "stage": dom,
+            "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 5),
+            "what": "SURVEY 8(d) bytes of a frame, N (44 + 12 I) + 80 M, x frames per launch / launch duration of the "
+                    "dominant kernel alone on the device (HIP events on its stream)",
+            "traffic": pmc_traffic(dom, plan.name),
+            "traffic_source": f"committed profiles/{PROFILE_ROUND}_{plan.name}_pmc summary of this command "
+                              "(rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; not measured in this run)",
+            "avg_launch_ms": round(dom_ms, 5),
+            "avg_launch_ms_under_load": round(stage_ms[dom] / max(1, launches[dom]), 5),
+            "algorithmic_bytes_per_launch": int(fb * frames_per_launch), "frames_per_launch": frames_per_launch,
+            # what the dominant kernel moves by its OWN design (not the 8d figure): the replay tests `cand` candidates
+            # of 16 bytes, most of them L2 hits
+            "kernel_own_bytes_per_launch": own["algorithmic_bytes_per_launch"],
+            "candidate_bytes": int(frames_per_launch * (cand or 0) * 16) if dom == "replay" and not plan.lists else None,
+            "note": "the dominant kernel of a chain is latency-bound (one sequencer wavefront per component set), not "
+                    "an HBM stream; see roofline.frame and roofline.streaming_kernels",
+            # the whole frame against the roofline over the step time (every kernel, every chain in flight)
+            "frame": {"bytes_per_frame": int(fb), "achieved": round(frame_gbs, 2), "unit": "GB/s",
+                      "frac": round(frame_gbs / HBM_PEAK_GBS, 5),
+                      "frac_of_copy_bandwidth": round(frame_gbs / copy_gbs, 5) if copy_gbs else None},
+            # the kernels that ARE plain HBM streams, each alone on the device, their own algorithmic bytes
+            "streaming_kernels": {s: stage_row(s) for s in STREAMING if per_launch.get(s, 0) > 0},
+            "plane_passes": stage_row("plane_passes") if per_launch.get("plane_passes", 0) > 0 else None,
+            "hbm_copy_kernel_gbs": round(copy_gbs, 1),
+            "stage_ms_per_launch_alone": {k: round(v, 5) for k, v in per_launch.items()}}
+
+
+def latency_of(plan, host_frames, lpx):
+    """one frame at a time (what the drop-in Segmenter / Clusterer classes do per callback)"""
+    import ctypes as Cc
+    hf = host_frames[plan.my_ids[0]]
+    n0, P, scfg, ccfg = hf.shape[0], plan.P, plan.scfg, plan.ccfg
+    one = lpx.Context(plan.local_rank)  # single-frame context: LPX_NEIGHBOURS_AUTO = lists, the low-latency mode
+    one.reserve(n0)
+
+    def med(fn, reps=15):
+        fn()
+        ts = []
+        for _ in range(reps):
+            a = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - a)
+        return float(np.median(ts)) * 1e3
+
+    def dev_call():
+        one.segment_cluster_device(plan.d_pts[0].data_ptr(), 32, n0, scfg, ccfg, plan.d_labels[0].data_ptr(),
+                                   plan.d_gidx[0].data_ptr(), plan.d_oidx[0].data_ptr(), plan.d_planes[0].data_ptr(),
+                                   plan.d_clabels[0].data_ptr(), plan.d_counts[0].data_ptr())
+        one.synchronize()
+
+    dev_ms = med(dev_call)
+    pageable = np.ascontiguousarray(hf)
+    host_ms = med(lambda: one.segment_cluster(pageable, scfg, ccfg))
+    # pinned: input and every result array page-locked (lpx_host_alloc)
+    pin_in = lpx.PinnedArray(hf.shape, np.float32)
+    pin_in.array[:] = hf
+    outs = [lpx.PinnedArray(n0, np.uint32) for _ in range(3)] + [lpx.PinnedArray(n0, np.int32),
+                                                                  lpx.PinnedArray(4 * P, np.float32)]
+    ng, no, nc = Cc.c_uint32(0), Cc.c_uint32(0), Cc.c_uint32(0)
+    sc, cc = scfg._c(), ccfg._c()
+
+    def pinned_call():
+        one.check(one._L.lpx_segment_cluster(one._h, pin_in.array.ctypes.data, 16, n0, Cc.byref(sc), Cc.byref(cc),
+                                             outs[0].array.ctypes.data, outs[1].array.ctypes.data, Cc.byref(ng),
+                                             outs[2].array.ctypes.data, Cc.byref(no), outs[4].array.ctypes.data,
+                                             outs[3].array.ctypes.data, Cc.byref(nc)))
+
+    pin_ms = med(pinned_call)
+
+    # what the UNCHANGED processor node does per message (src/processor.cpp:150 and :178): segment() on the host
+    # cloud, the obstacle cloud copied out on the host, then cluster() on that cloud -- two blocking calls
+    def two_calls():
+        _, _, oi, _ = one.segment(pageable, scfg)
+        one.cluster(pageable[oi], ccfg)
+
+    two_ms = med(two_calls)
+    one.set_neighbour_mode("search")
+    dev_search_ms = med(dev_call)
+    one.close()
+    return {"frame_points": n0, "what": "one frame at a time on a single-frame context, median of 15",
+            "device_resident_ms": round(dev_ms, 4), "device_resident_mpts_s": round(n0 / dev_ms / 1e3, 2),
+            "host_api_pageable_ms": round(host_ms, 4), "host_api_pinned_ms": round(pin_ms, 4),
+            "host_api_pinned_mpts_s": round(n0 / pin_ms / 1e3, 2),
+            "dropin_segment_then_cluster_ms": round(two_ms, 4),
+            "dropin_what": "lpx_segment, host copy of the obstacle cloud, lpx_cluster: the two blocking calls of "
+                           "the unchanged processor node (pageable memory)",
+            "device_resident_ms_search_mode": round(dev_search_ms, 4),
+            "note": "single-frame contexts default to LPX_NEIGHBOURS_LISTS (shortest critical path); the "
+                    "throughput figure uses LPX_NEIGHBOURS_SEARCH"}
+
+
+def inflight_curve(plan, lpx, seconds=0.6):
+    """Throughput and per-frame completion latency against the number of frames in flight: C contexts (HIP streams),
+    each a closed loop of `enqueue a chain of B frames -> wait for it`, so C x B frames are in flight.  What a
+    4-sensor rig (4 in flight) or a 32-frame backlog gets, between the two ends the headline and `latency` show."""
+    import threading
+    shapes = [(1, 1, "lists"), (1, 1, "search"), (4, 1, "lists"), (4, 1, "search"), (1, 4, "search"),
+              (16, 1, "lists"), (2, 8, "search"), (1, 16, "search"), (8, 8, "search"), (2, 32, "search"),
+              (16, 32, "search")]
+    rows = []
+    F = plan.F
+    for C, B, mode in shapes:
+        if C * B > F:
+            continue
+        reuse = (B == plan.B and mode == ("lists" if plan.lists else "search") and C <= plan.C)
+        ctxs = plan.ctxs[:C] if reuse else [plan.new_context(lpx, B, mode) for _ in range(C)]
+        lat = [[] for _ in range(C)]
+        frames = [0] * C
+        points = [0] * C
+        stop = time.perf_counter() + seconds
+        start_evt = threading.Event()
+
+        def loop(i):
+            plan.torch.cuda.set_device(plan.local_rank)
+            k = i * B  # every context walks its own frames of the resident array
+            for warm in (True, False):
+                start_evt.wait() if not warm else None
+                while True:
+                    lo = k % (F - B + 1)
+                    a = time.perf_counter()
+                    plan.enqueue_frames(ctxs[i], lo, lo + B)
+                    ctxs[i].synchronize()
+                    b = time.perf_counter()
+                    k += C * B
+                    if warm:
+                        break
+                    lat[i].append(b - a)
+                    frames[i] += B
+                    points[i] += int(plan.n_points[lo:lo + B].sum())
+                    if b >= stop:
+                        break
+
+        th = [threading.Thread(target=loop, args=(i,)) for i in range(C)]
+        for x in th:
+            x.start()
+        time.sleep(0.05)
+        t0 = time.perf_counter()
+        stop = t0 + seconds
+        start_evt.set()
+        for x in th:
+            x.join()
+        wall = time.perf_counter() - t0
+        allat = np.concatenate([np.array(x) for x in lat]) * 1e3
+        rows.append({"frames_in_flight": C * B, "contexts": C, "frames_per_chain": B, "neighbour_mode": mode,
+                     "mpts_s": round(sum(points) / wall / 1e6, 1), "frames_per_s": round(sum(frames) / wall, 1),
+                     "p50_frame_completion_ms": round(float(np.median(allat)), 3),
+                     "p99_frame_completion_ms": round(float(np.percentile(allat, 99)), 3)})
+        if not reuse:
+            for c in ctxs:
+                c.close()
+    return {"what": "closed loops: every context enqueues a chain of B frames and waits for it; C x B frames in flight; "
+                    "completion = enqueue of the chain -> all its results resident in HBM (device-resident inputs)",
+            "seconds_per_point": seconds, "curve": rows}
+
+
+def feeder_rates(plan, host_frames, lpx, elapsed, steps, world):
+    """the same frames through the feeder (PCIe-inclusive): files -> pinned -> H2D -> chains -> D2H"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = []
+        for j, hf in enumerate(host_frames):
+            paths.append(os.path.join(tmp, f"{j:010d}.pcd"))
+            lpx.write_pcd(paths[-1], hf)
+        feeder = lpx.Feeder(paths, plan.local_rank)
+        ids = np.array(plan.my_ids, np.uint32)
+        out = feeder.run(plan.ctxs[0], ids, plan.scfg, plan.ccfg)
+        a = time.perf_counter()
+        passes = 3
+        for _ in range(passes):
+            feeder.run(plan.ctxs[0], ids, plan.scfg, plan.ccfg, out)
+        tf = (time.perf_counter() - a) / passes
+        # all contexts of the bench, one pipeline each (lpx_feeder_run_multi), the same frame list
+        out3 = feeder.run(plan.ctxs, ids, plan.scfg, plan.ccfg)
+        a = time.perf_counter()
+        for _ in range(passes):
+            feeder.run(plan.ctxs, ids, plan.scfg, plan.ccfg, out3)
+        tm = (time.perf_counter() - a) / passes
+        del out, out3
+        feeder.close()
+    return {"frames": len(plan.my_ids), "device_resident_frames_per_s": round(plan.F * world * steps / elapsed, 1),
+            "feeder_frames_per_s": round(len(ids) / tf, 1),
+            "feeder_mpts_s": round(plan.points_per_step / tf / 1e6, 2),
+            "feeder_what": "lpx_feeder_run on ONE batch context: pinned records H2D, chains of "
+                           f"{plan.B}, exact-size D2H of labels / index lists / cluster labels / planes, "
+                           "two buffer sets (PCIe-inclusive; never the headline value)",
+            "feeder_multi_frames_per_s": round(len(ids) / tm, 1),
+            "feeder_multi_mpts_s": round(plan.points_per_step / tm / 1e6, 2),
+            "feeder_multi_what": f"lpx_feeder_run_multi on the {len(plan.ctxs)} contexts of this run (one "
+                                 "pipeline and host thread per context), the same frames"}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
     wl = WORKLOADS[args.workload]
-    args.lists = not args.search and (args.lists or wl.get("lists", False))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = args.backend or ("gloo" if args.dry_run else "nccl")
 
     host_frames = load_workload(args.workload)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baselines(host_frames, wl, args.cpu_seconds)  # before the GPU is initialised (fork)
 
     import torch
     import torch.distributed as dist
-    from lidar_processing_amd import (ClusteringConfiguration, Context, Feeder, PinnedArray, SegmentationConfiguration,
-                                      write_pcd)
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    scfg = SegmentationConfiguration(**wl["seg"])
-    ccfg = ClusteringConfiguration(**wl["clu"])
-    P, I = wl["seg"]["number_of_planar_partitions"], wl["seg"]["number_of_iterations"]
-
-    # ---- inputs: resident in HBM before the timed region (32-byte PointXYZI records, one pitched array) ----
-    F = args.frames_per_step or wl["frames_per_step"]
-    B = max(1, min(args.batch or wl["batch"], F))
-    my_ids = frame_ids_for_rank(rank, world, F, len(host_frames))
-    pitch = max(hf.shape[0] for hf in host_frames)
-    host_in = np.zeros((F, pitch, 8), np.float32)
-    for j, fid in enumerate(my_ids):
-        host_in[j, :host_frames[fid].shape[0], :4] = host_frames[fid]
-    d_pts = torch.from_numpy(host_in).to(dev)
-    del host_in
-    n_points = np.array([host_frames[fid].shape[0] for fid in my_ids], np.uint32)
-    chains = [(k, min(k + B, F)) for k in range(0, F, B)]  # frames [lo, hi) of every launch chain
-    C = max(1, min(args.contexts or wl["contexts"], len(chains)))
-    ctxs = [Context(local_rank, batch=B) for _ in range(C)]
-    for c in ctxs:
-        c.set_neighbour_mode("lists" if args.lists else "search")  # a batch=1 context would default to lists
-        c.reserve(pitch)
-    d_labels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
-    d_gidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
-    d_oidx = torch.empty((F, pitch), dtype=torch.int32, device=dev)
-    d_planes = torch.empty((F, 4 * P), dtype=torch.float32, device=dev)
-    d_clabels = torch.empty((F, pitch), dtype=torch.int32, device=dev)
-    d_counts = torch.zeros((F, 4), dtype=torch.int32, device=dev)
-    points_per_step = int(n_points.sum())
-
-    import concurrent.futures
-    T = max(1, min(args.threads, C))
-    pool = concurrent.futures.ThreadPoolExecutor(T) if T > 1 else None
-
-    def enqueue_chain(k):
-        lo, hi = chains[k]
-        ctxs[k % C].segment_cluster_batch_device(n_points[lo:hi], d_pts[lo].data_ptr(), 32, pitch, scfg, ccfg,
-                                                 d_labels[lo].data_ptr(), d_gidx[lo].data_ptr(), d_oidx[lo].data_ptr(),
-                                                 d_planes[lo].data_ptr(), d_clabels[lo].data_ptr(),
-                                                 d_counts[lo].data_ptr())
-
-    def enqueue(tid):
-        # thread tid owns contexts tid, tid + T, ... and therefore chains k with (k % C) % T == tid
-        torch.cuda.set_device(local_rank)
-        for k in range(len(chains)):
-            if (k % C) % T == tid:
-                enqueue_chain(k)
-
-    def step():
-        if pool is None:
-            enqueue(0)
-        else:
-            list(pool.map(enqueue, range(T)))
-
-    def sync():
-        for c in ctxs:
-            c.synchronize()
-        torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    F = args.frames_per_step or wl["frames_per_step"]
+    if args.dry_run:
+        # ---- no GPU: everything around the hot path (launch, rendezvous, sharding, aggregation, the line) ----
+        if world > 1:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        my_ids = frame_ids_for_rank(rank, world, F, len(host_frames))
+        points_per_step = int(sum(host_frames[fid].shape[0] for fid in my_ids))
+        barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * args.steps)  # stands for the K steps
+        barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed, total_points, total_frames = aggregate(elapsed, points_per_step, torch.device("cpu"), world, F)
+        if rank == 0:
+            print(json.dumps({"metric": "Mpts/s seg+cluster (120k-pt frame)", "value": 0.0, "unit": "Mpts/s",
+                              "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
+                              "config": {"workload": wl["config"], "frames_per_step_per_gpu": F,
+                                         "points_per_step": int(total_points), "frames_per_step": int(total_frames),
+                                         "distributed_backend": backend if world > 1 else None,
+                                         "distributed_world_size": dist.get_world_size() if world > 1 else 1,
+                                         "frame_ids_rank0_head": my_ids[:4]}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
 
-    counts = d_counts.cpu().numpy().view(np.uint32)
-    if (counts[:, 3] != 0).any():
-        raise SystemExit(f"device status != 0: {counts[:, 3].tolist()}")
-    elapsed, total_points_per_step = aggregate(elapsed, points_per_step, dev, world)
+    import lidar_processing_amd as lpx
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback (--dry-run walks the launch only)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                **({"device_id": dev} if backend == "nccl" else {}))
 
-    # ---- stage times: HIP-event pairs around every stage (lpx_profile_*), on the streams the kernels run on ----
-    # (1) the same K steps under the same load as the timed region; (2) every chain of one step alone on the device:
-    # the launch duration of the kernels themselves.  `roofline` describes the stage that dominates (2).
-    roofline, latency, stream_info = None, None, None
+    plan = Plan(args.workload, host_frames, args, rank, world, local_rank, torch, lpx)
+    elapsed, counts = plan.timed(args.steps, args.warmup, barrier)
+    elapsed, total_points_per_step, total_frames_per_step = aggregate(elapsed, plan.points_per_step, dev, world, plan.F)
+
+    roofline, latency, stream_info, inflight, sub = None, None, None, None, None
     stage_ms = {}
     if rank == 0:
-        def profiled(run):
-            for c in ctxs:
-                c.profile_enable(True)
-            run()
-            sync()
-            ms_tot, n_tot = {}, {}
-            for c in ctxs:
-                for k, (ms, cnt) in c.profile_read().items():
-                    ms_tot[k] = ms_tot.get(k, 0.0) + ms
-                    n_tot[k] = n_tot.get(k, 0) + cnt
-                c.profile_enable(False)
-            return ms_tot, n_tot
-
-        def loaded():
-            for _ in range(args.steps):
-                step()
-
-        def isolated():
-            for k in range(len(chains)):
-                enqueue_chain(k)
-                ctxs[k % C].synchronize()
-
-        stage_ms, launches = profiled(loaded)
-        iso_ms, iso_launches = profiled(isolated)
-        per_launch = {k: iso_ms[k] / max(1, iso_launches[k]) for k in iso_ms}
-        dom = max(per_launch, key=per_launch.get)
-        # one launch (group) of a stage covers the frames of a chain: frame-averaged sizes of this rank's step times
-        # the frames per chain; search / list sizes come from the device counters of the frame slots
-        frames_per_launch = float(np.mean([hi - lo for lo, hi in chains]))
-        Nn, Mm = float(n_points.mean()), float(counts[:, 1].mean())
-        fst = [c.frame_stats(slot) for c in ctxs for slot in range(B)]
-        E = float(np.mean([f["neighbour_entries"] for f in fst]))
-        E_replay = float(np.mean([f["replay_entries"] for f in fst]))
-        cand = None if args.lists else float(np.mean([f["candidates"] for f in fst]))
-        D = 0
-        while (int(Mm) >> D) > 64:
-            D += 1
-        groups = float((2 << D) - 1)
-
-        def stage_row(stage):
-            algo = frames_per_launch * algorithmic_bytes(stage, Nn, Mm, E, I, P, E_replay, cand, groups)
-            ms = per_launch[stage]
-            ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"kernel": STAGE_KERNEL.get(stage, stage), "avg_launch_ms": round(ms, 5),
-                    "algorithmic_bytes_per_launch": int(algo), "achieved": round(ach, 2),
-                    "frac": round(ach / HBM_PEAK_GBS, 5)}
-
-        if args.lists:
-            STAGE_KERNEL.update(cc_hook="cc_hook_kernel", neighbours="nb_group_kernel", components="cc_flatten_kernel",
-                                replay="replay_lds_kernel" if Mm <= 393216 else "replay_kernel")  # LDS bitmap limit
-        row = stage_row(dom)
-        step_ms = elapsed / args.steps * 1e3
-        fb = frame_bytes(Nn, Mm, I)
-        frame_gbs = fb * F * world / (step_ms * 1e-3) / 1e9
-        copy_gbs = ctxs[0].copy_bandwidth(1 << 30, 10)
-        roofline = {"bound": "hbm", "kernel": row["kernel"], "stage": dom, "achieved": row["achieved"],
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": row["frac"], "traffic": pmc_traffic(dom, args.workload),
-                    "traffic_source": "committed profiles/r02_*_pmc summary of this command (not measured in this run)",
-                    "avg_launch_ms": row["avg_launch_ms"],
-                    "avg_launch_ms_under_load": round(stage_ms[dom] / max(1, launches[dom]), 5),
-                    "algorithmic_bytes_per_launch": row["algorithmic_bytes_per_launch"],
-                    "frames_per_launch": frames_per_launch,
-                    "note": "the dominant kernel of a chain is latency-bound (one sequencer wavefront per component "
-                            "set), not an HBM stream; see roofline.frame and roofline.streaming_kernels",
-                    # the whole frame against the roofline, B = N (44 + 12 I) + 80 M over the step time
-                    "frame": {"bytes_per_frame": int(fb), "achieved": round(frame_gbs, 2), "unit": "GB/s",
-                              "frac": round(frame_gbs / HBM_PEAK_GBS, 5),
-                              "frac_of_copy_bandwidth": round(frame_gbs / copy_gbs, 5) if copy_gbs else None},
-                    # the kernels that ARE plain HBM streams, each alone on the device, algorithmic bytes only
-                    "streaming_kernels": {s: stage_row(s) for s in STREAMING if per_launch.get(s, 0) > 0},
-                    "hbm_copy_kernel_gbs": round(copy_gbs, 1),
-                    "stage_ms_per_launch_alone": {k: round(v, 5) for k, v in per_launch.items()}}
-
-        # ---- latency: one frame at a time (what the drop-in Segmenter / Clusterer classes do per callback) ----
+        stage_ms, launches, per_launch = stage_profile(plan, args.steps)
+        roofline = roofline_of(plan, counts, elapsed, args.steps, world, stage_ms, launches, per_launch)
         if not args.no_latency:
-            hf = host_frames[my_ids[0]]
-            n0 = hf.shape[0]
-            one = Context(local_rank)  # single-frame context: LPX_NEIGHBOURS_AUTO = lists, the low-latency mode
-            one.reserve(n0)
-
-            def med(fn, reps=15):
-                fn()
-                ts = []
-                for _ in range(reps):
-                    a = time.perf_counter()
-                    fn()
-                    ts.append(time.perf_counter() - a)
-                return float(np.median(ts)) * 1e3
-
-            def dev_call():
-                one.segment_cluster_device(d_pts[0].data_ptr(), 32, n0, scfg, ccfg, d_labels[0].data_ptr(),
-                                           d_gidx[0].data_ptr(), d_oidx[0].data_ptr(), d_planes[0].data_ptr(),
-                                           d_clabels[0].data_ptr(), d_counts[0].data_ptr())
-                one.synchronize()
-
-            dev_ms = med(dev_call)
-            pageable = np.ascontiguousarray(hf)
-            host_ms = med(lambda: one.segment_cluster(pageable, scfg, ccfg))
-            # pinned: input and every result array page-locked (lpx_host_alloc)
-            import ctypes as Cc
-            pin_in = PinnedArray(hf.shape, np.float32)
-            pin_in.array[:] = hf
-            outs = [PinnedArray(n0, np.uint32) for _ in range(3)] + [PinnedArray(n0, np.int32), PinnedArray(4 * P, np.float32)]
-            ng, no, nc = Cc.c_uint32(0), Cc.c_uint32(0), Cc.c_uint32(0)
-            sc, cc = scfg._c(), ccfg._c()
-
-            def pinned_call():
-                one.check(one._L.lpx_segment_cluster(one._h, pin_in.array.ctypes.data, 16, n0, Cc.byref(sc), Cc.byref(cc),
-                                                     outs[0].array.ctypes.data, outs[1].array.ctypes.data, Cc.byref(ng),
-                                                     outs[2].array.ctypes.data, Cc.byref(no), outs[4].array.ctypes.data,
-                                                     outs[3].array.ctypes.data, Cc.byref(nc)))
-
-            pin_ms = med(pinned_call)
-
-            # what the UNCHANGED processor node does per message (src/processor.cpp:150 and :178): segment() on the host
-            # cloud, the obstacle cloud copied out on the host, then cluster() on that cloud -- two blocking calls
-            def two_calls():
-                _, _, oi, _ = one.segment(pageable, scfg)
-                one.cluster(pageable[oi], ccfg)
-
-            two_ms = med(two_calls)
-            one.set_neighbour_mode("search")
-            dev_search_ms = med(dev_call)
-            one.close()
-            latency = {"frame_points": n0, "what": "one frame at a time on a single-frame context, median of 15",
-                       "device_resident_ms": round(dev_ms, 4), "device_resident_mpts_s": round(n0 / dev_ms / 1e3, 2),
-                       "host_api_pageable_ms": round(host_ms, 4), "host_api_pinned_ms": round(pin_ms, 4),
-                       "host_api_pinned_mpts_s": round(n0 / pin_ms / 1e3, 2),
-                       "dropin_segment_then_cluster_ms": round(two_ms, 4),
-                       "dropin_what": "lpx_segment, host copy of the obstacle cloud, lpx_cluster: the two blocking calls of "
-                                      "the unchanged processor node (pageable memory)",
-                       "device_resident_ms_search_mode": round(dev_search_ms, 4),
-                       "note": "single-frame contexts default to LPX_NEIGHBOURS_LISTS (shortest critical path); the "
-                               "throughput figure uses LPX_NEIGHBOURS_SEARCH"}
-
-        # ---- stream: the same frames through the feeder (PCIe-inclusive) ----
+            latency = latency_of(plan, host_frames, lpx)
         if args.workload == "stream":
-            import tempfile
-            with tempfile.TemporaryDirectory() as tmp:
-                paths = []
-                for j, hf in enumerate(host_frames):
-                    paths.append(os.path.join(tmp, f"{j:010d}.pcd"))
-                    write_pcd(paths[-1], hf)
-                feeder = Feeder(paths, local_rank)
-                ids = np.array(my_ids, np.uint32)
-                out = feeder.run(ctxs[0], ids, scfg, ccfg)
-                a = time.perf_counter()
-                passes = 3
-                for _ in range(passes):
-                    feeder.run(ctxs[0], ids, scfg, ccfg, out)
-                tf = (time.perf_counter() - a) / passes
-                # all contexts of the bench, one pipeline each (lpx_feeder_run_multi), the same frame list
-                ids3 = ids
-                lanes = ctxs
-                out3 = feeder.run(lanes, ids3, scfg, ccfg)
-                a = time.perf_counter()
-                for _ in range(passes):
-                    feeder.run(lanes, ids3, scfg, ccfg, out3)
-                tm = (time.perf_counter() - a) / passes
-                del out, out3
-                feeder.close()
-            stream_info = {"frames": len(my_ids), "device_resident_frames_per_s": round(F * world * args.steps / elapsed, 1),
-                           "feeder_frames_per_s": round(len(ids) / tf, 1),
-                           "feeder_mpts_s": round(points_per_step / tf / 1e6, 2),
-                           "feeder_what": "lpx_feeder_run on ONE batch context: pinned records H2D, chains of "
-                                          f"{B}, exact-size D2H of labels / index lists / cluster labels / planes, "
-                                          "two buffer sets (PCIe-inclusive; never the headline value)",
-                           "feeder_multi_frames_per_s": round(len(ids3) / tm, 1),
-                           "feeder_multi_mpts_s": round(points_per_step / tm / 1e6, 2),
-                           "feeder_multi_what": f"lpx_feeder_run_multi on the {len(ctxs)} contexts of this run (one "
-                                                "pipeline and host thread per context), the same frames"}
+            stream_info = feeder_rates(plan, host_frames, lpx, elapsed, args.steps, world)
+        if not args.no_inflight and args.workload in ("stream", "kitti"):
+            inflight = inflight_curve(plan, lpx)
+    if rank == 0 and world == 1 and args.workload == "stream" and not args.no_sub:
+        # the round-1/2 headline shape next to the stream: configs[1] on three frames cycled, 512 per step
+        plan.close()
+        del plan
+        torch.cuda.empty_cache()
+        p3 = Plan("kitti", load_workload("kitti"), args, rank, world, local_rank, torch, lpx)
+        e3, _ = p3.timed(max(3, args.steps // 2), 2, lambda: None)
+        sub = {"mpts_s": round(p3.points_per_step * max(3, args.steps // 2) / e3 / 1e6, 1),
+               "frames_per_step": p3.F, "what": WORKLOADS["kitti"]["config"]}
+        plan = p3
 
     if rank == 0:
         value = total_points_per_step * args.steps / elapsed / 1e6
+        real = args.workload in ("kitti", "stream")
         line = {
-            "metric": "Mpts/s seg+cluster (120k-pt frame)" if args.workload in ("kitti", "stream")
-                      else f"Mpts/s seg+cluster ({args.workload})",
+            "metric": "Mpts/s seg+cluster (120k-pt frame)" if real else f"Mpts/s seg+cluster ({args.workload})",
             "value": round(value, 3),
             "unit": "Mpts/s",
             "n_gpus": world,
@@ -514,27 +722,36 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": ("real KITTI frames (committed fixture of the reference's data/*.pcd)" if args.workload in ("kitti", "stream")
+            "data": ("real KITTI frames (committed fixture of the reference's data/*.pcd)" if real
                      else "synthetic plane + boxes cloud (SURVEY 8d generator, 1 mm quantised)"),
-            "config": {"workload": wl["config"], "neighbour_mode": "lists" if args.lists else "search",
-                       "frames_per_step_per_gpu": F, "frames_per_launch_chain": B, "contexts_per_gpu": C,
-                       "host_threads_per_gpu": T, "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
-                       "points_per_step": int(total_points_per_step),
-                       "frames_per_s": round(F * world * args.steps / elapsed, 2)},
+            "config": {"workload": wl["config"], "neighbour_mode": "lists" if (not args.search and (args.lists or wl.get("lists"))) else "search",
+                       "frames_per_step_per_gpu": F, "frames_per_launch_chain": max(1, min(args.batch or wl["batch"], F)),
+                       "contexts_per_gpu": max(1, min(args.contexts or wl["contexts"], -(-F // max(1, min(args.batch or wl["batch"], F))))),
+                       "host_threads_per_gpu": args.threads, "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "points_per_step": int(total_points_per_step), "frames_per_step": int(total_frames_per_step),
+                       "frames_per_s": round(total_frames_per_step * args.steps / elapsed, 2),
+                       "sharding": "frame i -> GPU i mod N, no data-path collective",
+                       "distributed_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
+                       "distributed_world_size": dist.get_world_size() if world > 1 else 1},
             "vs_target": {"north_star_mpts_s": 50.0, "ratio": round(value / 50.0, 2)},
             "roofline": roofline,
             "latency": latency,
+            "throughput_vs_inflight": inflight,
             "cpu_baseline": cpu,
             "stage_ms_per_frame_under_load": {k: round(v / (args.steps * F), 5) for k, v in stage_ms.items()},
         }
         if stream_info:
             line["stream"] = stream_info
+        if sub:
+            line["kitti_3_frames_cycled"] = sub
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
-    for c in ctxs:
-        c.close()
+    plan.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -140,7 +140,8 @@ class Segmenter final
     // the ground cloud recoloured as PointXYZRGBL(x, y, z, 220, 220, 220, label 0) and the obstacle cloud as
     // (x, y, z, 0, 255, 0, label 1), whose records the node then memcpy's into the published PointCloud2 messages
     // (src/conversions.cpp:164-193).  The records are written on the device from the points that are still
-    // resident there; valid after segment() and before the next segment() on this object.
+    // resident there; valid after segment() and before the next call on the (possibly shared) context: with a
+    // Clusterer on the same LpxContext, call it before cluster() -- as processor.cpp does -- or it throws.
     template <typename PointOutT>
     void coloured_clouds(pcl::PointCloud<PointOutT> &ground_cloud, pcl::PointCloud<PointOutT> &obstacle_cloud)
     {

@@ -57,7 +57,14 @@ typedef struct
 
 #define LPX_OK 0
 #define LPX_ERR_ARG (-1)      /* bad argument */
-#define LPX_ERR_RANGE (-2)    /* a coordinate is NaN or infinite (any finite cloud is processed) */
+#define LPX_ERR_RANGE (-2)    /* a coordinate is NaN or infinite.  Any finite cloud is processed, with two limits on
+                               * what "like the reference" means far from the origin: (1) the plane-fit MOMENTS use a
+                               * coordinate clamped to +-2^24 m (16.7e6 m; UTM / ECEF scale stays exact), the inlier
+                               * test always the float itself -- beyond the clamp the planes are this library's, not
+                               * the reference's float sums (the regression is locked by the repo's own oracle only);
+                               * (2) the component grid saturates at +-2^20 cells (cell edge 0.57 d): farther points
+                               * share a few edge cells, results stay exact but one giant point set serialises the
+                               * replay, i.e. latency, not correctness, degrades for map-frame clouds with small d */
 #define LPX_ERR_HIP (-3)      /* HIP runtime error, see lpx_last_error() */
 #define LPX_ERR_CAPACITY (-4) /* workspace too small and could not be grown */
 #define LPX_ERR_NO_DEVICE (-5)
@@ -148,8 +155,11 @@ int lpx_segment_cluster_fields(lpx_ctx *ctx, const void *data, uint32_t point_st
  * label 0), obstacle points as (x, y, z, 0, 255, 0, label 1) (src/processor.cpp:152-163), whose 32-byte records
  * are memcpy'd into the data[] of the outgoing PointCloud2 messages (src/conversions.cpp:164-193).  Record layout
  * (PCL 1.12 point_types): float x, y, z, 1.0f | uint8 b, g, r, a = 255 | uint32 label | 8 zero bytes.  Records
- * of the LAST host segmentation call of this context, in output-cloud order; each array needs room for 32 bytes
- * per point of that cloud (n_ground / n_obstacle as returned by that call). */
+ * of the LAST host segmentation call of this context (lpx_segment* / lpx_segment_cluster*), in output-cloud order;
+ * each array needs room for 32 bytes per point of that cloud (n_ground / n_obstacle as returned by that call: the
+ * library remembers those counts and never copies more).  Valid until the next call on the context other than
+ * lpx_cluster_groups / lpx_cluster_hulls: a lpx_cluster of another cloud, a new segmentation or any device / batch
+ * entry point re-initialises the frame state, and lpx_coloured_clouds then returns LPX_ERR_ARG. */
 int lpx_coloured_clouds(lpx_ctx *ctx, void *ground_records, void *obstacle_records, uint32_t *n_ground,
                         uint32_t *n_obstacle);
 
@@ -262,7 +272,10 @@ const char *lpx_feeder_last_error(const lpx_feeder *f);
  * of chain k + 1 travel H2D on a copy stream and the results of chain k - 1 travel D2H (exact sizes) on another,
  * so PCIe in both directions overlaps the kernels.  Host result arrays (ordinary or pinned memory) are pitched by
  * frame_pitch elements per frame; planes (may be NULL) by 4 * number_of_planar_partitions floats, counts by 4
- * words {n_ground, n_obstacle, n_clusters, status}.  Per frame the results equal lpx_segment_cluster's. */
+ * words {n_ground, n_obstacle, n_clusters, status}.  Per frame the results equal lpx_segment_cluster's.  A frame
+ * the device flags (status != 0: non-finite coordinates, LPX_ERR_RANGE; neighbour lists that do not fit a context
+ * in LPX_NEIGHBOURS_LISTS mode, LPX_ERR_CAPACITY -- batch contexts default to LPX_NEIGHBOURS_SEARCH, which has no
+ * list workspace) makes the run return that code for the first such frame; counts[] holds every frame's status. */
 typedef struct
 {
     uint32_t *labels, *ground_idx, *obstacle_idx;

@@ -5,7 +5,8 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblpx.so")
+# LPX_LIB: development switch for A/B measurements of alternative builds of the same library (tools/build_variant.sh)
+LIB_PATH = os.path.abspath(os.environ["LPX_LIB"]) if os.environ.get("LPX_LIB") else os.path.join(_HERE, "liblpx.so")
 
 
 class SegCfg(C.Structure):

@@ -55,12 +55,31 @@ static inline size_t align256(size_t v)
     return (v + 255) & ~(size_t)255;
 }
 
+// Which kernel families (lpx_internal.h: lpx_block) keep a frame's workgroups on one XCD.  Measured on MI355X, 16
+// chains of 32 KITTI frames in flight vs 8 chains of 8 1M-point frames: with every family re-read, the 1M-point
+// workload gains 11 % (a frame's hash cells, kd nodes and chunk tables are fetched into one L2 instead of eight; the
+// replay alone 13.2 -> 10.0 ms per chain), but eight XCDs then work on eight DIFFERENT frames at a time, and with
+// sixteen chains of small frames in flight that multiplies the tables live in the 256 MiB Infinity Cache by eight:
+// the 120k-point workload loses 3.5 % (the component grid alone 7 %; only the sorts gain, 0.8 %).  Hence by frame
+// size.  LPX_REMAP=<hex mask> overrides.
+static uint32_t lpx_remap_mask(uint32_t points_per_slot)
+{
+    static const char *env = getenv("LPX_REMAP");
+    if (env)
+        return (uint32_t)strtoul(env, nullptr, 16) & 0xffu;
+    return points_per_slot >= 400000u ? 0xffu : 0x02u;
+}
+
 // One arena per frame slot: every internal buffer is a fixed sub-range of it, so slot b of any buffer is
-// b * fstride bytes behind slot 0 (what the kernels add for blockIdx.z).  Growing reallocates the arena
+// b * fstride bytes behind slot 0 (what the kernels add for their frame index, lpx_block().z).  Growing reallocates the arena
 // and drops its contents, which only happens before a call enqueues work.  The neighbour lists have their
 // own arena so that the capacity retry of the host entry points keeps the frame data.
 int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
 {
+    // 2^30 points per frame is the limit of the 32-bit table sizes below (the cell table has 2^k >= 2 n slots); a
+    // larger -- or garbage -- count is an argument error, not a hang
+    if (n >= (1u << 30))
+        return lpx_fail(ctx, LPX_ERR_ARG, "%u points in a frame: the limit is 2^30 - 1", n);
     if (n > ctx->cap_n || !ctx->arena)
     {
         if (n < ctx->cap_n)
@@ -127,6 +146,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         ctx->fstride = total;
         ctx->cap_n = n;
         ctx->cell_cap = cell_cap;
+        ctx->fs_tag = total | lpx_remap_mask(n);
     }
     if (!ctx->use_lists && !ctx->nb_arena)
         return LPX_OK;  // the neighbour-list workspace below belongs to the list path only (allocated on first use)
@@ -166,6 +186,7 @@ static int begin_call(lpx_ctx *ctx, uint32_t frames, uint32_t upitch)
         return lpx_fail(ctx, LPX_ERR_ARG, "%u frames in a call, the context has %u frame slots", frames, ctx->batch);
     ctx->cur_b = frames;
     ctx->upitch = upitch;
+    ctx->seg_valid = false;  // set again at the end of a host segmentation call (what lpx_coloured_clouds serves)
     ctx->in_off[0] = 0;  // PCL records: x, y, z lead the record; the *_fields entry points overwrite this
     ctx->in_off[1] = 4;
     ctx->in_off[2] = 8;
@@ -729,8 +750,13 @@ static int segment_impl(lpx_ctx *ctx, const void *pts, size_t stride, const uint
                               (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
         return rc;
     FrameState fs;
-    return download_segment(ctx, n, cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle, planes,
-                            &fs);
+    if ((rc = download_segment(ctx, n, cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle, planes,
+                               &fs)))
+        return rc;
+    ctx->seg_valid = true;
+    ctx->seg_ground = fs.n_ground;
+    ctx->seg_obstacle = fs.n_obstacle;
+    return LPX_OK;
 }
 
 extern "C" int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *cfg,
@@ -865,7 +891,13 @@ static int segment_cluster_impl(lpx_ctx *ctx, const void *pts, size_t stride, co
         *n_ground = fs.n_ground;
     if (n_obstacle)
         *n_obstacle = fs.n_obstacle;
-    return download_clusters(ctx, fs, cluster_labels, n_clusters);  // one synchronisation for all copies
+    if ((rc = download_clusters(ctx, fs, cluster_labels, n_clusters)))  // one synchronisation for all copies
+        return rc;
+    // the clustering of the resident obstacle cloud leaves the segmentation's points and index lists in place
+    ctx->seg_valid = true;
+    ctx->seg_ground = fs.n_ground;
+    ctx->seg_obstacle = fs.n_obstacle;
+    return LPX_OK;
 }
 
 extern "C" int lpx_segment_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t n, const lpx_seg_cfg *seg_cfg,
@@ -916,18 +948,26 @@ extern "C" int lpx_coloured_clouds_batch_device(lpx_ctx *ctx, uint32_t n_frames,
     return lpx_run_colour(ctx, frame_pitch, d_gidx, d_oidx, d_ground_records, d_obstacle_records);
 }
 
-// host form: records of the LAST lpx_segment* / lpx_segment_cluster* HOST call of this context
+// host form: records of the LAST lpx_segment* / lpx_segment_cluster* HOST call of this context.  Any other call on the
+// context in between (lpx_cluster of another cloud, a device or batch entry point) re-initialises the frame state and
+// may move the arena: the call then fails with LPX_ERR_ARG instead of copying records of the wrong cloud.  Never
+// copies more than the counts that segmentation call returned to the caller.
 extern "C" int lpx_coloured_clouds(lpx_ctx *ctx, void *ground_records, void *obstacle_records, uint32_t *n_ground,
                                    uint32_t *n_obstacle)
 {
     if (!ctx || !ground_records || !obstacle_records)
         return LPX_ERR_ARG;
-    LPX_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t n = ctx->last_n;
     if (n_ground)
         *n_ground = 0;
     if (n_obstacle)
         *n_obstacle = 0;
+    if (!ctx->seg_valid)
+        return lpx_fail(ctx, LPX_ERR_ARG, "lpx_coloured_clouds: the last call on this context was not a host "
+                                         "segmentation (lpx_segment* / lpx_segment_cluster*); its clouds are gone");
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->last_n, ng = ctx->seg_ground, no = ctx->seg_obstacle;
+    if ((uint64_t)ng + no > n)
+        return lpx_fail(ctx, LPX_ERR_INTERNAL, "remembered cloud sizes %u + %u exceed the %u points segmented", ng, no, n);
     if (n == 0)
         return LPX_OK;
     int rc = lpx_ensure(ctx, ctx->rec_out, 64 * (size_t)n + 64);
@@ -938,19 +978,15 @@ extern "C" int lpx_coloured_clouds(lpx_ctx *ctx, void *ground_records, void *obs
     ctx->upitch = 0;
     if ((rc = lpx_run_colour(ctx, n, (const uint32_t *)ctx->d_gidx.p, (const uint32_t *)ctx->d_oidx.p, grec, orec)))
         return rc;
-    FrameState fs;
-    if ((rc = read_frame(ctx, &fs)))
-        return rc;
-    if (fs.n_ground)
-        LPX_HIP(ctx, hipMemcpyAsync(ground_records, grec, 32 * (size_t)fs.n_ground, hipMemcpyDeviceToHost, ctx->stream));
-    if (fs.n_obstacle)
-        LPX_HIP(ctx, hipMemcpyAsync(obstacle_records, orec, 32 * (size_t)fs.n_obstacle, hipMemcpyDeviceToHost,
-                                    ctx->stream));
+    if (ng)
+        LPX_HIP(ctx, hipMemcpyAsync(ground_records, grec, 32 * (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));
+    if (no)
+        LPX_HIP(ctx, hipMemcpyAsync(obstacle_records, orec, 32 * (size_t)no, hipMemcpyDeviceToHost, ctx->stream));
     LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n_ground)
-        *n_ground = fs.n_ground;
+        *n_ground = ng;
     if (n_obstacle)
-        *n_obstacle = fs.n_obstacle;
+        *n_obstacle = no;
     return LPX_OK;
 }
 
@@ -974,7 +1010,9 @@ extern "C" int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters,
     // offsets / indices go to kd-build scratch (free once the clustering is done): the index lists of the
     // segmentation stay resident for lpx_coloured_clouds
     uint32_t *d_off = (uint32_t *)ctx->lpos.p, *d_ind = (uint32_t *)ctx->rpos.p;
+    const bool seg_valid = ctx->seg_valid;  // regrouping touches neither the frame state nor the segmentation's buffers
     int rc = begin_call(ctx, 1, 0);
+    ctx->seg_valid = seg_valid;
     if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)))
         return rc;
     LPX_HIP(ctx, hipMemcpyAsync(offsets, d_off, sizeof(uint32_t) * ((size_t)n_clusters + 1),
@@ -1011,7 +1049,9 @@ extern "C" int lpx_cluster_hulls(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, 
     uint32_t *d_off = (uint32_t *)ctx->lpos.p, *d_ind = (uint32_t *)ctx->rpos.p;
     uint32_t *d_hoff = (uint32_t *)ctx->nb_off.p, *d_hidx = (uint32_t *)ctx->nb_len.p;
     float *d_hxy = (float *)ctx->key64_a.p;
+    const bool seg_valid = ctx->seg_valid;  // (as lpx_cluster_groups)
     int rc = begin_call(ctx, 1, 0);
+    ctx->seg_valid = seg_valid;
     if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)) ||
         (rc = lpx_run_hulls(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind, max_points, d_hoff, d_hidx, d_hxy)))
         return rc;
@@ -1323,7 +1363,8 @@ extern "C" int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
 
 __global__ void dbg_roots_kernel(uint32_t *parent, uint32_t m, uint32_t *root)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const LpxBlock lpx_blk = lpx_block<6>(0);
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i >= m)
         return;
     uint32_t x = i;
@@ -1366,24 +1407,18 @@ extern "C" int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// achievable HBM bandwidth: a plain streaming copy (16 bytes per lane, grid-stride), timed with HIP events
-// on the context stream.  Reported next to the 8 TB/s nominal peak.
+// achievable HBM bandwidth: a plain streaming copy, timed with HIP events on the context stream.  Reported next to the
+// 8 TB/s nominal peak.  Shape: ONE 16-byte element per lane, one workgroup per 4 KiB, non-temporal load
+// and store -- measured on MI355X (tools/probe/copy_bw.hip, 1 GiB): 6.56 TB/s (6.24 with plain accesses), the
+// guide's 6.29 TB/s float4 copy.  A grid-stride loop over 2048-16384 resident workgroups, the usual shape elsewhere,
+// reaches only 4.4-5.2 TB/s here, and hipMemcpyAsync device-to-device 4.8.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16)
+typedef float lpx_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_kernel(const lpx_v4f *__restrict__ src, lpx_v4f *__restrict__ dst, size_t n16)
 {
-    // four independent 16-byte loads per lane and trip keep ~16 KiB in flight per workgroup
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride)
-    {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a;
-        dst[i + stride] = b;
-        dst[i + 2 * stride] = c;
-        dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride)
-        dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 extern "C" int lpx_dbg_copy_bandwidth(lpx_ctx *ctx, size_t bytes, uint32_t reps, double *gb_per_s)
@@ -1403,11 +1438,11 @@ extern "C" int lpx_dbg_copy_bandwidth(lpx_ctx *ctx, size_t bytes, uint32_t reps,
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const size_t n16 = bytes / 16;
-    const dim3 grid(256 * 8), blk(256);  // 8 workgroups per CU
-    hipLaunchKernelGGL(copy_kernel, grid, blk, 0, ctx->stream, (const float4 *)a, (float4 *)b, n16);  // warm-up
+    const dim3 grid((unsigned)((n16 + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(copy_kernel, grid, blk, 0, ctx->stream, (const lpx_v4f *)a, (lpx_v4f *)b, n16);  // warm-up
     hipEventRecord(e0, ctx->stream);
     for (uint32_t r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(copy_kernel, grid, blk, 0, ctx->stream, (const float4 *)a, (float4 *)b, n16);
+        hipLaunchKernelGGL(copy_kernel, grid, blk, 0, ctx->stream, (const lpx_v4f *)a, (lpx_v4f *)b, n16);
     hipEventRecord(e1, ctx->stream);
     hipEventSynchronize(e1);
     float ms = 0.0f;

@@ -36,6 +36,7 @@ __global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ 
                                uint32_t *__restrict__ valid, uint32_t *__restrict__ cc_lo,
                                uint32_t *__restrict__ cc_hi, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
     parent = lpx_slot(parent, fs);
     frame = lpx_slot(frame, fs);
     root = lpx_slot(root, fs);
@@ -44,7 +45,7 @@ __global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ 
     valid = lpx_slot(valid, fs);
     cc_lo = lpx_slot(cc_lo, fs);
     cc_hi = lpx_slot(cc_hi, fs);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i >= frame->n_obstacle)
         return;
     uint32_t x = i;
@@ -68,12 +69,13 @@ __global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, FrameState 
                                  uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi,
                                  uint32_t *__restrict__ roots, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
     sroot = lpx_slot(sroot, fs);
     frame = lpx_slot(frame, fs);
     cc_lo = lpx_slot(cc_lo, fs);
     cc_hi = lpx_slot(cc_hi, fs);
     roots = lpx_slot(roots, fs);
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = lpx_blk.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
     if (p >= M)
         return;
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
                                                                  int32_t *seed_of, uint32_t *queue, uint32_t *valid,
                                                                  ReplayParams prm, uint64_t cap, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<7>(fv.fs);
     frame = lpx_slot(frame, fv.fs);
     cc_lo = lpx_slot(cc_lo, fv.fs);
     cc_hi = lpx_slot(cc_hi, fv.fs);
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
     seed_of = lpx_slot(seed_of, fv.fs);
     queue = lpx_slot(queue, fv.fs);
     valid = lpx_slot(valid, fv.fs);
-    const uint32_t r = blockIdx.x * RP_WAVES + threadIdx.x / WAVE;
+    const uint32_t r = lpx_blk.x * RP_WAVES + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     const uint32_t M = frame->n_obstacle;
     if (r >= M || frame->nb_total > cap)
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                                                            const uint32_t *__restrict__ roots,
                                                            uint32_t *__restrict__ dbg, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<7>(fv.fs);
     extern __shared__ uint32_t sbits[];
     frame = lpx_slot(frame, fv.fs);
     fstate = lpx_slot(fstate, fv.fs);
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
     if (frame->nb_total > cap)
         return;
     const uint32_t n_roots = frame->n_roots;
-    if (blockIdx.x >= n_roots)
+    if (lpx_blk.x >= n_roots)
         return;
     // the bitmap is zeroed once: components own disjoint points, so the 2-bit states of one component
     // are never read by another
@@ -507,9 +511,12 @@ constexpr int RS_RING = LPX_RS_RING;         // queue entries mirrored in LDS, p
 #endif
 constexpr int RS_BATCH = LPX_RS_BATCH;                  // candidate chunks in flight per wavefront
 
+constexpr int RS_HITS = 128;  // list words of one expansion gathered per wavefront before they are applied
+
 struct RsShared  // fixed part of the LDS of replay_search_kernel (the bitmap follows)
 {
     uint32_t ring[RS_WAVES][RS_RING];
+    uint32_t hits[RS_WAVES][RS_HITS];
 };
 
 typedef float4 KdNode;
@@ -534,46 +541,52 @@ __device__ __forceinline__ unsigned long long rs_cull(const ChunkRec &ch, float 
     return __ballot(ch.count != 0u && (ex * ex + ey * ey + ez * ez) <= r2 * 1.0001f + 1.0e-6f);
 }
 
-// Tests the chunks named by the bits of `km` (lane c of `ch` describes chunk c) in order; SINK(word) gets the
-// per-lane list words of every chunk step.
-template <class Sink>
-__device__ __forceinline__ void rs_scan(const KdNode *__restrict__ PR, const ChunkRec &ch, unsigned long long km,
-                                        float qx, float qy, float qz, float r2, float thr_f, uint32_t lane,
-                                        unsigned long long &cand, Sink &&sink)
+// One batch of candidate chunks in flight: RS_BATCH independent 16-byte loads per lane.
+struct RsBatch
 {
-    while (km)
+    KdNode nd[RS_BATCH];
+    uint32_t cnt[RS_BATCH], rk[RS_BATCH];
+};
+
+// requests the next (up to RS_BATCH) chunks named by the bits of `km` (lane c of `ch` describes chunk c), in order
+__device__ __forceinline__ void rs_issue(RsBatch &b, const KdNode *__restrict__ PR, const ChunkRec &ch,
+                                         unsigned long long &km, uint32_t lane)
+{
+#pragma unroll
+    for (int u = 0; u < RS_BATCH; ++u)
     {
-        KdNode nd[RS_BATCH];
-        uint32_t cnt[RS_BATCH], rk[RS_BATCH];
-#pragma unroll
-        for (int u = 0; u < RS_BATCH; ++u)
+        b.cnt[u] = 0u;
+        b.rk[u] = 0u;
+        if (km)
         {
-            cnt[u] = 0u;
-            rk[u] = 0u;
-            if (km)
-            {
-                const int c = __ffsll((long long)km) - 1;
-                km &= km - 1;
-                rk[u] = (uint32_t)__builtin_amdgcn_readlane((int)ch.rank, c);
-                cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)ch.count, c);
-            }
-            nd[u] = PR[lane < cnt[u] ? rk[u] + lane : 0u];  // unconditional: the loads of a batch go out back to back
+            const int c = __ffsll((long long)km) - 1;
+            km &= km - 1;
+            b.rk[u] = (uint32_t)__builtin_amdgcn_readlane((int)ch.rank, c);
+            b.cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)ch.count, c);
         }
+        b.nd[u] = PR[lane < b.cnt[u] ? b.rk[u] + lane : 0u];  // unconditional: the loads of a batch go out back to back
+    }
+}
+
+// distance-tests the chunks of a batch in order; SINK(word) gets the per-lane list words of every chunk step
+template <class Sink>
+__device__ __forceinline__ void rs_consume(const RsBatch &b, const KdNode *__restrict__ PR, float qx, float qy, float qz,
+                                           float r2, float thr_f, uint32_t lane, unsigned long long &cand, Sink &&sink)
+{
 #pragma unroll
-        for (int u = 0; u < RS_BATCH; ++u)
+    for (int u = 0; u < RS_BATCH; ++u)
+    {
+        if (b.cnt[u] == 0u)
+            break;
+        cand += min(b.cnt[u], 64u);
+        sink(rs_test(b.nd[u], lane < b.cnt[u], qx, qy, qz, r2, thr_f));
+        // the long tail chunk of a group with more than 64 chunks: the rest of its ranks, 64 at a time
+        for (uint32_t o = 64; o < b.cnt[u]; o += 64)
         {
-            if (cnt[u] == 0u)
-                break;
-            cand += min(cnt[u], 64u);
-            sink(rs_test(nd[u], lane < cnt[u], qx, qy, qz, r2, thr_f));
-            // the long tail chunk of a group with more than 64 chunks: the rest of its ranks, 64 at a time
-            for (uint32_t o = 64; o < cnt[u]; o += 64)
-            {
-                const bool v = o + lane < cnt[u];
-                const KdNode n2 = PR[v ? rk[u] + o + lane : 0u];
-                cand += min(cnt[u] - o, 64u);
-                sink(rs_test(n2, v, qx, qy, qz, r2, thr_f));
-            }
+            const bool v = o + lane < b.cnt[u];
+            const KdNode n2 = PR[v ? b.rk[u] + o + lane : 0u];
+            cand += min(b.cnt[u] - o, 64u);
+            sink(rs_test(n2, v, qx, qy, qz, r2, thr_f));
         }
     }
 }
@@ -586,6 +599,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const float *__restrict__ OZ, uint8_t *gstate, int32_t *seed_of, uint32_t *queue, uint32_t *valid,
     ReplayParams prm, FrameState *fstate, const uint32_t *__restrict__ roots, uint32_t m_lo, uint32_t m_hi, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<7>(fv.fs);
     extern __shared__ uint32_t smem[];
     RsShared &sh = *(RsShared *)smem;
     uint32_t *sbits = smem + sizeof(RsShared) / sizeof(uint32_t);
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const uint32_t M = frame->n_obstacle;
     const uint32_t n_roots = frame->n_roots;
     // frames outside (m_lo, m_hi] obstacle points belong to the other launch (an empty frame to none)
-    if (M <= m_lo || M > m_hi || blockIdx.x * RS_WAVES >= n_roots)
+    if (M <= m_lo || M > m_hi || lpx_blk.x * RS_WAVES >= n_roots)
         return;
     if (STATE_LDS)
     {
@@ -706,6 +720,37 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 if (!STATE_LDS)
                     __threadfence_block();  // the next step reads states written by other lanes
             };
+            // The list words of an expansion (the hits of its candidate chunks, in candidate = pre-order order) are
+            // gathered in LDS first and applied 64 at a time: a chunk of 64 candidates holds ~5 hits on a KITTI frame,
+            // and applying chunk by chunk paid one state read, three ballots and the LDS atomics for every chunk with a
+            // hit (56-59 % of a sequencer's time); gathering costs one ballot and one LDS store per chunk.
+            volatile uint32_t *hb = sh.hits[w];
+            uint32_t hc = 0;  // words gathered (wave-uniform)
+            auto flush64 = [&]() {
+                __builtin_amdgcn_wave_barrier();  // one wavefront, in-order LDS: the stores above are visible
+                apply(lane < hc ? hb[lane] : 0xffffffffu);
+                if (hc > (uint32_t)WAVE)
+                {
+                    const uint32_t mv = lane < hc - WAVE ? hb[WAVE + lane] : 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < hc - WAVE)
+                        hb[lane] = mv;
+                    hc -= WAVE;
+                }
+                else
+                    hc = 0;
+            };
+            auto collect = [&](uint32_t word) {
+                const bool in = word != 0xffffffffu;
+                const unsigned long long im = __ballot(in);
+                if (!im)
+                    return;  // no candidate of this chunk is a neighbour
+                if (in)
+                    hb[hc + __popcll(im & lt)] = word;
+                hc += __popcll(im);
+                if (hc >= (uint32_t)WAVE)
+                    flush64();
+            };
             while (qh < qt)
             {
                 // a window of up to 64 pops; which of them the reference expands is decided in registers (see
@@ -744,16 +789,21 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 if (!em)
                     continue;
                 ++st_win;
-                // the expansions of the window, in order; the chunk table of the next one is requested before the
-                // current one is searched
+                // The expansions of the window, in order.  Which points a window expands is known up front and a search
+                // does not depend on the point states, so the searches are software-pipelined: the chunk table of
+                // expansion i + 1 is requested before expansion i is searched, and the first candidate batch of i + 1
+                // goes out before the hits of i are applied (the LDS work of the apply then runs under those loads).
                 int e = __ffsll((long long)em) - 1;
                 em &= em - 1;
                 ChunkRec ch = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, e) * LPX_GROUP_CHUNKS + lane];
+                float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), e));
+                float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), e));
+                float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), e));
+                unsigned long long km = rs_cull(ch, qx, qy, qz, r2);
+                RsBatch bt;
+                rs_issue(bt, PR, ch, km, lane);
                 for (;;)
                 {
-                    const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), e));
-                    const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), e));
-                    const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), e));
                     const int e_next = em ? __ffsll((long long)em) - 1 : -1;
                     ChunkRec ch_next = ch;
                     if (e_next >= 0)
@@ -762,11 +812,26 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                         ch_next = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, e_next) * LPX_GROUP_CHUNKS + lane];
                     }
                     ++st_exp;
-                    rs_scan(PR, ch, rs_cull(ch, qx, qy, qz, r2), qx, qy, qz, r2, thr_f, lane, st_cand, apply);
+                    rs_consume(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
+                    while (km)
+                    {
+                        rs_issue(bt, PR, ch, km, lane);
+                        rs_consume(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
+                    }
+                    if (e_next >= 0)
+                    {
+                        e = e_next;
+                        ch = ch_next;
+                        qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), e));
+                        qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), e));
+                        qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), e));
+                        km = rs_cull(ch, qx, qy, qz, r2);
+                        rs_issue(bt, PR, ch, km, lane);
+                    }
+                    while (hc)
+                        flush64();  // the hits of the expansion just searched, before any hit of the next one
                     if (e_next < 0)
                         break;
-                    e = e_next;
-                    ch = ch_next;
                 }
             }
             if (lane == 0)
@@ -789,20 +854,21 @@ __global__ void relabel_kernel(FrameState *frame, const int32_t *__restrict__ se
                                int32_t *__restrict__ labels, uint64_t cap, const uint64_t *__restrict__ total,
                                uint32_t *__restrict__ counts, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<6>(fv.fs);
     frame = lpx_slot(frame, fv.fs);
     seed_of = lpx_slot(seed_of, fv.fs);
     valid = lpx_slot(valid, fv.fs);
     dense = lpx_slot(dense, fv.fs);
     total = lpx_slot(total, fv.fs);
     labels = lpx_user(labels, fv.upitch);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i == 0)
     {
         const uint32_t nc = (uint32_t)*total;  // number of valid seeds = number of clusters
         frame->n_clusters = nc;
         if (counts)  // last kernel of the call: hand the frame counts to the caller
         {
-            counts += 4 * (size_t)blockIdx.z;
+            counts += 4 * (size_t)lpx_blk.z;
             counts[0] = frame->n_ground;
             counts[1] = frame->n_obstacle;
             counts[2] = nc;
@@ -831,7 +897,8 @@ __global__ void relabel_kernel(FrameState *frame, const int32_t *__restrict__ se
 __global__ void group_keys_kernel(const int32_t *__restrict__ labels, uint32_t m, uint32_t *__restrict__ key,
                                   uint32_t *__restrict__ val)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const LpxBlock lpx_blk = lpx_block<6>(0);
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i >= m)
         return;
     const int32_t l = labels[i];
@@ -842,7 +909,8 @@ __global__ void group_keys_kernel(const int32_t *__restrict__ labels, uint32_t m
 __global__ void group_offsets_kernel(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval, uint32_t m,
                                      uint32_t *__restrict__ offsets, uint32_t *__restrict__ indices)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const LpxBlock lpx_blk = lpx_block<6>(0);
+    const uint32_t p = lpx_blk.x * blockDim.x + threadIdx.x;
     if (p >= m)
         return;
     const uint32_t k = skey[p];
@@ -877,7 +945,8 @@ __global__ void hull_key_kernel(const uint32_t *__restrict__ vals, const float *
                                 const int32_t *__restrict__ labels, const uint32_t *__restrict__ d_n,
                                 uint32_t *__restrict__ key)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const LpxBlock lpx_blk = lpx_block<6>(0);
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i >= *d_n)
         return;
     const uint32_t v = vals[i];
@@ -897,7 +966,8 @@ __global__ void hull_chain_kernel(const uint32_t *__restrict__ off, const uint32
                                   uint32_t *__restrict__ st_idx, float2 *__restrict__ st_xy,
                                   uint32_t *__restrict__ hull_len)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const LpxBlock lpx_blk = lpx_block<6>(0);
+    const uint32_t c = lpx_blk.x * blockDim.x + threadIdx.x;
     const uint32_t nc = frame->n_clusters;
     if (c > nc)
         return;
@@ -1057,7 +1127,8 @@ __global__ void hull_pack_kernel(const uint32_t *__restrict__ off, const uint32_
                                  const uint32_t *__restrict__ hull_off, uint32_t *__restrict__ out_idx,
                                  float2 *__restrict__ out_xy)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const LpxBlock lpx_blk = lpx_block<6>(0);
+    const uint32_t p = lpx_blk.x * blockDim.x + threadIdx.x;
     if (p >= *d_n)
         return;
     const uint32_t c = slabel[p];  // position p of the sorted point list belongs to cluster c

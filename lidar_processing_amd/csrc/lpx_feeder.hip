@@ -443,6 +443,16 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
             FHIP(l, hipMemcpyAsync(out->planes + (size_t)lo * 4 * P, o.planes, sizeof(float) * 4 * P * nb,
                                    hipMemcpyDeviceToHost, l->d2h));
         FHIP(l, hipEventRecord(l->ev_d2h[s], l->d2h));
+        // a frame the device flagged (non-finite coordinates; neighbour lists that did not fit a LISTS-mode context)
+        // has no valid labels: the run reports the first such frame instead of LPX_OK (counts[] keeps every status)
+        for (uint32_t b = 0; b < nb; ++b)
+            if (hc[4 * b + 3] != 0u)
+            {
+                char msg[96];
+                snprintf(msg, sizeof msg, "frame %u of the run (file %u): device status %d", lo + b, a.frame_ids[lo + b],
+                         -(int)hc[4 * b + 3]);
+                return ffail(l, -(int)hc[4 * b + 3], "%s", msg);
+            }
         return LPX_OK;
     };
 

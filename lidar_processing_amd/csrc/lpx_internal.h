@@ -145,11 +145,16 @@ struct lpx_ctx
     uint32_t upitch = 0;       // pitch of the caller arrays of that call
     void *arena = nullptr, *nb_arena = nullptr;
     size_t fstride = 0, nb_fstride = 0;
+    size_t fs_tag = 0;         // fstride | families whose launches re-read their workgroup number (what kernels get)
 
     // ---- segmentation buffers (cap_n) ----
     Buf in_aos;                // staging for host input
     Buf rec_out;               // staging for the coloured-cloud records handed to the host
     uint32_t last_n = 0;       // points of the last single-frame segmentation (bounds n_ground + n_obstacle)
+    // host-side memory of the last HOST segmentation call: what lpx_coloured_clouds may copy out.  Cleared by every
+    // other call that re-initialises the frame state or may move the arena (cluster, device and batch entry points).
+    bool seg_valid = false;
+    uint32_t seg_ground = 0, seg_obstacle = 0;
     Buf pts4;                  // the cloud in original order, float4 {x, y, z, 0} per point
     Buf key_a, key_b;          // u32 keys ping-pong
     Buf val_a, val_b;          // u32 values ping-pong
@@ -216,7 +221,7 @@ struct lpx_ctx
 static inline FV lpx_fv(const lpx_ctx *ctx)
 {
     FV fv;
-    fv.fs = ctx->fstride;
+    fv.fs = ctx->fs_tag;
     fv.fs_nb = ctx->nb_fstride;
     fv.upitch = ctx->upitch;
     fv.pad = 0;
@@ -310,18 +315,67 @@ int lpx_ensure_lists(lpx_ctx *ctx);
 
 #define WAVE 64
 
-// slot `blockIdx.z` of an arena buffer (null stays null)
-template <class T>
-__device__ __forceinline__ T *lpx_slot(T *p, size_t stride_bytes)
+// XCD-affine launch geometry.  A launch covers the frames of a call with gridDim.z, and the hardware deals the
+// workgroups of a launch round-robin over the 8 XCDs in linear order (x fastest, z slowest): with the plain
+// (blockIdx.x, blockIdx.z) = (tile, frame) reading, every XCD works on every frame, so each of the eight private,
+// mutually non-coherent 4 MiB L2s fetches its own copy of every table a frame's workgroups share (hash cells, kd
+// nodes, chunk tables, label lines that sixteen scattered stores fill) and writes back its own partial lines.
+// lpx_block() re-reads the linear workgroup number so that the workgroups an XCD receives belong to the frames
+// z = c, c + 8, c + 16, ... of ITS residue c: a frame then lives in one L2.  A bijection on the grid for the first
+// gridDim.z & ~7 frames, the identity for the rest (and for single-frame launches); placement is a matter of
+// speed only, nothing depends on which XCD a workgroup really gets.
+// Kernel families (template argument of lpx_block): 0 streaming kernels of the segmentation, 1 sorts and scans, 2 seeds
+// and plane passes, 3 kd build, 4 neighbour tables, 5 component grid, 6 component ranges / labels / groups, 7 replay.
+// Which families re-read their workgroup number is a property of the LAUNCH (every workgroup of a launch must agree):
+// the host passes it in the low byte of the frame-arena stride that every kernel receives (the stride is a multiple of
+// 256): bit g = family g.  The host's choice: lpx_remap_mask() in lpx_api.hip.
+#define LPX_FS_TAG_MASK ((size_t)255)
+struct LpxBlock
 {
-    return p ? (T *)((char *)p + (size_t)blockIdx.z * stride_bytes) : p;
-}
-// frame `blockIdx.z` of a caller array pitched by `pitch` elements
-template <class T>
-__device__ __forceinline__ T *lpx_user(T *p, uint32_t pitch)
+    uint32_t x, y, z;
+};
+template <int FAMILY>
+__device__ __forceinline__ LpxBlock lpx_block(size_t tagged_stride)
 {
-    return p ? p + (size_t)blockIdx.z * pitch : p;
+    LpxBlock b = {blockIdx.x, blockIdx.y, blockIdx.z};
+    if ((((uint32_t)tagged_stride >> FAMILY) & 1u) && blockIdx.z < (gridDim.z & ~7u))
+    {
+        // the 8 frames z = 8 g + s (s = 0..7) of a group occupy 8 nxy consecutive linear workgroup numbers that start at
+        // a multiple of 8: number l inside the group lands on XCD l & 7 and becomes tile l >> 3 of frame 8 g + (l & 7)
+        const uint32_t s = blockIdx.z & 7u;
+        if (gridDim.y == 1u)
+        {
+            const uint32_t l = blockIdx.x + gridDim.x * s;
+            b.x = l >> 3;
+            b.z = (blockIdx.z & ~7u) + (l & 7u);
+        }
+        else
+        {
+            const uint32_t l = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * s), r = l >> 3;
+            b.y = r / gridDim.x;
+            b.x = r - b.y * gridDim.x;
+            b.z = (blockIdx.z & ~7u) + (l & 7u);
+        }
+    }
+    return b;
 }
+
+// Every kernel starts with `const LpxBlock lpx_blk = lpx_block();` (one evaluation per workgroup); lpx_slot /
+// lpx_user and the tile indices read that.
+// slot `lpx_blk.z` of an arena buffer (null stays null)
+template <class T>
+__device__ __forceinline__ T *lpx_slot_z(T *p, size_t stride_bytes, uint32_t z)
+{
+    return p ? (T *)((char *)p + (size_t)z * (stride_bytes & ~LPX_FS_TAG_MASK)) : p;
+}
+// frame `lpx_blk.z` of a caller array pitched by `pitch` elements
+template <class T>
+__device__ __forceinline__ T *lpx_user_z(T *p, uint32_t pitch, uint32_t z)
+{
+    return p ? p + (size_t)z * pitch : p;
+}
+#define lpx_slot(p, stride_bytes) lpx_slot_z((p), (stride_bytes), lpx_blk.z)
+#define lpx_user(p, pitch) lpx_user_z((p), (pitch), lpx_blk.z)
 
 // order-preserving key of a float under operator< with -0 == +0 (ties are broken by index later)
 __device__ __forceinline__ uint32_t lpx_float_key(float f)

@@ -521,6 +521,7 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
                                                           int BLK_CAP, int STAGE_CAP,
                                                           const KdTopState *__restrict__ top, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<3>(fs);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     nodes = lpx_slot(nodes, fs);
     lpos = lpx_slot(lpos, fs);
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     int b = 0, e = (int)frame->n_obstacle;
     if ((e >> level) <= BLK_CAP)
         return;  // this level already belongs to kd_lds_kernel (the host planned with an upper bound)
-    descend(b, e, blockIdx.x, level);
+    descend(b, e, lpx_blk.x, level);
     if (e - b < 2)
         return;
     const int axis = level % 3;
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     if (top)
     {
         // the multi-workgroup rounds (kd_top_*) have narrowed the range: continue the same introselect loop
-        const KdTopState st = lpx_slot(top, fs)[blockIdx.x];
+        const KdTopState st = lpx_slot(top, fs)[lpx_blk.x];
         first = st.first;
         last = st.last;
         depth_limit = st.depth;
@@ -618,12 +619,13 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
 __global__ void kd_top_pivot(Node *nodes, const uint32_t *__restrict__ lpos, const uint32_t *__restrict__ rasc,
                              const FrameState *__restrict__ frame, KdTopState *state, int level, int init, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<3>(fs);
     nodes = lpx_slot(nodes, fs);
     lpos = lpx_slot(lpos, fs);
     rasc = lpx_slot(rasc, fs);
     frame = lpx_slot(frame, fs);
     state = lpx_slot(state, fs);
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = lpx_blk.x * blockDim.x + threadIdx.x;
     if (r >= (1u << level))
         return;
     KdTopState st = state[r];
@@ -676,16 +678,17 @@ __global__ __launch_bounds__(TOP_THREADS) void kd_top_flags(const Node *__restri
                                                             const KdTopState *__restrict__ state,
                                                             uint2 *__restrict__ tile_cnt, int level, int tiles, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<3>(fs);
     __shared__ uint32_t s_l[TOP_THREADS / WAVE], s_r[TOP_THREADS / WAVE];
     nodes = lpx_slot(nodes, fs);
     state = lpx_slot(state, fs);
     tile_cnt = lpx_slot(tile_cnt, fs);
-    const uint32_t r = blockIdx.y;
+    const uint32_t r = lpx_blk.y;
     const KdTopState st = state[r];
     if (!st.active)
         return;
     const int axis = level % 3;
-    const int p0 = st.first + 1 + (int)blockIdx.x * TOP_TILE;
+    const int p0 = st.first + 1 + (int)lpx_blk.x * TOP_TILE;
     uint32_t cl = 0, cr = 0;
     if (p0 < st.last)
     {
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(TOP_THREADS) void kd_top_flags(const Node *__restri
             a += s_l[i];
             b += s_r[i];
         }
-        tile_cnt[(size_t)r * tiles + blockIdx.x] = make_uint2(a, b);
+        tile_cnt[(size_t)r * tiles + lpx_blk.x] = make_uint2(a, b);
     }
 }
 
@@ -723,6 +726,7 @@ __global__ __launch_bounds__(TOP_THREADS) void kd_top_lists(const Node *__restri
                                                             uint32_t *__restrict__ lpos, uint32_t *__restrict__ rasc,
                                                             int level, int tiles, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<3>(fs);
     __shared__ uint32_t s_a[TOP_THREADS / WAVE], s_b[TOP_THREADS / WAVE];
     __shared__ uint32_t s_base[2];
     nodes = lpx_slot(nodes, fs);
@@ -730,18 +734,18 @@ __global__ __launch_bounds__(TOP_THREADS) void kd_top_lists(const Node *__restri
     tile_cnt = lpx_slot(tile_cnt, fs);
     lpos = lpx_slot(lpos, fs);
     rasc = lpx_slot(rasc, fs);
-    const uint32_t r = blockIdx.y;
+    const uint32_t r = lpx_blk.y;
     const KdTopState st = state[r];
     if (!st.active)
         return;
     const int axis = level % 3;
     const int span = st.last - st.first - 1;
     const int used = (span + TOP_TILE - 1) / TOP_TILE;  // tiles that hold positions this round
-    if ((int)blockIdx.x >= used)
+    if ((int)lpx_blk.x >= used)
         return;
     // exclusive prefix of the tile counts before this tile (and, in the last tile, the totals)
     uint32_t bl = 0, br = 0;
-    for (int t = (int)threadIdx.x; t < (int)blockIdx.x; t += TOP_THREADS)
+    for (int t = (int)threadIdx.x; t < (int)lpx_blk.x; t += TOP_THREADS)
     {
         const uint2 c = tile_cnt[(size_t)r * tiles + t];
         bl += c.x;
@@ -765,16 +769,16 @@ __global__ __launch_bounds__(TOP_THREADS) void kd_top_lists(const Node *__restri
         }
         s_base[0] = a;
         s_base[1] = b;
-        if ((int)blockIdx.x == used - 1)
+        if ((int)lpx_blk.x == used - 1)
         {
-            const uint2 c = tile_cnt[(size_t)r * tiles + blockIdx.x];
+            const uint2 c = tile_cnt[(size_t)r * tiles + lpx_blk.x];
             state[r].cntL = (int)(a + c.x);
             state[r].cntR = (int)(b + c.y);
         }
     }
     __syncthreads();
     uint32_t runL = s_base[0], runR = s_base[1];
-    const int p0 = st.first + 1 + (int)blockIdx.x * TOP_TILE;
+    const int p0 = st.first + 1 + (int)lpx_blk.x * TOP_TILE;
     const int p1 = min(p0 + TOP_TILE, st.last);
     const unsigned long long lt = lpx_lanemask_lt();
     const uint32_t w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
@@ -821,17 +825,18 @@ __global__ __launch_bounds__(TOP_THREADS) void kd_top_swap(Node *nodes, KdTopSta
                                                            const uint32_t *__restrict__ lpos,
                                                            const uint32_t *__restrict__ rasc, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<3>(fs);
     nodes = lpx_slot(nodes, fs);
     state = lpx_slot(state, fs);
     lpos = lpx_slot(lpos, fs);
     rasc = lpx_slot(rasc, fs);
-    const uint32_t r = blockIdx.y;
+    const uint32_t r = lpx_blk.y;
     const KdTopState st = state[r];
     if (!st.active)
         return;
     const int kmax = min(st.cntL, st.cntR);
     uint32_t my = 0;
-    for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < kmax; k += (int)(gridDim.x * blockDim.x))
+    for (int k = (int)(lpx_blk.x * blockDim.x + threadIdx.x); k < kmax; k += (int)(gridDim.x * blockDim.x))
     {
         const int sl = (int)lpos[st.first + k], sr = (int)rasc[st.first + st.cntR - 1 - k];
         if (sl < sr)
@@ -922,6 +927,7 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
                                                     const FrameState *__restrict__ frame,
                                                     uint32_t *__restrict__ dbg, int BLK_CAP, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<3>(fs);
     nodes = lpx_slot(nodes, fs);
     PR = lpx_slot(PR, fs);
     frame = lpx_slot(frame, fs);
@@ -939,14 +945,14 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
     int lv = 0;
     while ((M >> lv) > BLK_CAP)
         ++lv;
-    if (blockIdx.x >= (1u << lv))
+    if (lpx_blk.x >= (1u << lv))
         return;
     int b = 0, e = M;
-    descend(b, e, blockIdx.x, lv);
+    descend(b, e, lpx_blk.x, lv);
     const int n = e - b;
     // the split nodes above this kernel's level are final already: block 0 copies them to the
     // pre-order layout (every other node is copied by the block that owns its range)
-    if (blockIdx.x == 0)
+    if (lpx_blk.x == 0)
         for (uint32_t h = tid; h + 1 < (1u << lv); h += LG)
         {
             const int l = 31 - __clz(h + 1);
@@ -1112,7 +1118,7 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
         if (!done && gl == 0)
             seq_insertion_sort(v, first, last, axis);
         __syncthreads();
-        if (dbg && tid == 0 && blockIdx.x == 0 && s < 12)
+        if (dbg && tid == 0 && lpx_blk.x == 0 && s < 12)
         {
             dbg[2 * s] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
             dbg[2 * s + 1] = n_rounds;
@@ -1127,7 +1133,7 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
             seq_build_subtree(v, rb, re, lv + s);
     }
     __syncthreads();
-    if (dbg && tid == 0 && blockIdx.x == 0)
+    if (dbg && tid == 0 && lpx_blk.x == 0)
     {
         dbg[30] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
         dbg[31] = (uint32_t)n;
@@ -1353,6 +1359,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
                                                                uint32_t *__restrict__ parent,
                                                                uint32_t *__restrict__ dbg, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
     __shared__ Item s_seq[NB_SEQ];
     PR = lpx_slot(PR, fv.fs);
     frame = lpx_slot(frame, fv.fs);
@@ -1376,17 +1383,17 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
         ++D;
     const uint32_t nbk = 1u << D;
     // blocks [0, nbk): one bucket group each; blocks [nbk, ...): four single-node groups each
-    const bool BLOCK = blockIdx.x < nbk;
+    const bool BLOCK = lpx_blk.x < nbk;
     uint32_t level, path, gid;
     if (BLOCK)
     {
-        gid = blockIdx.x;
+        gid = lpx_blk.x;
         level = D;
         path = gid;
     }
     else
     {
-        const uint32_t u = (blockIdx.x - nbk) * NB_WAVES + w;
+        const uint32_t u = (lpx_blk.x - nbk) * NB_WAVES + w;
         if (u >= nbk - 1)
             return;
         gid = nbk + u;
@@ -1758,9 +1765,10 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
 // list checks every edge: equal roots (the common case) cost one cached load, the rest are united.
 __global__ void cc_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *parent, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<4>(fs);
     frame = lpx_slot(frame, fs);
     parent = lpx_slot(parent, fs);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i >= frame->n_obstacle)
         return;
     if (frame->status)  // the lists did not fit: groups returned before they wrote their parents (caller retries)
@@ -1783,6 +1791,7 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
                                                        const uint32_t *__restrict__ nb_idx, uint32_t *parent,
                                                        uint64_t cap, uint32_t roots_only, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
     frame = lpx_slot(frame, fv.fs);
     off = lpx_slot(off, fv.fs);
     len = lpx_slot(len, fv.fs);
@@ -1793,7 +1802,7 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
     if (frame->nb_total > cap)
         return;
     const uint32_t stride = gridDim.x * (blockDim.x / WAVE);
-    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE; i < M; i += stride)
+    for (uint32_t i = (lpx_blk.x * blockDim.x + threadIdx.x) / WAVE; i < M; i += stride)
     {
         // roots_only: a first, cheap round over the lists of the forest's roots alone.  A root has no
         // smaller neighbour; any neighbour that hangs under another tree merges the two, which removes
@@ -1863,6 +1872,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
                                                                uint32_t *__restrict__ grp_of, uint32_t spine_max,
                                                                uint32_t bucket, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
     __shared__ Item s_seq[NB_WAVES][2 * IX_CAPS];
     __shared__ uint32_t s_pre[NB_WAVES][IX_CAPS + 8];
     __shared__ uint32_t s_mrank[NB_WAVES][IX_CAPS + 8], s_mpre[NB_WAVES][IX_CAPS + 8];
@@ -1879,7 +1889,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
     while ((M >> D) > bucket)
         ++D;
     const uint32_t nbk = 1u << D;
-    const uint32_t gid = blockIdx.x * NB_WAVES + w;  // [0, nbk): buckets; [nbk, 2 nbk - 1): upper nodes
+    const uint32_t gid = lpx_blk.x * NB_WAVES + w;  // [0, nbk): buckets; [nbk, 2 nbk - 1): upper nodes
     if (gid >= 2 * nbk - 1)
         return;
     uint32_t level, path;
@@ -2160,11 +2170,12 @@ __global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long 
                                   uint32_t *__restrict__ tparent, uint32_t *__restrict__ thead, uint32_t cap_max,
                                   size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<5>(fs);
     frame = lpx_slot(frame, fs);
     tkey = lpx_slot(tkey, fs);
     tparent = lpx_slot(tparent, fs);
     thead = lpx_slot(thead, fs);
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = lpx_blk.x * blockDim.x + threadIdx.x;
     if (s == 0)
     {
         frame->n_cells = 0;
@@ -2183,6 +2194,7 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
                                    uint32_t *__restrict__ cells, uint32_t *__restrict__ cell_of,
                                    float4 *__restrict__ trep, uint32_t cap_max, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<5>(fs);
     trep = lpx_slot(trep, fs);
     frame = lpx_slot(frame, fs);
     OX = lpx_slot(OX, fs);
@@ -2193,7 +2205,7 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
     next = lpx_slot(next, fs);
     cells = lpx_slot(cells, fs);
     cell_of = lpx_slot(cell_of, fs);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
     if (i >= M)
         return;
@@ -2230,11 +2242,12 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
 __global__ void grid_alloc_kernel(FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
                                   const uint32_t *__restrict__ tcount, uint32_t *__restrict__ tstart, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<5>(fs);
     frame = lpx_slot(frame, fs);
     cells = lpx_slot(cells, fs);
     tcount = lpx_slot(tcount, fs);
     tstart = lpx_slot(tstart, fs);
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = lpx_blk.x * blockDim.x + threadIdx.x;
     if (c >= frame->n_cells)
         return;
     const uint32_t h = cells[c];
@@ -2247,6 +2260,7 @@ __global__ void grid_scatter_kernel(const FrameState *__restrict__ frame, const 
                                     const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ rank,
                                     const uint32_t *__restrict__ tstart, float4 *__restrict__ cpts, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<5>(fs);
     frame = lpx_slot(frame, fs);
     OX = lpx_slot(OX, fs);
     OY = lpx_slot(OY, fs);
@@ -2255,7 +2269,7 @@ __global__ void grid_scatter_kernel(const FrameState *__restrict__ frame, const 
     rank = lpx_slot(rank, fs);
     tstart = lpx_slot(tstart, fs);
     cpts = lpx_slot(cpts, fs);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i >= frame->n_obstacle)
         return;
     cpts[tstart[cell_of[i]] + rank[i]] = make_float4(OX[i], OY[i], OZ[i], __uint_as_float(i));
@@ -2285,6 +2299,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(const FrameState *__res
                                                          const float4 *__restrict__ trep, float r2, uint32_t cap_max,
                                                          int dbg, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<5>(fs);
     trep = lpx_slot(trep, fs);
     frame = lpx_slot(frame, fs);
     tkey = lpx_slot(tkey, fs);
@@ -2300,7 +2315,7 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(const FrameState *__res
     constexpr uint32_t P = FAR ? 49u : 13u;
     const unsigned long long total = (unsigned long long)frame->n_cells * P;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
+    for (unsigned long long item = (unsigned long long)lpx_blk.x * blockDim.x + threadIdx.x; item < total; item += stride)
     {
         const uint32_t c = (uint32_t)(item / P), j = (uint32_t)(item % P);
         int dx, dy, dz;
@@ -2382,10 +2397,11 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(const FrameState *__res
 __global__ void grid_compress_kernel(const FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
                                      uint32_t *tparent, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<5>(fs);
     frame = lpx_slot(frame, fs);
     cells = lpx_slot(cells, fs);
     tparent = lpx_slot(tparent, fs);
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = lpx_blk.x * blockDim.x + threadIdx.x;
     if (c >= frame->n_cells)
         return;
     const uint32_t s = cells[c];
@@ -2405,6 +2421,7 @@ __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32
                                     uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
                                     uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<5>(fs);
     frame = lpx_slot(frame, fs);
     tparent = lpx_slot(tparent, fs);
     tstart = lpx_slot(tstart, fs);
@@ -2415,7 +2432,7 @@ __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32
     valid = lpx_slot(valid, fs);
     cc_lo = lpx_slot(cc_lo, fs);
     cc_hi = lpx_slot(cc_hi, fs);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i >= frame->n_obstacle)
         return;
     uint32_t x = cell_of[i];
@@ -2436,7 +2453,8 @@ __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32
 
 __global__ void layout_idx_kernel(const Node *__restrict__ nodes, uint32_t m, uint32_t *__restrict__ out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const LpxBlock lpx_blk = lpx_block<3>(0);
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i < m)
         out[i] = __float_as_uint(nodes[i].w);
 }
@@ -2509,15 +2527,15 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
                 {
                     hipLaunchKernelGGL(kd_top_pivot, gp, dim3(64), 0, ctx->stream, nodes, (const uint32_t *)lpos,
                                        (const uint32_t *)rasc, frame, state, level, r == 0 ? 1 : (r == rounds ? 2 : 0),
-                                       ctx->fstride);
+                                       ctx->fs_tag);
                     if (r == rounds)
                         break;  // the last call only applies the last cut
                     hipLaunchKernelGGL(kd_top_flags, gt, dim3(TOP_THREADS), 0, ctx->stream, (const Node *)nodes,
-                                       (const KdTopState *)state, tile_cnt, level, tiles, ctx->fstride);
+                                       (const KdTopState *)state, tile_cnt, level, tiles, ctx->fs_tag);
                     hipLaunchKernelGGL(kd_top_lists, gt, dim3(TOP_THREADS), 0, ctx->stream, (const Node *)nodes, state,
-                                       (const uint2 *)tile_cnt, lpos, rasc, level, tiles, ctx->fstride);
+                                       (const uint2 *)tile_cnt, lpos, rasc, level, tiles, ctx->fs_tag);
                     hipLaunchKernelGGL(kd_top_swap, gs, dim3(TOP_THREADS), 0, ctx->stream, nodes, state,
-                                       (const uint32_t *)lpos, (const uint32_t *)rasc, ctx->fstride);
+                                       (const uint32_t *)lpos, (const uint32_t *)rasc, ctx->fs_tag);
                 }
                 top = state;
             }
@@ -2525,16 +2543,16 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
         hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G),
                            (stage ? blk_lds : 64 * sizeof(uint32_t)) + key_lds, ctx->stream, nodes, lpos, rasc, frame, level,
                            blk_cap,
-                           stage ? blk_cap : 0, top, ctx->fstride);
+                           stage ? blk_cap : 0, top, ctx->fs_tag);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
     if (ctx->cur_b > 1)
         hipLaunchKernelGGL(kd_lds_kernel<uint16_t>, dim3(1u << level, 1, ctx->cur_b), dim3(LG), lds_lds, ctx->stream, nodes,
-                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fstride);
+                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fs_tag);
     else
         hipLaunchKernelGGL(kd_lds_kernel<uint32_t>, dim3(1u << level, 1, ctx->cur_b), dim3(LG), blk_lds, ctx->stream, nodes,
-                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fstride);
+                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fs_tag);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
@@ -2568,7 +2586,7 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
     {
         StageTimer tm(ctx, ST_NB_SCAN);
         hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
-                           (uint32_t *)ctx->parent.p, ctx->fstride);
+                           (uint32_t *)ctx->parent.p, ctx->fs_tag);
         const uint32_t hgrid = (m_max + 3) / 4 < 4096u ? (m_max + 3) / 4 : 4096u;
         for (uint32_t roots_only = 1;; roots_only = 0)
         {
@@ -2578,7 +2596,7 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
             if (!roots_only)
                 break;
             hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream,
-                               frame, (uint32_t *)ctx->parent.p, ctx->fstride);
+                               frame, (uint32_t *)ctx->parent.p, ctx->fs_tag);
         }
     }
     LPX_HIP(ctx, hipGetLastError());
@@ -2640,17 +2658,17 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     uint32_t *tparent = (uint32_t *)ctx->cell_parent.p, *thead = (uint32_t *)ctx->cell_rep.p;
     uint32_t *next = (uint32_t *)ctx->parent.p, *cells = (uint32_t *)ctx->lpos.p;  // free in this path
     hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, thead, ctx->cell_cap,
-                       ctx->fstride);
+                       ctx->fs_tag);
     hipLaunchKernelGGL(grid_insert_kernel, gm, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells,
-                       (uint32_t *)ctx->cell_of.p, (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fstride);
+                       (uint32_t *)ctx->cell_of.p, (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fs_tag);
     uint32_t *tstart = (uint32_t *)ctx->cell_start.p;
     float4 *cpts = (float4 *)ctx->nodes.p;  // the array-layout kd nodes are consumed by the build: free here
     hipLaunchKernelGGL(grid_alloc_kernel, gm, blk, 0, ctx->stream, frame, (const uint32_t *)cells, (const uint32_t *)thead,
-                       tstart, ctx->fstride);
+                       tstart, ctx->fs_tag);
     hipLaunchKernelGGL(grid_scatter_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (const uint32_t *)ctx->cell_of.p,
-                       (const uint32_t *)next, (const uint32_t *)tstart, cpts, ctx->fstride);
+                       (const uint32_t *)next, (const uint32_t *)tstart, cpts, ctx->fs_tag);
     // one (cell, partner) pair per lane, grid-stride (the device knows how many cells there are)
     {
         const uint32_t pg0 = (m_max * 13u + 255u) / 256u < 512u ? (m_max * 13u + 255u) / 256u : 512u;
@@ -2658,18 +2676,18 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
 #define GP_ARGS                                                                                                        \
     (const FrameState *)frame, (const unsigned long long *)tkey, tparent, (const uint32_t *)thead,                    \
         (const uint32_t *)tstart, (const uint32_t *)cells, (const float4 *)cpts, (const float4 *)ctx->cell_xyz.p, r2,  \
-        ctx->cell_cap, gp_dbg, ctx->fstride
+        ctx->cell_cap, gp_dbg, ctx->fs_tag
         static const int gp_dbg = getenv("LPX_GP_DBG") ? atoi(getenv("LPX_GP_DBG")) : 0;  // timing experiments only
         hipLaunchKernelGGL(grid_pairs_kernel<false>, dim3(pg0, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
         hipLaunchKernelGGL(grid_compress_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, (const uint32_t *)cells,
-                           tparent, ctx->fstride);
+                           tparent, ctx->fs_tag);
         hipLaunchKernelGGL(grid_pairs_kernel<true>, dim3(pg1, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
 #undef GP_ARGS
     }
     hipLaunchKernelGGL(grid_flatten_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, tparent,
                        (const uint32_t *)tstart, (const uint32_t *)ctx->cell_of.p, d_root, d_iota,
                        (uint8_t *)ctx->state.p, (uint32_t *)ctx->valid.p, (uint32_t *)ctx->cc_lo.p,
-                       (uint32_t *)ctx->cc_hi.p, ctx->fstride);
+                       (uint32_t *)ctx->cc_hi.p, ctx->fs_tag);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__
                                                                    uint32_t *__restrict__ hist, uint32_t nblocks,
                                                                    int block_major, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t h[RADIX];
     keys = lpx_slot(keys, fs);
     d_n = lpx_slot(d_n, fs);
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__
     const uint32_t tid = threadIdx.x;
     h[tid] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * SORT_TILE;
+    const uint32_t base = lpx_blk.x * SORT_TILE;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r)
     {
@@ -45,9 +46,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__
     }
     __syncthreads();
     if (block_major)
-        hist[blockIdx.x * RADIX + tid] = h[tid];
+        hist[lpx_blk.x * RADIX + tid] = h[tid];
     else
-        hist[tid * nblocks + blockIdx.x] = h[tid];
+        hist[tid * nblocks + lpx_blk.x] = h[tid];
 }
 
 template <typename KeyT, bool HAS_VALS>
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
                                                                       const uint32_t *__restrict__ offs,
                                                                       uint32_t nblocks, int large, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
     __shared__ uint32_t dsum[SORT_WAVES];
     keys_in = lpx_slot(keys_in, fs);
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
         (&wcnt[0][0])[i] = 0;
     __syncthreads();
 
-    const uint32_t chunk = blockIdx.x * SORT_TILE + w * (SORT_ITEMS * WAVE);
+    const uint32_t chunk = lpx_blk.x * SORT_TILE + w * (SORT_ITEMS * WAVE);
     const unsigned long long lt = lpx_lanemask_lt();
     KeyT k[SORT_ITEMS];
     uint32_t v[SORT_ITEMS];
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
     uint32_t below = 0, t = 0;
     if (large)
     {
-        below = offs[tid * nblocks + blockIdx.x];
+        below = offs[tid * nblocks + lpx_blk.x];
         t = offs[RADIX * nblocks + tid];
     }
     else
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
             for (int u = 0; u < 8; ++u)
             {
                 t += c[u];
-                below += (b0 + u < blockIdx.x) ? c[u] : 0u;
+                below += (b0 + u < lpx_blk.x) ? c[u] : 0u;
             }
         }
     }
@@ -183,6 +185,7 @@ constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint32_t *in, uint32_t *out, uint32_t n_max,
                                                              const uint32_t *d_n, uint64_t *d_total, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t wsum[2][SCAN_GROUPS][SCAN_WAVES];
     in = lpx_slot(in, fs);
     out = lpx_slot(out, fs);
@@ -251,9 +254,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint32_t *in, 
 // on a 5M-point frame.)
 __global__ __launch_bounds__(SORT_THREADS) void hist_rows_kernel(uint32_t *hist, uint32_t nblocks, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t wsum[2][SORT_WAVES];
     hist = lpx_slot(hist, fs);
-    uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
+    uint32_t *row = hist + (size_t)lpx_blk.x * nblocks;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     uint32_t carry = 0, it = 0;
     for (uint32_t base = 0; base < nblocks; base += SORT_THREADS * 4, ++it)
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(SORT_THREADS) void hist_rows_kernel(uint32_t *hist,
         carry += tot;
     }
     if (tid == 0)
-        hist[(size_t)RADIX * nblocks + blockIdx.x] = carry;
+        hist[(size_t)RADIX * nblocks + lpx_blk.x] = carry;
 }
 
 // Exclusive scan of a long array in three launches: tile sums, single-block scan of the sums, tiles again with
@@ -321,6 +325,7 @@ template <bool APPLY>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(const uint32_t *in, uint32_t *out, uint32_t n_max,
                                                                    const uint32_t *d_n, uint32_t *tile_sums, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t wsum[SCAN_WAVES];
     in = lpx_slot(in, fs);
     out = lpx_slot(out, fs);
@@ -328,11 +333,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(const uint32_t
     tile_sums = lpx_slot(tile_sums, fs);
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     const uint32_t tid = threadIdx.x;
-    const uint32_t e = blockIdx.x * XS_TILE + tid * 4;
-    if (blockIdx.x * (uint32_t)XS_TILE >= n)
+    const uint32_t e = lpx_blk.x * XS_TILE + tid * 4;
+    if (lpx_blk.x * (uint32_t)XS_TILE >= n)
     {
         if (!APPLY && tid == 0)
-            tile_sums[blockIdx.x] = 0;
+            tile_sums[lpx_blk.x] = 0;
         return;
     }
     uint32_t a[4], tsum = 0;
@@ -347,10 +352,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(const uint32_t
     if (!APPLY)
     {
         if (tid == 0)
-            tile_sums[blockIdx.x] = total;
+            tile_sums[lpx_blk.x] = total;
         return;
     }
-    uint32_t run = tile_sums[blockIdx.x] + excl;
+    uint32_t run = tile_sums[lpx_blk.x] + excl;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
     {
@@ -389,16 +394,16 @@ int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t
         uint32_t *sums = (uint32_t *)((char *)ctx->hist.p + 64);
         const dim3 grid(tiles, 1, ctx->cur_b);
         hipLaunchKernelGGL(scan_tiles_kernel<false>, grid, dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, sums,
-                           ctx->fstride);
+                           ctx->fs_tag);
         hipLaunchKernelGGL(scan_kernel, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream,
-                           (const uint32_t *)sums, sums, tiles, (const uint32_t *)nullptr, d_total, ctx->fstride);
+                           (const uint32_t *)sums, sums, tiles, (const uint32_t *)nullptr, d_total, ctx->fs_tag);
         hipLaunchKernelGGL(scan_tiles_kernel<true>, grid, dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, sums,
-                           ctx->fstride);
+                           ctx->fs_tag);
         LPX_HIP(ctx, hipGetLastError());
         return LPX_OK;
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, d_total,
-                       ctx->fstride);
+                       ctx->fs_tag);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
@@ -414,7 +419,7 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     const int large = nblocks > FUSED_SCAN_MAX_BLOCKS;
     uint32_t *ka = keys_a, *kb = keys_b, *va = vals_a, *vb = vals_b;
     const uint32_t B = ctx->cur_b;
-    const size_t fs = ctx->fstride;
+    const size_t fs = ctx->fs_tag;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
         hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
@@ -447,7 +452,7 @@ int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n
     const int large = nblocks > FUSED_SCAN_MAX_BLOCKS;
     uint64_t *ka = keys_a, *kb = keys_b;
     const uint32_t B = ctx->cur_b;
-    const size_t fs = ctx->fstride;
+    const size_t fs = ctx->fs_tag;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
         hipLaunchKernelGGL((radix_hist_kernel<uint64_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka, n,

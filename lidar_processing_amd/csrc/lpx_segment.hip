@@ -55,6 +55,7 @@ __device__ __forceinline__ void seg_bind(SegParams &prm, const FrameState *frame
 // ------------------------------------------------------------------------------------------------
 __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacles, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<0>(fs);
     frame = lpx_slot(frame, fs);
     uint32_t *w = (uint32_t *)frame;
     for (uint32_t i = threadIdx.x; i < sizeof(FrameState) / sizeof(uint32_t); i += blockDim.x)
@@ -62,15 +63,16 @@ __global__ void frame_init_kernel(FrameState *frame, NArr n, uint32_t as_obstacl
     __syncthreads();
     if (threadIdx.x == 0)
     {
-        frame->n_obstacle = as_obstacles ? n.v[blockIdx.z] : 0u;
-        frame->n_in = n.v[blockIdx.z];
+        frame->n_obstacle = as_obstacles ? n.v[lpx_blk.z] : 0u;
+        frame->n_in = n.v[lpx_blk.z];
     }
 }
 
 __global__ void counts_kernel(const FrameState *frame, uint32_t *counts, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<0>(fs);
     frame = lpx_slot(frame, fs);
-    counts += 4 * (size_t)blockIdx.z;
+    counts += 4 * (size_t)lpx_blk.z;
     if (threadIdx.x == 0)
     {
         counts[0] = frame->n_ground;
@@ -107,7 +109,8 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
                               uint32_t *__restrict__ key, uint32_t *__restrict__ val,
                               FrameState *__restrict__ frame, float4 *__restrict__ nodes, FV fv)
 {
-    pts += (size_t)blockIdx.z * fv.upitch * stride;
+    const LpxBlock lpx_blk = lpx_block<0>(fv.fs);
+    pts += (size_t)lpx_blk.z * fv.upitch * stride;
     P4 = lpx_slot(P4, fv.fs);
     X = lpx_slot(X, fv.fs);
     Y = lpx_slot(Y, fv.fs);
@@ -116,7 +119,7 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
     val = lpx_slot(val, fv.fs);
     frame = lpx_slot(frame, fv.fs);
     nodes = lpx_slot(nodes, fv.fs);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     const bool in = i < frame->n_in;  // no early return: the wavefront reduces at the end
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (in)
@@ -163,6 +166,7 @@ __global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float4 *_
                               uint64_t *__restrict__ zkey, SegParams prm, const FrameState *__restrict__ frame,
                               size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<0>(fs);
     sidx = lpx_slot(sidx, fs);
     P4 = lpx_slot(P4, fs);
     XS = lpx_slot(XS, fs);
@@ -170,7 +174,7 @@ __global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float4 *_
     ZS = lpx_slot(ZS, fs);
     zkey = lpx_slot(zkey, fs);
     seg_bind(prm, lpx_slot(frame, fs));
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = lpx_blk.x * blockDim.x + threadIdx.x;
     if (p >= prm.n)
         return;
     const float4 q = P4[sidx[p]];  // one random 16-byte read per point
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
                                                             uint32_t *__restrict__ ticket,
                                                             const FrameState *__restrict__ frame, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
     __shared__ __attribute__((aligned(16))) float zbuf[SEED_LDS];
     __shared__ float s_sum;
     __shared__ uint32_t s_cut;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
     acc = lpx_slot(acc, fs);
     ticket = lpx_slot(ticket, fs);
     seg_bind(prm, lpx_slot(frame, fs));
-    const uint32_t s = blockIdx.x;
+    const uint32_t s = lpx_blk.x;
     const uint32_t ns = prm.n_per;
     const uint64_t *zs = zsorted + (size_t)s * ns;
     const uint32_t tid = threadIdx.x;
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
                                                                    uint32_t *__restrict__ ticket,
                                                                    const FrameState *__restrict__ frame, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
     __shared__ __attribute__((aligned(16))) uint32_t s_buf[SEL_MAX_LPR];
     static_assert(SEL_BINS * (SEL_THREADS / WAVE) <= (int)SEL_MAX_LPR, "private histograms alias the sort buffer");
     uint32_t *s_hist = s_buf;  // [wavefront][bin] during the select, before the buffer is filled
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
     acc = lpx_slot(acc, fs);
     ticket = lpx_slot(ticket, fs);
     seg_bind(prm, lpx_slot(frame, fs));
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint32_t s = lpx_blk.x, tid = threadIdx.x;
     const uint32_t ns = prm.n_per;
     const uint32_t base = s * ns;
     if (tid < LPX_ACC_WORDS)
@@ -863,6 +869,7 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
                                                                   uint32_t *__restrict__ blk_counts,
                                                                   const FrameState *__restrict__ frame, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
     __shared__ long long red[SEG_WAVES][LPX_ACC_WORDS];
     __shared__ uint32_t s_last;
     XS = lpx_slot(XS, fs);
@@ -877,7 +884,7 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     frame = lpx_slot(frame, fs);
     seg_bind(prm, frame);
     const bool any_far = frame->has_far != 0;
-    const uint32_t s = blockIdx.y, b = blockIdx.x;
+    const uint32_t s = lpx_blk.y, b = lpx_blk.x;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     const uint32_t seg_lo = s * prm.n_per;
     const uint32_t lo = seg_lo + b * prm.chunk;
@@ -1091,6 +1098,7 @@ __global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *
                                                                     uint32_t *__restrict__ blk_counts,
                                                                     const FrameState *__restrict__ frame, size_t fs)
 {
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
     __shared__ long long red[ONE_WAVES][LPX_ACC_WORDS];
     __shared__ float s_plane[6];  // a, b, c, d, thr, failed
     XS = lpx_slot(XS, fs);
@@ -1103,7 +1111,7 @@ __global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *
     frame = lpx_slot(frame, fs);
     seg_bind(prm, frame);
     const bool any_far = frame->has_far != 0;
-    const uint32_t s = blockIdx.x;
+    const uint32_t s = lpx_blk.x;
     long long *fa = facc + (size_t)s * LPX_FAR_WORDS;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     const uint32_t lo = s * prm.n_per, hi = lo + prm.n_per;
@@ -1321,6 +1329,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
                                                                const SegState *__restrict__ st,
                                                                float *__restrict__ planes, FrameState *frame, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<0>(fv.fs);
     __shared__ uint32_t wg[SEG_WAVES], wo[SEG_WAVES];
     flags = lpx_slot(flags, fv.fs);
     sidx = lpx_slot(sidx, fv.fs);
@@ -1339,7 +1348,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     oidx = lpx_user(oidx, fv.upitch);
     planes = lpx_user(planes, 4u * prm.P);
     seg_bind(prm, frame);
-    const uint32_t s = blockIdx.y, b = blockIdx.x;
+    const uint32_t s = lpx_blk.y, b = lpx_blk.x;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     const uint32_t nb = prm.P * prm.bps;
     const uint32_t seg_lo = s * prm.n_per;
@@ -1429,13 +1438,14 @@ __global__ void colour_kernel(const float4 *__restrict__ P4,
                               const FrameState *__restrict__ frame, float4 *__restrict__ grec,
                               float4 *__restrict__ orec, FV fv)
 {
+    const LpxBlock lpx_blk = lpx_block<0>(fv.fs);
     P4 = lpx_slot(P4, fv.fs);
     frame = lpx_slot(frame, fv.fs);
     gidx = lpx_user(gidx, fv.upitch);
     oidx = lpx_user(oidx, fv.upitch);
     grec = lpx_user(grec, 2u * fv.upitch);
     orec = lpx_user(orec, 2u * fv.upitch);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     const uint32_t ng = frame->n_ground, no = frame->n_obstacle;
     if (i >= ng + no)
         return;
@@ -1479,7 +1489,8 @@ __global__ void dbg_plane_out_kernel(const SegState *st, float *out)
 
 __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, uint32_t n)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const LpxBlock lpx_blk = lpx_block<0>(0);
+    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     if (i < n)
         p[i] = v;
 }
@@ -1527,7 +1538,7 @@ int lpx_frame_init(lpx_ctx *ctx, const uint32_t *n_points, bool as_obstacles)
     for (uint32_t b = 0; b < LPX_MAX_BATCH; ++b)
         na.v[b] = b < ctx->cur_b ? n_points[b] : 0u;
     hipLaunchKernelGGL(frame_init_kernel, dim3(1, 1, ctx->cur_b), dim3(WAVE), 0, ctx->stream, (FrameState *)ctx->frame.p,
-                       na, as_obstacles ? 1u : 0u, ctx->fstride);
+                       na, as_obstacles ? 1u : 0u, ctx->fs_tag);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
@@ -1535,7 +1546,7 @@ int lpx_frame_init(lpx_ctx *ctx, const uint32_t *n_points, bool as_obstacles)
 int lpx_write_counts(lpx_ctx *ctx, uint32_t *d_counts)
 {
     hipLaunchKernelGGL(counts_kernel, dim3(1, 1, ctx->cur_b), dim3(WAVE), 0, ctx->stream,
-                       (const FrameState *)ctx->frame.p, d_counts, ctx->fstride);
+                       (const FrameState *)ctx->frame.p, d_counts, ctx->fs_tag);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

@@ -223,3 +223,35 @@ def test_multi_rank_aggregation_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, 1.5, 3000.0), (1, 1.5, 3000.0)]
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself_dry_run():
+    """`python bench.py --gpus 2` without a launcher starts its two ranks itself (frame i -> GPU i mod N,
+    no data-path collective) and rank 0 reports the world it ran in.  --dry-run --backend gloo walks main() end to
+    end without a GPU: spawn, rendezvous on 127.0.0.1, sharding, MAX / SUM aggregation, the JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo",
+                        "--workload", "kitti", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["value"] == 0.0
+    assert line["config"]["distributed_world_size"] == 2 and line["config"]["distributed_backend"] == "gloo"
+    # both ranks' frames are in the aggregate: 2 x 512 frames, rank 0 holds frames 0, 2, 4, ... of the stream
+    assert line["config"]["frames_per_step"] == 2 * line["config"]["frames_per_step_per_gpu"]
+    assert line["config"]["frame_ids_rank0_head"] == [0, 2, 1, 0]  # i mod 3 over the three committed frames
+    assert line["scaling"] == "weak" and line["steps"] == 2
+
+
+def test_bench_under_a_launcher_does_not_spawn():
+    """with WORLD_SIZE set (torch.distributed.run) bench.py is one rank of an existing job"""
+    import json
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--workload", "kitti",
+                        "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1

@@ -1,0 +1,19 @@
+#!/bin/bash
+# tools/build_variant.sh NAME [extra hipcc flags...] -- builds lidar_processing_amd/ab/liblpx_NAME.so with extra
+# compile flags (objects under /tmp), for A/B runs on the GPU box: LPX_LIB=lidar_processing_amd/ab/liblpx_NAME.so.
+# Development only: the product library is lidar_processing_amd/liblpx.so.
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+obj=/tmp/lpx_variant_$name
+mkdir -p "$obj" "$root/lidar_processing_amd/ab"
+cd "$root/lidar_processing_amd/csrc"
+pids=()
+for f in lpx_primitives lpx_segment lpx_kdtree lpx_cluster lpx_api lpx_feeder; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I../../include -I. \
+    -Wno-unused-value -Wno-unused-result "$@" -c $f.hip -o "$obj/$f.o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/lidar_processing_amd/ab/liblpx_$name.so" "$obj"/*.o
+echo "built lidar_processing_amd/ab/liblpx_$name.so"
