@@ -523,13 +523,14 @@ def inflight_curve(plan, lpx, seconds=0.6):
     each a closed loop of `enqueue a chain of B frames -> wait for it`, so C x B frames are in flight.  What a
     4-sensor rig (4 in flight) or a 32-frame backlog gets, between the two ends the headline and `latency` show."""
     import threading
+    own = "lists" if plan.lists else "search"
     shapes = [(1, 1, "lists"), (1, 1, "search"), (4, 1, "lists"), (4, 1, "search"), (1, 4, "search"),
               (16, 1, "lists"), (2, 8, "search"), (1, 16, "search"), (8, 8, "search"), (2, 32, "search"),
-              (16, 32, "search")]
+              (4, 32, "search"), (8, 32, "search"), (plan.C, plan.B, own)]  # the last row is the headline's own shape
     rows = []
     F = plan.F
     for C, B, mode in shapes:
-        if C * B > F:
+        if C * B > F or (rows and (C, B, mode) == shapes[-1] and rows[-1]["contexts"] == C and rows[-1]["frames_per_chain"] == B):
             continue
         reuse = (B == plan.B and mode == ("lists" if plan.lists else "search") and C <= plan.C)
         ctxs = plan.ctxs[:C] if reuse else [plan.new_context(lpx, B, mode) for _ in range(C)]
@@ -542,8 +543,9 @@ def inflight_curve(plan, lpx, seconds=0.6):
         def loop(i):
             plan.torch.cuda.set_device(plan.local_rank)
             k = i * B  # every context walks its own frames of the resident array
-            for warm in (True, False):
-                start_evt.wait() if not warm else None
+            for warm in (2, 1, 0):  # two untimed chains (allocation, table sizes), then the timed loop
+                if not warm:
+                    start_evt.wait()
                 while True:
                     lo = k % (F - B + 1)
                     a = time.perf_counter()
@@ -562,7 +564,7 @@ def inflight_curve(plan, lpx, seconds=0.6):
         th = [threading.Thread(target=loop, args=(i,)) for i in range(C)]
         for x in th:
             x.start()
-        time.sleep(0.05)
+        time.sleep(0.05 + 0.01 * C * B)
         t0 = time.perf_counter()
         stop = t0 + seconds
         start_evt.set()
@@ -702,8 +704,8 @@ def main(argv=None):
         del plan
         torch.cuda.empty_cache()
         p3 = Plan("kitti", load_workload("kitti"), args, rank, world, local_rank, torch, lpx)
-        e3, _ = p3.timed(max(3, args.steps // 2), 2, lambda: None)
-        sub = {"mpts_s": round(p3.points_per_step * max(3, args.steps // 2) / e3 / 1e6, 1),
+        e3, _ = p3.timed(args.steps, args.warmup, lambda: None)
+        sub = {"mpts_s": round(p3.points_per_step * args.steps / e3 / 1e6, 1),
                "frames_per_step": p3.F, "what": WORKLOADS["kitti"]["config"]}
         plan = p3
 

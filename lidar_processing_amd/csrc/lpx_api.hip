@@ -1132,7 +1132,7 @@ extern "C" int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *o
     out12[3] = fs.status;
     out12[4] = (uint32_t)lpx_entries_written(fs);
     out12[5] = (uint32_t)(lpx_entries_written(fs) >> 32);
-    out12[6] = fs.n_roots;
+    out12[6] = fs.n_roots + fs.n_single;  // sets: the replay's work list plus the single-point sets
     out12[7] = fs.n_expansions;
     out12[8] = (uint32_t)fs.replay_entries;
     out12[9] = (uint32_t)(fs.replay_entries >> 32);

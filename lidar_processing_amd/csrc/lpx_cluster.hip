@@ -64,29 +64,58 @@ __global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ 
     cc_hi[i] = 0;
 }
 
-// sorted by root (stable): members of a component are contiguous, ascending original index
-__global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, FrameState *frame,
-                                 uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi,
-                                 uint32_t *__restrict__ roots, size_t fs)
+// sorted by root (stable): members of a component are contiguous, ascending original index.
+// A set of ONE point needs no sequencer: the greedy loop (src/clustering.cpp:69-124) seeds it, its radius search
+// returns the point itself and nothing else, the point is touched once and absorbed (distance 0), so the group has one
+// touch -- decided right here.  KITTI frames hold several hundred such sets; each used to cost a sequencer a ticket,
+// three dependent loads and a search.
+__global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, const uint32_t *__restrict__ members,
+                                 FrameState *frame, uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi,
+                                 uint32_t *__restrict__ roots, int32_t *__restrict__ seed_of,
+                                 uint32_t *__restrict__ valid, uint32_t min_size, uint32_t max_size, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<6>(fs);
     sroot = lpx_slot(sroot, fs);
+    members = lpx_slot(members, fs);
     frame = lpx_slot(frame, fs);
     cc_lo = lpx_slot(cc_lo, fs);
     cc_hi = lpx_slot(cc_hi, fs);
     roots = lpx_slot(roots, fs);
+    seed_of = lpx_slot(seed_of, fs);
+    valid = lpx_slot(valid, fs);
     const uint32_t p = lpx_blk.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
-    if (p >= M)
-        return;
-    const uint32_t r = sroot[p];
-    if (p == 0 || sroot[p - 1] != r)
+    bool single = false;
+    if (p < M)
     {
-        cc_lo[r] = p;
-        roots[atomicAdd(&frame->n_roots, 1u)] = r;  // work list of the replay
+        const uint32_t r = sroot[p];
+        const bool first = p == 0 || sroot[p - 1] != r, last = p + 1 == M || sroot[p + 1] != r;
+        single = first && last;
+        if (single)
+        {
+            const uint32_t i = members[p];
+            seed_of[i] = (int32_t)i;
+            valid[i] = (1u >= min_size && 1u <= max_size) ? 1u : 0u;  // :113
+        }
+        else
+        {
+            if (first)
+            {
+                cc_lo[r] = p;
+                roots[atomicAdd(&frame->n_roots, 1u)] = r;  // work list of the replay
+            }
+            if (last)
+                cc_hi[r] = p + 1;
+        }
     }
-    if (p + 1 == M || sroot[p + 1] != r)
-        cc_hi[r] = p + 1;
+    // the statistics keep counting the radius searches the reference makes: one per single-point set, one neighbour each
+    const uint32_t ns = (uint32_t)__popcll(__ballot(single));
+    if (ns && (threadIdx.x % WAVE) == 0)
+    {
+        atomicAdd(&frame->n_expansions, ns);
+        atomicAdd(&frame->n_single, ns);
+        atomicAdd((unsigned long long *)&frame->replay_entries, (unsigned long long)ns);
+    }
 }
 
 struct ReplayParams
@@ -591,13 +620,31 @@ __device__ __forceinline__ void rs_consume(const RsBatch &b, const KdNode *__res
     }
 }
 
+// LPX_RS_PROF (tools/replay_prof.py, a variant build): cycles of every sequencer by phase, one record per wavefront
+// in the lpx_dbg_group_stats buffer: {total, seed scan, window set-up, chunk table + cull + issue, candidates (wait +
+// test + gather), apply, expansions, windows}
+#ifdef LPX_RS_PROF
+#define RS_NOW() clock64()
+#define RS_LAP(acc, t)                                                                                                \
+    do                                                                                                                \
+    {                                                                                                                 \
+        const unsigned long long n_ = clock64();                                                                      \
+        acc += n_ - (t);                                                                                              \
+        (t) = n_;                                                                                                     \
+    } while (0)
+#else
+#define RS_NOW() 0ull
+#define RS_LAP(acc, t) ((void)0)
+#endif
+
 template <bool STATE_LDS>
 __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const FrameState *__restrict__ frame, const uint32_t *__restrict__ cc_lo, const uint32_t *__restrict__ cc_hi,
     const uint32_t *__restrict__ members, const KdNode *__restrict__ PR, const ChunkRec *__restrict__ chunks,
     const uint32_t *__restrict__ grp_of, const float *__restrict__ OX, const float *__restrict__ OY,
     const float *__restrict__ OZ, uint8_t *gstate, int32_t *seed_of, uint32_t *queue, uint32_t *valid,
-    ReplayParams prm, FrameState *fstate, const uint32_t *__restrict__ roots, uint32_t m_lo, uint32_t m_hi, FV fv)
+    ReplayParams prm, FrameState *fstate, const uint32_t *__restrict__ roots, uint32_t m_lo, uint32_t m_hi,
+    unsigned long long *prof, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<7>(fv.fs);
     extern __shared__ uint32_t smem[];
@@ -647,6 +694,9 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     } while (0)
     unsigned long long st_entries = 0, st_cand = 0;
     uint32_t st_exp = 0, st_win = 0;
+    [[maybe_unused]] unsigned long long pf_seed = 0, pf_win = 0, pf_tab = 0, pf_cand = 0, pf_apply = 0;
+    [[maybe_unused]] unsigned long long pf_t = RS_NOW();
+    [[maybe_unused]] const unsigned long long pf_t0 = pf_t;
     for (;;)
     {
         uint32_t ticket = 0;
@@ -678,6 +728,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 }
                 cursor += WAVE;
             }
+            RS_LAP(pf_seed, pf_t);
             if (seed == 0xffffffffu)
                 break;
             uint32_t qh = 0, qt = 1;
@@ -786,6 +837,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                     am &= ~(1ull << h);
                 }
                 qh = wb + wn;
+                RS_LAP(pf_win, pf_t);
                 if (!em)
                     continue;
                 ++st_win;
@@ -802,6 +854,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 unsigned long long km = rs_cull(ch, qx, qy, qz, r2);
                 RsBatch bt;
                 rs_issue(bt, PR, ch, km, lane);
+                RS_LAP(pf_tab, pf_t);
                 for (;;)
                 {
                     const int e_next = em ? __ffsll((long long)em) - 1 : -1;
@@ -818,6 +871,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                         rs_issue(bt, PR, ch, km, lane);
                         rs_consume(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
                     }
+                    RS_LAP(pf_cand, pf_t);
                     if (e_next >= 0)
                     {
                         e = e_next;
@@ -828,8 +882,10 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                         km = rs_cull(ch, qx, qy, qz, r2);
                         rs_issue(bt, PR, ch, km, lane);
                     }
+                    RS_LAP(pf_tab, pf_t);
                     while (hc)
                         flush64();  // the hits of the expansion just searched, before any hit of the next one
+                    RS_LAP(pf_apply, pf_t);
                     if (e_next < 0)
                         break;
                 }
@@ -845,6 +901,24 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
         atomicAdd(&fstate->n_windows, st_win);
         atomicAdd((unsigned long long *)&fstate->cand_total, st_cand);
     }
+#ifdef LPX_RS_PROF
+    if (prof && lane == 0)
+    {
+        const unsigned long long slot = atomicAdd(prof, 1ull);
+        if (slot < 4000)
+        {
+            unsigned long long *r = prof + 8 + 8 * slot;
+            r[0] = clock64() - pf_t0;
+            r[1] = pf_seed;
+            r[2] = pf_win;
+            r[3] = pf_tab;
+            r[4] = pf_cand;
+            r[5] = pf_apply;
+            r[6] = st_exp;
+            r[7] = ((unsigned long long)st_win << 32) | (uint32_t)(st_entries > 0xffffffffull ? 0xffffffffull : st_entries);
+        }
+    }
+#endif
 #undef ST_GET
 #undef ST_OR
 }
@@ -1208,8 +1282,9 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                                 &frame->n_obstacle, bits_for_count(m_max), &sroot, &members);
         if (rc)
             return rc;
-        hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, sroot, frame, cc_lo, cc_hi, (uint32_t *)ctx->rpos.p,
-                           fv.fs);
+        hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, (const uint32_t *)sroot, (const uint32_t *)members, frame,
+                           cc_lo, cc_hi, (uint32_t *)ctx->rpos.p, (int32_t *)ctx->seed_of.p, valid, prm.min_size,
+                           prm.max_size, fv.fs);
     }
     if (!ctx->use_lists && !skip_replay)
     {
@@ -1242,7 +1317,10 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         (const KdNode *)ctx->nodes_pre.p, (const ChunkRec *)ctx->chunks.p, (const uint32_t *)ctx->grp_of.p,            \
         (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (uint8_t *)ctx->state.p,          \
         (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, frame, (const uint32_t *)ctx->rpos.p,         \
-        (uint32_t)(lo_), (uint32_t)(hi_), fv
+        (uint32_t)(lo_), (uint32_t)(hi_),                                                                             \
+        (unsigned long long *)(ctx->dbg_buf && ctx->dbg_store.bytes >= (512u << 10) ? (char *)ctx->dbg_buf + (256u << 10) \
+                                                                                   : nullptr),                       \
+        fv
         // Point states as a 2-bit LDS bitmap sized for the host's bound (31 KiB for a 123k-point frame; the resident
         // footprint is set by rgrid, not by this), capped at what LDS holds (~440k points).  When the bound exceeds
         // the cap a second launch with one byte per point in HBM serves the frames that really are that large; each

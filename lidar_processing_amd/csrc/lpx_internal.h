@@ -61,6 +61,7 @@ struct alignas(128) FrameState
     uint32_t n_expansions;    // radius_search calls the reference would have made
     uint32_t n_windows;       // queue windows with at least one expansion (expansion-driven path)
     uint32_t n_overflow;      // searches redone by the sequencer because the list did not fit its LDS region
+    uint32_t n_single;        // single-point sets, settled by cc_ranges_kernel (not in the work list of n_roots)
     // The single-pass region of the list workspace is handed out from LPX_RS_STRIPES sub-regions with a cursor each
     // (group g bumps cursor g % LPX_RS_STRIPES): thousands of bumps of ONE word per frame serialise at L2.
     FrameStripe rs_stripe[LPX_RS_STRIPES];

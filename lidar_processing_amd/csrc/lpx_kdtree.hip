@@ -373,19 +373,105 @@ struct Coop<1024>
 };
 
 // __unguarded_partition_pivot(first, last) by a group of G threads; returns the cut
+#ifdef LPX_KD_PROF
+#define KD_LAP(acc, t)                                                                                                \
+    do                                                                                                                \
+    {                                                                                                                 \
+        const unsigned long long n_ = clock64();                                                                      \
+        (acc) += n_ - (t);                                                                                            \
+        (t) = n_;                                                                                                     \
+    } while (0)
+__device__ unsigned long long kd_pf[8];  // median, flags, swaps, cut (cycles of thread 0 of the profiled workgroup)
+#else
+#define KD_LAP(acc, t) ((void)0)
+#endif
+
 template <int G>
-__device__ int coop_partition_pivot(const View &v, int first, int last, int axis, int tid, uint32_t *cs, float *kb)
+__device__ int coop_partition_pivot(const View &v, int first, int last, int axis, int tid, uint32_t *cs, float *kb,
+                                    bool wide = false)
 {
+#ifdef LPX_KD_PROF
+    unsigned long long pt = clock64();
+    const bool pf = tid == 0 && blockIdx.x == 0 && blockIdx.z == 0;
+#define KD_P(i) if (pf) KD_LAP(kd_pf[i], pt)
+#else
+#define KD_P(i) ((void)0)
+#endif
     if (tid == 0)
         seq_median_to_first(v, first, last, axis);
     Coop<G>::sync();
     const float pv = nkey(v, first, axis);
+    KD_P(0);
     int cntL = 0, cntR = 0;
     // flag pass, PE consecutive positions per thread (one scan per G*PE keys).  The keys come through LDS: the group
     // reads them with consecutive lanes on consecutive nodes (a thread fetching its own four 16-byte nodes makes
     // every lane a separate 64-byte request -- or a 16-way bank conflict once the nodes are staged -- and that was
     // two thirds of this kernel's time), then every thread takes its four as one 16-byte LDS read.
     constexpr int PE = 4;
+    // Ranges in GLOBAL memory (the first rounds of the upper levels: v.off == 0 and the nodes are not staged): eight
+    // rows of G positions per step -- eight independent key loads per thread in flight, ranks by ballot, the row x
+    // wavefront counts scanned once per step.  Per 8192 positions: one round trip and three barriers, where the
+    // four-keys-per-thread form below pays two of each set; the stop lists it writes are the same.
+    if (G == 1024 && wide)
+    {
+        constexpr int R = 8;
+        uint32_t *tab = (uint32_t *)kb;   // [R][16] packed counts of a step: left stops | right stops << 16
+        uint32_t *tab2 = tab + R * 16;    // their exclusive prefix, [R * 16] = the step's totals
+        const uint32_t w = (uint32_t)tid / WAVE, lane = (uint32_t)tid % WAVE;
+        const unsigned long long lt = lpx_lanemask_lt();
+        for (int base = first + 1; base < last; base += G * R)
+        {
+            float kk[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+            {
+                const int p = base + j * G + tid;
+                kk[j] = p < last ? nkey(v, p, axis) : pv;
+            }
+            unsigned long long bL[R], bR[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+            {
+                const bool valid = base + j * G + tid < last;
+                bL[j] = __ballot(valid && !(kk[j] < pv));  // left cursor stops here
+                bR[j] = __ballot(valid && !(pv < kk[j]));  // right cursor stops here
+                if (lane == 0)
+                    tab[j * 16 + w] = (uint32_t)__popcll(bL[j]) | ((uint32_t)__popcll(bR[j]) << 16);
+            }
+            __syncthreads();
+            uint32_t mine = 0, incl = 0;
+            if (tid < R * 16)
+            {
+                mine = tab[tid];
+                incl = lpx_wave_incl_scan_u32(mine);  // at most 8192 stops per step: the halves do not carry
+                if (lane == WAVE - 1)
+                    cs[32 + w] = incl;
+            }
+            __syncthreads();
+            if (tid < R * 16)
+            {
+                const uint32_t add = w ? cs[32] : 0u;
+                tab2[tid] = incl - mine + add;
+                if (tid == R * 16 - 1)
+                    tab2[R * 16] = incl + add;
+            }
+            __syncthreads();
+            const uint32_t total = tab2[R * 16];
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+            {
+                const int p = base + j * G + tid;
+                const uint32_t off = tab2[j * 16 + w];
+                if ((bL[j] >> lane) & 1ull)
+                    v.lp[first + cntL + (int)(off & 0xffffu) + __popcll(bL[j] & lt) - v.off] = (uint32_t)p;
+                if ((bR[j] >> lane) & 1ull)
+                    v.ra[first + cntR + (int)(off >> 16) + __popcll(bR[j] & lt) - v.off] = (uint32_t)p;
+            }
+            cntL += (int)(total & 0xffffu);
+            cntR += (int)(total >> 16);
+        }
+    }
+    else
     for (int base = first + 1; base < last; base += G * PE)
     {
 #pragma unroll
@@ -435,6 +521,7 @@ __device__ int coop_partition_pivot(const View &v, int first, int last, int axis
         cntR += (int)(total >> 16);
     }
     Coop<G>::sync();
+    KD_P(1);
     const int kmax = min(cntL, cntR);
     uint32_t my = 0;
     for (int k0 = tid; k0 < kmax; k0 += 4 * G)
@@ -467,9 +554,11 @@ __device__ int coop_partition_pivot(const View &v, int first, int last, int axis
             }
     }
     const int K = (int)Coop<G>::sum(my, cs);
+    KD_P(2);
     const int c1 = (K < cntL) ? (int)v.lp[first + K - v.off] : INT_MAX;
     const int c2 = (K > 0) ? (int)v.ra[first + cntR - K - v.off] : INT_MAX;
     Coop<G>::sync();
+    KD_P(3);
     return min(c1, c2);
 }
 
@@ -510,6 +599,8 @@ constexpr int BLK_G = 1024;
 constexpr int BLK_CAP_BATCH = 1984;  // batches: kd_lds_kernel needs 20 B x 1984 + 256 B = 39 936 B, four workgroups per CU
                                      // (2032 nodes = 40 896 B measured as three per CU: 402 against 273 us per chain)
 constexpr int BLK_CAP_MAX = 4096;  // most nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch (blk_cap is a launch argument)
+constexpr int BLK_TAIL = 1024;  // batches, upper levels: the active range is staged in LDS once it is this small
+constexpr int WAVE_TAIL = 1024;  // kd_block_kernel: a staged range this small is finished by one wavefront
 constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
 
 // one workgroup per range of `level`: std::nth_element(b, mid, e) on axis level % 3
@@ -560,6 +651,14 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     bool staged = false;
     int sb = 0, se = 0;
     bool done = false;
+#ifdef LPX_KD_PROF
+    const bool pf = tid == 0 && blockIdx.x == 0 && blockIdx.z == 0;
+    unsigned long long t_all = clock64(), t_g = 0, t_l = 0, t_lap = t_all;
+    int r_g = 0, r_l = 0;
+    if (pf)
+        for (int i = 0; i < 8; ++i)
+            kd_pf[i] = 0;
+#endif
     while (last - first > 3)
     {
         if (!staged && last - first <= STAGE_CAP)
@@ -575,6 +674,37 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
             staged = true;
             Coop<BLK_G>::sync();
         }
+        // A staged range of at most WAVE_TAIL nodes is finished by ONE wavefront: sixteen wavefronts meeting at eight
+        // barriers per round cost ~6.8k cycles per round for a few hundred nodes (measured), and every nth_element
+        // ends with about ten such rounds; a single wavefront needs no barrier at all.
+        if (staged && last - first <= WAVE_TAIL)
+        {
+            if (tid < WAVE)
+            {
+                while (last - first > 3)
+                {
+                    if (depth_limit == 0)
+                    {
+                        if (tid == 0)
+                        {
+                            seq_heap_select(v, first, nth + 1, last, axis);
+                            nswap(v, first, nth);
+                        }
+                        done = true;
+                        break;
+                    }
+                    --depth_limit;
+                    const int cut = coop_partition_pivot<WAVE>(v, first, last, axis, tid, cs, kb);
+                    if (cut <= nth)
+                        first = cut;
+                    else
+                        last = cut;
+                }
+            }
+            else
+                done = true;  // (the other wavefronts only wait for the write-back)
+            break;
+        }
         if (depth_limit == 0)
         {
             if (tid == 0)
@@ -586,7 +716,16 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
             break;
         }
         --depth_limit;
-        const int cut = coop_partition_pivot<BLK_G>(v, first, last, axis, tid, cs, kb);
+#ifdef LPX_KD_PROF
+        t_lap = clock64();
+#endif
+        const int cut = coop_partition_pivot<BLK_G>(v, first, last, axis, tid, cs, kb, !staged);
+#ifdef LPX_KD_PROF
+        if (staged)
+            t_l += clock64() - t_lap, ++r_l;
+        else
+            t_g += clock64() - t_lap, ++r_g;
+#endif
         if (cut <= nth)
             first = cut;
         else
@@ -598,6 +737,12 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
     if (staged)
         for (int i = sb + tid; i < se; i += BLK_G)
             nodes[i] = l_nodes[i - sb];
+#ifdef LPX_KD_PROF
+    if (pf)
+        printf("kd_block level %d range %d: total %llu cycles; %d global rounds %llu, %d LDS rounds %llu; median %llu flags %llu "
+               "swaps %llu cut %llu\n", level, e - b, clock64() - t_all, r_g, t_g, r_l, t_l, kd_pf[0], kd_pf[1], kd_pf[2],
+               kd_pf[3]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2540,10 +2685,15 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
                 top = state;
             }
         }
-        hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G),
-                           (stage ? blk_lds : 64 * sizeof(uint32_t)) + key_lds, ctx->stream, nodes, lpos, rasc, frame, level,
-                           blk_cap,
-                           stage ? blk_cap : 0, top, ctx->fs_tag);
+        // The top levels of a batch stage only the END of every nth_element: the introselect loop runs ~15 rounds per
+        // range whatever its size, each a chain of dependent global round trips (~6 us); once the active range is down
+        // to BLK_TAIL nodes the remaining ~10 rounds run from 24 KiB of LDS.  (Staging the full blk_cap there makes
+        // these workgroups wait for a CU with 48 KiB free while other chains fill the device.)
+        static const int tail_env = getenv("LPX_KD_TAIL") ? atoi(getenv("LPX_KD_TAIL")) : BLK_TAIL;
+        const int stage_cap = stage ? blk_cap : (tail_env < blk_cap ? tail_env : blk_cap);
+        const size_t stage_lds = sizeof(Node) * stage_cap + 2 * sizeof(uint32_t) * stage_cap + 64 * sizeof(uint32_t);
+        hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G), stage_lds + key_lds, ctx->stream,
+                           nodes, lpos, rasc, frame, level, blk_cap, stage_cap, top, ctx->fs_tag);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
