@@ -404,8 +404,8 @@ static int create_common(int device, hipStream_t stream, bool own, uint32_t batc
     else
         ctx->stream = stream;
     ctx->batch = batch;
-    if (hipHostMalloc((void **)&ctx->h_search, 4 * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess)
-        memset(ctx->h_search, 0, 4 * sizeof(uint64_t));
+    if (hipHostMalloc((void **)&ctx->h_search, 6 * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess)
+        memset(ctx->h_search, 0, 6 * sizeof(uint64_t));
     else
         ctx->h_search = nullptr;
     ctx->reg_index = reg_claim(device, batch);

@@ -650,6 +650,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     extern __shared__ uint32_t smem[];
     RsShared &sh = *(RsShared *)smem;
     uint32_t *sbits = smem + sizeof(RsShared) / sizeof(uint32_t);
+    FrameState *const fstate0 = fstate;  // slot 0 collects what the host reads back after the launch
     frame = lpx_slot(frame, fv.fs);
     fstate = lpx_slot(fstate, fv.fs);
     cc_lo = lpx_slot(cc_lo, fv.fs);
@@ -669,6 +670,8 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const uint32_t tid = threadIdx.x, w = tid / WAVE, lane = tid % WAVE;
     const uint32_t M = frame->n_obstacle;
     const uint32_t n_roots = frame->n_roots;
+    if (STATE_LDS && lpx_blk.x == 0 && tid == 0)
+        atomicMax(&fstate0->max_obstacle, M);
     // frames outside (m_lo, m_hi] obstacle points belong to the other launch (an empty frame to none)
     if (M <= m_lo || M > m_hi || lpx_blk.x * RS_WAVES >= n_roots)
         return;
@@ -1327,7 +1330,20 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // launch checks the frame's obstacle count on the device (a 1M-point cloud usually has < 440k obstacles).
         static const int rs_state = getenv("LPX_RS_STATE") ? atoi(getenv("LPX_RS_STATE")) : 0;  // 1: states in HBM
         const uint32_t lds_pts = rs_state == 1 ? 0u : (uint32_t)(((152 * 1024 - fixed) / sizeof(uint32_t) - 4) * 16);
-        const uint32_t m_lds = m_max < lds_pts ? m_max : lds_pts;
+        uint32_t m_lds = m_max < lds_pts ? m_max : lds_pts;
+        // The bound m_max is the INPUT size of the largest frame; the obstacle cloud is about half of it.  With many
+        // chains in flight the replay workgroups of all of them are resident together for milliseconds, and what their
+        // bitmaps hold of every CU's LDS is what the LDS-staged kernels of the other chains (kd subtrees, chunk tables,
+        // seed selection) cannot get.  So the bitmap is sized by the largest obstacle count the context's previous call
+        // saw (+25 %); a frame that exceeds it is served by the second launch.
+        static const int rs_fit = getenv("LPX_RS_FIT") ? atoi(getenv("LPX_RS_FIT")) : 1;
+        if (rs_fit && ctx->cur_b > 1 && ctx->h_search && m_lds)
+        {
+            const uint32_t seen = (uint32_t)(ctx->h_search[5] & 0xffffffffull);
+            const uint32_t want = seen + seen / 4 + 1024;
+            if (seen && want < m_lds)
+                m_lds = want;
+        }
         if (m_lds)
             hipLaunchKernelGGL(replay_search_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(RS_THREADS),
                                fixed + bitmap_bytes(m_lds), st, RS_ARGS(0u, m_lds));
@@ -1338,7 +1354,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // what the searches of this call cost per hit, for the group size of the next call (read when it is there)
         if (ctx->h_search)
             LPX_HIP(ctx, hipMemcpyAsync(ctx->h_search, (const char *)frame + offsetof(FrameState, replay_entries),
-                                        4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+                                        6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     }
     else if (ctx->use_lists)
     {

@@ -62,6 +62,8 @@ struct alignas(128) FrameState
     uint32_t n_windows;       // queue windows with at least one expansion (expansion-driven path)
     uint32_t n_overflow;      // searches redone by the sequencer because the list did not fit its LDS region
     uint32_t n_single;        // single-point sets, settled by cc_ranges_kernel (not in the work list of n_roots)
+    uint32_t max_obstacle;    // slot 0 only: largest n_obstacle of the frames of the call (sizes the next call's LDS bitmaps)
+    uint32_t pad_stats;
     // The single-pass region of the list workspace is handed out from LPX_RS_STRIPES sub-regions with a cursor each
     // (group g bumps cursor g % LPX_RS_STRIPES): thousands of bumps of ONE word per frame serialise at L2.
     FrameStripe rs_stripe[LPX_RS_STRIPES];
@@ -175,7 +177,8 @@ struct lpx_ctx
     Buf lpos, rpos;            // partition scratch
     uint32_t ix_bucket = LPX_NB_BUCKET_DEFAULT;  // most nodes of a kd group of the search tables: 64, or 32 on scenes whose
                                                  // searches test many candidates per hit (adapted from h_search)
-    uint64_t *h_search = nullptr;  // pinned: {hits, -, candidates, expansions} of the previous search-mode call (slot 0)
+    uint64_t *h_search = nullptr;  // pinned: {hits, -, candidates, expansions | windows, overflows | single sets, largest
+                                   // obstacle count} of the previous search-mode call (slot 0's statistics)
     int reg_index = -1;        // entry of this context in the registry behind lpx_active_frame_slots
     Buf kd_state;              // introselect state of the ranges of a top kd level (multi-workgroup rounds)
     Buf nb_len, nb_off;        // u32 len, u32 off (cap_n + 1)

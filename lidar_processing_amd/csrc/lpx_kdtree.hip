@@ -259,8 +259,83 @@ __device__ void seq_build_subtree(const View &v, int b, int e, int depth)
 // ------------------------------------------------------------------------------------------------
 // cooperative group primitives: G = 64 (one wavefront) or 1024 (one workgroup)
 // ------------------------------------------------------------------------------------------------
+// a workgroup of G threads (G / 64 wavefronts, at most 16)
 template <int G>
-struct Coop;
+struct Coop
+{
+    static constexpr int NW = G / WAVE;
+    static_assert(G % WAVE == 0 && NW >= 2 && NW <= 16, "block groups are 2..16 wavefronts");
+    static __device__ __forceinline__ void sync()
+    {
+        __threadfence_block();
+        __syncthreads();
+    }
+    // cs: >= 32 words of LDS
+    static __device__ __forceinline__ void scan2(bool f0, bool f1, uint32_t &r0, uint32_t &r1, uint32_t &t0,
+                                                  uint32_t &t1, uint32_t *cs)
+    {
+        const unsigned long long lt = lpx_lanemask_lt();
+        const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+        const uint32_t w = threadIdx.x / WAVE;
+        if ((threadIdx.x % WAVE) == 0)
+            cs[w] = (uint32_t)__popcll(m0) | ((uint32_t)__popcll(m1) << 16);
+        __syncthreads();
+        uint32_t b0 = 0, b1 = 0, s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+        {
+            const uint32_t c = cs[i];
+            if (i < (int)w)
+            {
+                b0 += c & 0xffffu;
+                b1 += c >> 16;
+            }
+            s0 += c & 0xffffu;
+            s1 += c >> 16;
+        }
+        __syncthreads();
+        r0 = b0 + __popcll(m0 & lt);
+        r1 = b1 + __popcll(m1 & lt);
+        t0 = s0;
+        t1 = s1;
+    }
+    static __device__ __forceinline__ void scan_packed(uint32_t v, uint32_t &excl, uint32_t &total, uint32_t *cs)
+    {
+        const uint32_t incl = lpx_wave_incl_scan_u32(v);
+        const uint32_t w = threadIdx.x / WAVE;
+        if ((threadIdx.x % WAVE) == WAVE - 1)
+            cs[w] = incl;
+        __syncthreads();
+        uint32_t b = 0, s = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+        {
+            const uint32_t c = cs[i];
+            if (i < (int)w)
+                b += c;
+            s += c;
+        }
+        __syncthreads();
+        excl = b + incl - v;
+        total = s;
+    }
+    static __device__ __forceinline__ uint32_t sum(uint32_t v, uint32_t *cs)
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v += __shfl_xor(v, o, 64);
+        const uint32_t w = threadIdx.x / WAVE;
+        if ((threadIdx.x % WAVE) == 0)
+            cs[16 + w] = v;
+        __syncthreads();
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            s += cs[16 + i];
+        __syncthreads();
+        return s;
+    }
+};
 
 template <>
 struct Coop<64>
@@ -294,81 +369,6 @@ struct Coop<64>
         const uint32_t incl = lpx_wave_incl_scan_u32(v);
         excl = incl - v;
         total = __shfl(incl, WAVE - 1, 64);
-    }
-};
-
-template <>
-struct Coop<1024>
-{
-    static __device__ __forceinline__ void sync()
-    {
-        __threadfence_block();
-        __syncthreads();
-    }
-    // cs: >= 32 words of LDS
-    static __device__ __forceinline__ void scan2(bool f0, bool f1, uint32_t &r0, uint32_t &r1, uint32_t &t0,
-                                                  uint32_t &t1, uint32_t *cs)
-    {
-        const unsigned long long lt = lpx_lanemask_lt();
-        const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
-        const uint32_t w = threadIdx.x / WAVE;
-        if ((threadIdx.x % WAVE) == 0)
-            cs[w] = (uint32_t)__popcll(m0) | ((uint32_t)__popcll(m1) << 16);
-        __syncthreads();
-        uint32_t b0 = 0, b1 = 0, s0 = 0, s1 = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-        {
-            const uint32_t c = cs[i];
-            if (i < (int)w)
-            {
-                b0 += c & 0xffffu;
-                b1 += c >> 16;
-            }
-            s0 += c & 0xffffu;
-            s1 += c >> 16;
-        }
-        __syncthreads();
-        r0 = b0 + __popcll(m0 & lt);
-        r1 = b1 + __popcll(m1 & lt);
-        t0 = s0;
-        t1 = s1;
-    }
-    static __device__ __forceinline__ void scan_packed(uint32_t v, uint32_t &excl, uint32_t &total, uint32_t *cs)
-    {
-        const uint32_t incl = lpx_wave_incl_scan_u32(v);
-        const uint32_t w = threadIdx.x / WAVE;
-        if ((threadIdx.x % WAVE) == WAVE - 1)
-            cs[w] = incl;
-        __syncthreads();
-        uint32_t b = 0, s = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-        {
-            const uint32_t c = cs[i];
-            if (i < (int)w)
-                b += c;
-            s += c;
-        }
-        __syncthreads();
-        excl = b + incl - v;
-        total = s;
-    }
-    static __device__ __forceinline__ uint32_t sum(uint32_t v, uint32_t *cs)
-    {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            v += __shfl_xor(v, o, 64);
-        const uint32_t w = threadIdx.x / WAVE;
-        if ((threadIdx.x % WAVE) == 0)
-            cs[16 + w] = v;
-        __syncthreads();
-        uint32_t s = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            s += cs[16 + i];
-        __syncthreads();
-        return s;
     }
 };
 
@@ -412,11 +412,12 @@ __device__ int coop_partition_pivot(const View &v, int first, int last, int axis
     // rows of G positions per step -- eight independent key loads per thread in flight, ranks by ballot, the row x
     // wavefront counts scanned once per step.  Per 8192 positions: one round trip and three barriers, where the
     // four-keys-per-thread form below pays two of each set; the stop lists it writes are the same.
-    if (G == 1024 && wide)
+    if (G > WAVE && wide)
     {
-        constexpr int R = 8;
-        uint32_t *tab = (uint32_t *)kb;   // [R][16] packed counts of a step: left stops | right stops << 16
-        uint32_t *tab2 = tab + R * 16;    // their exclusive prefix, [R * 16] = the step's totals
+        constexpr int R = 8, NW = G / WAVE;
+        static_assert(G == WAVE || R * NW <= 2 * WAVE, "the step's count table is scanned by two wavefronts");
+        uint32_t *tab = (uint32_t *)kb;   // [R][NW] packed counts of a step: left stops | right stops << 16
+        uint32_t *tab2 = tab + R * NW;    // their exclusive prefix, [R * NW] = the step's totals
         const uint32_t w = (uint32_t)tid / WAVE, lane = (uint32_t)tid % WAVE;
         const unsigned long long lt = lpx_lanemask_lt();
         for (int base = first + 1; base < last; base += G * R)
@@ -436,11 +437,11 @@ __device__ int coop_partition_pivot(const View &v, int first, int last, int axis
                 bL[j] = __ballot(valid && !(kk[j] < pv));  // left cursor stops here
                 bR[j] = __ballot(valid && !(pv < kk[j]));  // right cursor stops here
                 if (lane == 0)
-                    tab[j * 16 + w] = (uint32_t)__popcll(bL[j]) | ((uint32_t)__popcll(bR[j]) << 16);
+                    tab[j * NW + w] = (uint32_t)__popcll(bL[j]) | ((uint32_t)__popcll(bR[j]) << 16);
             }
             __syncthreads();
             uint32_t mine = 0, incl = 0;
-            if (tid < R * 16)
+            if (tid < R * NW)
             {
                 mine = tab[tid];
                 incl = lpx_wave_incl_scan_u32(mine);  // at most 8192 stops per step: the halves do not carry
@@ -448,20 +449,20 @@ __device__ int coop_partition_pivot(const View &v, int first, int last, int axis
                     cs[32 + w] = incl;
             }
             __syncthreads();
-            if (tid < R * 16)
+            if (tid < R * NW)
             {
                 const uint32_t add = w ? cs[32] : 0u;
                 tab2[tid] = incl - mine + add;
-                if (tid == R * 16 - 1)
-                    tab2[R * 16] = incl + add;
+                if (tid == R * NW - 1)
+                    tab2[R * NW] = incl + add;
             }
             __syncthreads();
-            const uint32_t total = tab2[R * 16];
+            const uint32_t total = tab2[R * NW];
 #pragma unroll
             for (int j = 0; j < R; ++j)
             {
                 const int p = base + j * G + tid;
-                const uint32_t off = tab2[j * 16 + w];
+                const uint32_t off = tab2[j * NW + w];
                 if ((bL[j] >> lane) & 1ull)
                     v.lp[first + cntL + (int)(off & 0xffffu) + __popcll(bL[j] & lt) - v.off] = (uint32_t)p;
                 if ((bR[j] >> lane) & 1ull)
@@ -595,18 +596,21 @@ constexpr int TOP_THREADS = 256;
 constexpr int TOP_HAND = 4096;        // ranges at or below this are left to kd_block_kernel (they fit its LDS)
 constexpr uint32_t TOP_MIN = 131072;  // levels whose ranges can exceed this take the multi-workgroup rounds
 
-constexpr int BLK_G = 1024;
+constexpr int BLK_G_MAX = 1024;
 constexpr int BLK_CAP_BATCH = 1984;  // batches: kd_lds_kernel needs 20 B x 1984 + 256 B = 39 936 B, four workgroups per CU
                                      // (2032 nodes = 40 896 B measured as three per CU: 402 against 273 us per chain)
 constexpr int BLK_CAP_MAX = 4096;  // most nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch (blk_cap is a launch argument)
 constexpr int BLK_TAIL = 1024;  // batches, upper levels: the active range is staged in LDS once it is this small
 constexpr int WAVE_TAIL = 1024;  // kd_block_kernel: a staged range this small is finished by one wavefront
+constexpr uint32_t BLK_WIDE = 80000;  // batches: levels whose ranges may exceed this many nodes get 1024-thread workgroups,
+constexpr uint32_t BLK_MID = 0;       // ... this many 256 threads, shorter ones a single wavefront
 constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
 
 // one workgroup per range of `level`: std::nth_element(b, mid, e) on axis level % 3
 // BLK_CAP: the LDS capacity that decides which levels belong to kd_lds_kernel; STAGE_CAP: what THIS launch may
 // stage in LDS (0 for the top levels, whose ranges are far above the capacity: their workgroups then need no LDS
 // and find a CU at once even when other chains fill the device)
+template <int BLK_G>  // threads of the workgroup that owns a range: 1024 while the ranges are long, 256 below
 __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *lpos, uint32_t *rasc,
                                                           const FrameState *__restrict__ frame, int level,
                                                           int BLK_CAP, int STAGE_CAP,
@@ -2434,8 +2438,11 @@ __constant__ uint8_t FAR_T[49] = {64,  65,  69,  70,  71,  72,  73,  74,  75,  7
                                   90,  94,  95,  96,  97,  98,  99,  100, 101, 102, 103, 104, 105, 106, 107, 108, 109,
                                   110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124};
 
+#ifndef LPX_WPE_PAIRS
+#define LPX_WPE_PAIRS 8
+#endif
 template <bool FAR>
-__global__ __launch_bounds__(256) void grid_pairs_kernel(const FrameState *__restrict__ frame,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_PAIRS))) void grid_pairs_kernel(const FrameState *__restrict__ frame,
                                                          const unsigned long long *__restrict__ tkey,
                                                          uint32_t *tparent, const uint32_t *__restrict__ tcount,
                                                          const uint32_t *__restrict__ tstart,
@@ -2460,80 +2467,143 @@ __global__ __launch_bounds__(256) void grid_pairs_kernel(const FrameState *__res
     constexpr uint32_t P = FAR ? 49u : 13u;
     const unsigned long long total = (unsigned long long)frame->n_cells * P;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long item = (unsigned long long)lpx_blk.x * blockDim.x + threadIdx.x; item < total; item += stride)
+    // U items per lane and trip.  An item is a chain of dependent loads (cell -> its key -> the partner's home slot ->
+    // representatives / roots), and at full occupancy this kernel's time scaled 1 : 1 with the wavefronts resident
+    // (measured with occupancy caps): it is bound by the latency of those chains, not by any throughput.  So every
+    // lane walks the first three links of U chains side by side -- U independent loads in flight per link -- and the
+    // representatives of the U partners likewise; only the rare tail (more probes, the union, a point-pair scan) stays
+    // one item at a time.
+    constexpr int U = 4;
+    for (unsigned long long item0 = (unsigned long long)lpx_blk.x * blockDim.x + threadIdx.x; item0 < total;
+         item0 += U * stride)
     {
-        const uint32_t c = (uint32_t)(item / P), j = (uint32_t)(item % P);
-        int dx, dy, dz;
-        if (FAR)
+        uint32_t sl[U], hh[U];
+        unsigned long long nk[U], k2[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
         {
-            const int t = FAR_T[j];
-            dx = t / 25 - 2, dy = (t / 5) % 5 - 2, dz = t % 5 - 2;
+            const unsigned long long item = item0 + u * stride;
+            live[u] = item < total;
+            sl[u] = live[u] ? cells[(uint32_t)(item / P)] : 0u;
         }
-        else
+        unsigned long long key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            key[u] = live[u] ? tkey[sl[u]] : 0ull;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
         {
-            const int u = 14 + (int)j;  // the offsets of [-1, 1]^3 that follow (0, 0, 0) lexicographically
-            dx = u / 9 - 1, dy = (u / 3) % 3 - 1, dz = u % 3 - 1;
-        }
-        const uint32_t s = cells[c];
-        const unsigned long long key = tkey[s];
-        const int nx = (int)(key >> 42) + dx, ny = (int)((key >> 21) & 0x1fffffu) + dy, nz = (int)(key & 0x1fffffu) + dz;
-        if ((unsigned)nx > 0x1fffffu || (unsigned)ny > 0x1fffffu || (unsigned)nz > 0x1fffffu)
-            continue;
-        const unsigned long long nk = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) |
-                                      (unsigned long long)nz;
-        uint32_t partner = CELL_NONE;
-        for (uint32_t h = cell_hash(nk) & mask;; h = (h + 1) & mask)
-        {
-            const unsigned long long k2 = tkey[h];
-            if (k2 == CELL_EMPTY)
-                break;
-            if (k2 == nk)
+            const uint32_t j = (uint32_t)((item0 + u * stride) % P);
+            int dx, dy, dz;
+            if (FAR)
             {
-                partner = h;
-                break;
+                const int t = FAR_T[live[u] ? j : 0u];
+                dx = t / 25 - 2, dy = (t / 5) % 5 - 2, dz = t % 5 - 2;
             }
-        }
-        if (partner == CELL_NONE || dbg == 1)
-            continue;
-        // the far pass first skips what the touching pass already united
-        // (grid_compress_kernel ran in between: one load per side answers it for all but the pairs of this pass)
-        if (FAR && (uf_ld(tparent + s) == uf_ld(tparent + partner) || uf_find(tparent, s) == uf_find(tparent, partner)))
-            continue;
-        // quick test: the point that claimed the cell against the one that claimed the partner
-        const float4 ra = trep[s], rb = trep[partner];
-        {
-            const float d0 = ra.x - rb.x, d1 = ra.y - rb.y, d2 = ra.z - rb.z;
-            if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)
+            else
             {
-                if (dbg != 2)
-                    uf_unite(tparent, s, partner);
-                continue;
+                const int t = 14 + (int)j;  // the offsets of [-1, 1]^3 that follow (0, 0, 0) lexicographically
+                dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
             }
+            const int nx = (int)(key[u] >> 42) + dx, ny = (int)((key[u] >> 21) & 0x1fffffu) + dy,
+                      nz = (int)(key[u] & 0x1fffffu) + dz;
+            if ((unsigned)nx > 0x1fffffu || (unsigned)ny > 0x1fffffu || (unsigned)nz > 0x1fffffu)
+                live[u] = false;
+            nk[u] = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) | (unsigned long long)nz;
+            hh[u] = cell_hash(nk[u]) & mask;
         }
-        if (dbg == 3)
-            continue;
-        if (!FAR && uf_find(tparent, s) == uf_find(tparent, partner))
-            continue;  // united meanwhile through other pairs
-        // every point of the partner against every point of the cell, until the first pair within d
-        bool joined = false;
-        const float4 *A = cpts + tstart[s], *B = cpts + tstart[partner];
-        const uint32_t na = tcount[s], nb = tcount[partner];
-        for (uint32_t b = 0; b < nb && !joined; ++b)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            k2[u] = live[u] ? tkey[hh[u]] : CELL_EMPTY;
+        // the partner's slot (almost always the home slot or none; further probes one item at a time)
+        uint32_t partner[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
         {
-            const float4 pb = B[b];
-            for (uint32_t a = 0; a < na; ++a)
+            partner[u] = CELL_NONE;
+            uint32_t h = hh[u];
+            unsigned long long k = k2[u];
+            while (k != CELL_EMPTY)
             {
-                const float4 pa = A[a];
-                const float d0 = pa.x - pb.x, d1 = pa.y - pb.y, d2 = pa.z - pb.z;
-                if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)  // dist_sqr, src/kdtree.hpp:145-157, inclusive :315
+                if (k == nk[u])
                 {
-                    joined = true;
+                    partner[u] = h;
                     break;
                 }
+                h = (h + 1) & mask;
+                k = tkey[h];
             }
+            if (dbg == 1)
+                partner[u] = CELL_NONE;
         }
-        if (joined)
-            uf_unite(tparent, s, partner);
+        // the far pass first skips what the touching pass already united (grid_compress_kernel ran in between: one
+        // load per side answers it for all but the pairs of this pass)
+        if (FAR)
+        {
+            uint32_t pa[U], pb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                pa[u] = partner[u] != CELL_NONE ? uf_ld(tparent + sl[u]) : 0u;
+                pb[u] = partner[u] != CELL_NONE ? uf_ld(tparent + partner[u]) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (partner[u] != CELL_NONE && pa[u] == pb[u])
+                    partner[u] = CELL_NONE;
+        }
+        // quick test: the point that claimed the cell against the one that claimed the partner
+        float4 ra[U], rb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const bool on = partner[u] != CELL_NONE;
+            ra[u] = trep[on ? sl[u] : 0u];
+            rb[u] = trep[on ? partner[u] : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            if (partner[u] == CELL_NONE)
+                continue;
+            const uint32_t sc = sl[u], pc = partner[u];
+            if (FAR && uf_find(tparent, sc) == uf_find(tparent, pc))
+                continue;
+            {
+                const float d0 = ra[u].x - rb[u].x, d1 = ra[u].y - rb[u].y, d2 = ra[u].z - rb[u].z;
+                if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)
+                {
+                    if (dbg != 2)
+                        uf_unite(tparent, sc, pc);
+                    continue;
+                }
+            }
+            if (dbg == 3)
+                continue;
+            if (!FAR && uf_find(tparent, sc) == uf_find(tparent, pc))
+                continue;  // united meanwhile through other pairs
+            // every point of the partner against every point of the cell, until the first pair within d
+            bool joined = false;
+            const float4 *A = cpts + tstart[sc], *B = cpts + tstart[pc];
+            const uint32_t na = tcount[sc], nb = tcount[pc];
+            for (uint32_t bi = 0; bi < nb && !joined; ++bi)
+            {
+                const float4 pbp = B[bi];
+                for (uint32_t ai = 0; ai < na; ++ai)
+                {
+                    const float4 pap = A[ai];
+                    const float d0 = pap.x - pbp.x, d1 = pap.y - pbp.y, d2 = pap.z - pbp.z;
+                    if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)  // dist_sqr, src/kdtree.hpp:145-157, inclusive :315
+                    {
+                        joined = true;
+                        break;
+                    }
+                }
+            }
+            if (joined)
+                uf_unite(tparent, sc, pc);
+        }
     }
 }
 
@@ -2629,13 +2699,17 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     // latency).  A batch shares the device with the small-LDS workgroups of other chains' neighbour kernels,
     // next to which a 96 KiB workgroup rarely finds room; half the capacity schedules freely.
     const int blk_cap = ctx->cur_b > 1 ? BLK_CAP_BATCH : BLK_CAP_MAX;
-    const size_t key_lds = sizeof(float) * BLK_G * 4;  // key buffer of kd_block_kernel's flag pass
+    const size_t key_lds = sizeof(float) * BLK_G_MAX * 4;  // key buffer of kd_block_kernel's flag pass
     const size_t blk_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint32_t) * blk_cap + 64 * sizeof(uint32_t);
     const size_t lds_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint16_t) * blk_cap + 64 * sizeof(uint32_t);  // batches
     if (!ctx->attr_kd)
     {
         const size_t max_lds = sizeof(Node) * BLK_CAP_MAX + 2 * sizeof(uint32_t) * BLK_CAP_MAX + 64 * sizeof(uint32_t);
-        LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(max_lds + key_lds)));
+        LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(max_lds + key_lds)));
+        LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_block_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(max_lds + key_lds)));
         LPX_HIP(ctx, hipFuncSetAttribute((const void *)kd_lds_kernel<uint32_t>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
@@ -2692,8 +2766,21 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
         static const int tail_env = getenv("LPX_KD_TAIL") ? atoi(getenv("LPX_KD_TAIL")) : BLK_TAIL;
         const int stage_cap = stage ? blk_cap : (tail_env < blk_cap ? tail_env : blk_cap);
         const size_t stage_lds = sizeof(Node) * stage_cap + 2 * sizeof(uint32_t) * stage_cap + 64 * sizeof(uint32_t);
-        hipLaunchKernelGGL(kd_block_kernel, dim3(1u << level, 1, ctx->cur_b), dim3(BLK_G), stage_lds + key_lds, ctx->stream,
-                           nodes, lpos, rasc, frame, level, blk_cap, stage_cap, top, ctx->fs_tag);
+        // Workgroup size by range length.  An introselect round is a chain of dependent steps whatever the range holds
+        // (~100 us per level from 47k nodes down to 3k), so below BLK_WIDE nodes sixteen wavefronts only wait for one
+        // another: with many chains in flight what a kernel costs the device is its resident wavefronts x their
+        // lifetime, and four wavefronts per range instead of sixteen give the other chains three quarters of it back.
+        static const uint32_t wide_env = getenv("LPX_KD_WIDE") ? (uint32_t)atoi(getenv("LPX_KD_WIDE")) : BLK_WIDE;
+        static const uint32_t mid_env = getenv("LPX_KD_MID") ? (uint32_t)atoi(getenv("LPX_KD_MID")) : BLK_MID;
+        if (size > wide_env || ctx->cur_b == 1)
+            hipLaunchKernelGGL(kd_block_kernel<1024>, dim3(1u << level, 1, ctx->cur_b), dim3(1024), stage_lds + key_lds,
+                               ctx->stream, nodes, lpos, rasc, frame, level, blk_cap, stage_cap, top, ctx->fs_tag);
+        else if (size > mid_env)
+            hipLaunchKernelGGL(kd_block_kernel<256>, dim3(1u << level, 1, ctx->cur_b), dim3(256), stage_lds + key_lds,
+                               ctx->stream, nodes, lpos, rasc, frame, level, blk_cap, stage_cap, top, ctx->fs_tag);
+        else
+            hipLaunchKernelGGL(kd_block_kernel<64>, dim3(1u << level, 1, ctx->cur_b), dim3(64), stage_lds + key_lds,
+                               ctx->stream, nodes, lpos, rasc, frame, level, blk_cap, stage_cap, top, ctx->fs_tag);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
@@ -2819,10 +2906,18 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     hipLaunchKernelGGL(grid_scatter_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (const uint32_t *)ctx->cell_of.p,
                        (const uint32_t *)next, (const uint32_t *)tstart, cpts, ctx->fs_tag);
-    // one (cell, partner) pair per lane, grid-stride (the device knows how many cells there are)
+    // (cell, partner) pairs, four per lane and trip, grid-stride (the device knows how many cells there are).  Few
+    // workgroups per frame: the kernel is latency-bound, and under load what it costs the other chains is its resident
+    // wavefronts x their lifetime -- measured on 16 chains of 32 KITTI frames: 512 / 2048 workgroups per frame (near /
+    // far pass) 1589 Mpts/s, 128 / 512 1686, 32 / 128 1723, 16 / 64 1723, while the kernels alone take 336 + 313,
+    // 295 + 234 (64 / 256) and 484 + 255 us (16 / 64).  A single frame keeps the wide launch.
     {
-        const uint32_t pg0 = (m_max * 13u + 255u) / 256u < 512u ? (m_max * 13u + 255u) / 256u : 512u;
-        const uint32_t pg1 = (m_max * 13u + 255u) / 256u < 2048u ? (m_max * 13u + 255u) / 256u : 2048u;
+        static const uint32_t g0_env = getenv("LPX_GP_G0") ? (uint32_t)atoi(getenv("LPX_GP_G0")) : 32u;
+        static const uint32_t g1_env = getenv("LPX_GP_G1") ? (uint32_t)atoi(getenv("LPX_GP_G1")) : 128u;
+        const uint32_t w0 = ctx->cur_b > 1 || getenv("LPX_GP_G0") ? g0_env : 512u;
+        const uint32_t w1 = ctx->cur_b > 1 || getenv("LPX_GP_G1") ? g1_env : 2048u;
+        const uint32_t pg0 = (m_max * 13u + 255u) / 256u < w0 ? (m_max * 13u + 255u) / 256u : w0;
+        const uint32_t pg1 = (m_max * 13u + 255u) / 256u < w1 ? (m_max * 13u + 255u) / 256u : w1;
 #define GP_ARGS                                                                                                        \
     (const FrameState *)frame, (const unsigned long long *)tkey, tparent, (const uint32_t *)thead,                    \
         (const uint32_t *)tstart, (const uint32_t *)cells, (const float4 *)cpts, (const float4 *)ctx->cell_xyz.p, r2,  \
