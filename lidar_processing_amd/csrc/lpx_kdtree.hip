@@ -2014,6 +2014,9 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
 // pruned fail the distance test anyway) and is never culled.  grp_of[point] = gid.
 // ------------------------------------------------------------------------------------------------
 constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B + prefix = 4.6 KiB)
+#ifndef LPX_IX_BOX_UNROLL
+#define LPX_IX_BOX_UNROLL 4
+#endif
 
 __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__restrict__ PR,
                                                                const FrameState *__restrict__ frame, float rr,
@@ -2193,51 +2196,72 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
     const uint32_t stored = min(n_chunks, (uint32_t)LPX_GROUP_CHUNKS);
     const uint32_t row = lane / 16, col = lane % 16;
     float lo0 = 0.0f, lo1 = 0.0f, lo2 = 0.0f, hi0 = 0.0f, hi1 = 0.0f, hi2 = 0.0f;
-    for (uint32_t c4 = 0; c4 < stored; c4 += 4)
+    // (BX groups of four chunks per trip: the 4 BX node loads of a lane go out before any is folded -- the trips of
+    // this loop are independent, but one trip at a time made sixteen dependent round trips of it)
+    constexpr int BX = LPX_IX_BOX_UNROLL;
+    for (uint32_t c16 = 0; c16 < stored; c16 += 4 * BX)
     {
-        const uint32_t c = c4 + row;
-        const uint2 cc = c < stored ? s_out[w][c] : make_uint2(0u, 0u);
-        float a0 = 3.0e38f, a1 = 3.0e38f, a2 = 3.0e38f, b0 = -3.0e38f, b1 = -3.0e38f, b2 = -3.0e38f;
-        const uint32_t span = cc.y > 64u ? 64u : cc.y;  // the long tail chunk gets an unbounded box below
+        Node nd[BX][4];
+        uint32_t span[BX];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int g = 0; g < BX; ++g)
         {
-            const uint32_t o = col + 16 * u;
-            const Node nd = PR[o < span ? cc.x + o : 0u];  // unconditional: the four loads go out together
-            if (o < span)
+            const uint32_t c = c16 + 4 * g + row;
+            const uint2 cc = c < stored ? s_out[w][c] : make_uint2(0u, 0u);
+            span[g] = cc.y > 64u ? 64u : cc.y;  // the long tail chunk gets an unbounded box below
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
             {
-                a0 = fminf(a0, nd.x);
-                a1 = fminf(a1, nd.y);
-                a2 = fminf(a2, nd.z);
-                b0 = fmaxf(b0, nd.x);
-                b1 = fmaxf(b1, nd.y);
-                b2 = fmaxf(b2, nd.z);
+                const uint32_t o = col + 16 * u;
+                nd[g][u] = PR[o < span[g] ? cc.x + o : 0u];  // unconditional: the loads go out together
             }
         }
-        a0 = lpx_row_min15_f32(a0);
-        a1 = lpx_row_min15_f32(a1);
-        a2 = lpx_row_min15_f32(a2);
-        b0 = lpx_row_max15_f32(b0);
-        b1 = lpx_row_max15_f32(b1);
-        b2 = lpx_row_max15_f32(b2);
-        // row r's result (its lane 15) belongs to output lane c4 + r
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int g = 0; g < BX; ++g)
         {
-            const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0), 16 * r + 15));
-            const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), 16 * r + 15));
-            const float v2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 16 * r + 15));
-            const float v3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0), 16 * r + 15));
-            const float v4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1), 16 * r + 15));
-            const float v5 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b2), 16 * r + 15));
-            if (lane == c4 + r)
+            const uint32_t c4 = c16 + 4 * g;
+            if (c4 >= stored)
+                break;
+            float a0 = 3.0e38f, a1 = 3.0e38f, a2 = 3.0e38f, b0 = -3.0e38f, b1 = -3.0e38f, b2 = -3.0e38f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
             {
-                lo0 = v0;
-                lo1 = v1;
-                lo2 = v2;
-                hi0 = v3;
-                hi1 = v4;
-                hi2 = v5;
+                const uint32_t o = col + 16 * u;
+                if (o < span[g])
+                {
+                    a0 = fminf(a0, nd[g][u].x);
+                    a1 = fminf(a1, nd[g][u].y);
+                    a2 = fminf(a2, nd[g][u].z);
+                    b0 = fmaxf(b0, nd[g][u].x);
+                    b1 = fmaxf(b1, nd[g][u].y);
+                    b2 = fmaxf(b2, nd[g][u].z);
+                }
+            }
+            a0 = lpx_row_min15_f32(a0);
+            a1 = lpx_row_min15_f32(a1);
+            a2 = lpx_row_min15_f32(a2);
+            b0 = lpx_row_max15_f32(b0);
+            b1 = lpx_row_max15_f32(b1);
+            b2 = lpx_row_max15_f32(b2);
+            // row r's result (its lane 15) belongs to output lane c4 + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0), 16 * r + 15));
+                const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), 16 * r + 15));
+                const float v2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 16 * r + 15));
+                const float v3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0), 16 * r + 15));
+                const float v4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1), 16 * r + 15));
+                const float v5 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b2), 16 * r + 15));
+                if (lane == c4 + r)
+                {
+                    lo0 = v0;
+                    lo1 = v1;
+                    lo2 = v2;
+                    hi0 = v3;
+                    hi1 = v4;
+                    hi2 = v5;
+                }
             }
         }
     }
@@ -2337,6 +2361,9 @@ __global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long 
     thead[s] = 0;  // points of the cell
 }
 
+#ifndef LPX_GRID_INSERT_ITEMS
+#define LPX_GRID_INSERT_ITEMS 1  // (4 and 8 measured: no gain -- the kernel waits for its atomics, not for its loads)
+#endif
 __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *__restrict__ OX,
                                    const float *__restrict__ OY, const float *__restrict__ OZ, float d,
                                    unsigned long long *tkey, uint32_t *thead, uint32_t *__restrict__ next,
@@ -2354,36 +2381,69 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
     next = lpx_slot(next, fs);
     cells = lpx_slot(cells, fs);
     cell_of = lpx_slot(cell_of, fs);
-    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
-    if (i >= M)
-        return;
     const uint32_t mask = cell_cap_for(M, cap_max) - 1;
     const double inv_c = cell_inv_edge(d);
-    const float px = OX[i], py = OY[i], pz = OZ[i];
-    const unsigned long long key = ((unsigned long long)cell_coord(px, inv_c) << 42) |
-                                   ((unsigned long long)cell_coord(py, inv_c) << 21) |
-                                   (unsigned long long)cell_coord(pz, inv_c);
-    uint32_t h = cell_hash(key) & mask;
-    for (;;)
+    // GI points per lane (consecutive lanes on consecutive points): the coordinate loads, the first probes and the
+    // position counters of the GI points are in flight together; only a probe that has to move on and the rare claim
+    // of a new cell run one point at a time
+    constexpr int GI = LPX_GRID_INSERT_ITEMS;
+    uint32_t idx[GI], h[GI];
+    float px[GI], py[GI], pz[GI];
+    unsigned long long key[GI], old[GI];
+    bool in[GI];
+#pragma unroll
+    for (int u = 0; u < GI; ++u)
     {
-        // look before the compare-and-swap: all but the first points of a cell find its key with a plain (L2) load,
-        // and atomics on one address serialise -- a dense cell near the sensor holds hundreds of points
-        unsigned long long old = __hip_atomic_load(tkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == CELL_EMPTY)
-            old = atomicCAS(tkey + h, CELL_EMPTY, key);
-        if (old == CELL_EMPTY)
-        {
-            cells[atomicAdd(&frame->n_cells, 1u)] = h;  // this point claimed the cell: list it ...
-            trep[h] = make_float4(px, py, pz, 0.0f);     // ... and represents it in the quick test of the linking
-            break;
-        }
-        if (old == key)
-            break;
-        h = (h + 1) & mask;
+        idx[u] = (lpx_blk.x * GI + u) * blockDim.x + threadIdx.x;
+        in[u] = idx[u] < M;
+        px[u] = in[u] ? OX[idx[u]] : 0.0f;
+        py[u] = in[u] ? OY[idx[u]] : 0.0f;
+        pz[u] = in[u] ? OZ[idx[u]] : 0.0f;
     }
-    cell_of[i] = h;
-    next[i] = atomicAdd(thead + h, 1u);  // the point's position among the points of its cell
+#pragma unroll
+    for (int u = 0; u < GI; ++u)
+    {
+        key[u] = ((unsigned long long)cell_coord(px[u], inv_c) << 42) | ((unsigned long long)cell_coord(py[u], inv_c) << 21) |
+                 (unsigned long long)cell_coord(pz[u], inv_c);
+        h[u] = cell_hash(key[u]) & mask;
+        old[u] = in[u] ? __hip_atomic_load(tkey + h[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : key[u];
+    }
+#pragma unroll
+    for (int u = 0; u < GI; ++u)
+    {
+        if (!in[u])
+            continue;
+        unsigned long long o = old[u];
+        for (;;)
+        {
+            // look before the compare-and-swap: all but the first points of a cell find its key with a plain (L2) load,
+            // and atomics on one address serialise -- a dense cell near the sensor holds hundreds of points
+            if (o == CELL_EMPTY)
+                o = atomicCAS(tkey + h[u], CELL_EMPTY, key[u]);
+            if (o == CELL_EMPTY)
+            {
+                cells[atomicAdd(&frame->n_cells, 1u)] = h[u];           // this point claimed the cell: list it ...
+                trep[h[u]] = make_float4(px[u], py[u], pz[u], 0.0f);    // ... and represents it in the quick test of the linking
+                break;
+            }
+            if (o == key[u])
+                break;
+            h[u] = (h[u] + 1) & mask;
+            o = __hip_atomic_load(tkey + h[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    uint32_t pos[GI];
+#pragma unroll
+    for (int u = 0; u < GI; ++u)
+        pos[u] = in[u] ? atomicAdd(thead + h[u], 1u) : 0u;  // the point's position among the points of its cell
+#pragma unroll
+    for (int u = 0; u < GI; ++u)
+        if (in[u])
+        {
+            cell_of[idx[u]] = h[u];
+            next[idx[u]] = pos[u];
+        }
 }
 
 // The points of every cell as ONE contiguous run of {x, y, z, index} records (the linking then reads a cell's points
@@ -2896,7 +2956,8 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     uint32_t *next = (uint32_t *)ctx->parent.p, *cells = (uint32_t *)ctx->lpos.p;  // free in this path
     hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, thead, ctx->cell_cap,
                        ctx->fs_tag);
-    hipLaunchKernelGGL(grid_insert_kernel, gm, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
+    const dim3 gi((m_max + 256 * LPX_GRID_INSERT_ITEMS - 1) / (256 * LPX_GRID_INSERT_ITEMS), 1, ctx->cur_b);
+    hipLaunchKernelGGL(grid_insert_kernel, gi, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells,
                        (uint32_t *)ctx->cell_of.p, (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fs_tag);
     uint32_t *tstart = (uint32_t *)ctx->cell_start.p;
