@@ -54,11 +54,11 @@ PROFILE_ROUND = "r03"  # committed rocprofv3 summaries this line points at: prof
 WORKLOADS = {
     "kitti": dict(config="configs[1]: 120k-pt KITTI frames (three frames cycled), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                   seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
-                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=512, batch=32, contexts=16),
+                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=640, batch=32, contexts=20),
     "stream": dict(config="configs[1] parameters on configs[3]'s frames: all 154 data/*.pcd 120k-pt KITTI frames in order "
-                          "(three passes over the sequence per step), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
+                          "(the sequence cycled: 704 frames per step), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                    seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
-                   clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=462, batch=32, contexts=15),
+                   clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=704, batch=32, contexts=22),
     "synth1m": dict(config="configs[2]: synthetic 1M-pt plane + boxes, 12 segments, 3 iters, FEC d=0.3 m q=0.5",
                     seg=dict(number_of_planar_partitions=12, number_of_iterations=3),
                     clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=64, batch=8, contexts=8),

@@ -1336,7 +1336,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // bitmaps hold of every CU's LDS is what the LDS-staged kernels of the other chains (kd subtrees, chunk tables,
         // seed selection) cannot get.  So the bitmap is sized by the largest obstacle count the context's previous call
         // saw (+25 %); a frame that exceeds it is served by the second launch.
-        static const int rs_fit = getenv("LPX_RS_FIT") ? atoi(getenv("LPX_RS_FIT")) : 1;
+        static const int rs_fit = getenv("LPX_RS_FIT") ? atoi(getenv("LPX_RS_FIT")) : 0;  // (measured: no gain, and a second launch per chain)
         if (rs_fit && ctx->cur_b > 1 && ctx->h_search && m_lds)
         {
             const uint32_t seen = (uint32_t)(ctx->h_search[5] & 0xffffffffull);

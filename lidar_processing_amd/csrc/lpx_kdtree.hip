@@ -1069,7 +1069,10 @@ __device__ __forceinline__ uint32_t kd_rank_of(uint32_t p, uint32_t M)
     }
 }
 
-constexpr int LG = 256;  // threads of kd_lds_kernel: one wavefront per SIMD, little per-round overhead
+#ifndef LPX_KD_LG
+#define LPX_KD_LG 256
+#endif
+constexpr int LG = LPX_KD_LG;  // threads of kd_lds_kernel: one wavefront per SIMD, little per-round overhead
 
 template <typename PosT>  // stop-list entries: uint16_t (batches: 20 B of LDS per node) or uint32_t (a single frame)
 __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restrict__ PR,
@@ -2975,8 +2978,11 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     {
         static const uint32_t g0_env = getenv("LPX_GP_G0") ? (uint32_t)atoi(getenv("LPX_GP_G0")) : 32u;
         static const uint32_t g1_env = getenv("LPX_GP_G1") ? (uint32_t)atoi(getenv("LPX_GP_G1")) : 128u;
-        const uint32_t w0 = ctx->cur_b > 1 || getenv("LPX_GP_G0") ? g0_env : 512u;
-        const uint32_t w1 = ctx->cur_b > 1 || getenv("LPX_GP_G1") ? g1_env : 2048u;
+        // (per 128k points of the largest frame: a 1M-point frame gets eight times the workgroups of a KITTI frame)
+        static const uint32_t gs_env = getenv("LPX_GP_SCALE") ? (uint32_t)atoi(getenv("LPX_GP_SCALE")) : 1u;
+        const uint32_t scale = gs_env ? (m_max + 131071u) / 131072u : 1u;
+        const uint32_t w0 = ctx->cur_b > 1 || getenv("LPX_GP_G0") ? g0_env * scale : 512u;
+        const uint32_t w1 = ctx->cur_b > 1 || getenv("LPX_GP_G1") ? g1_env * scale : 2048u;
         const uint32_t pg0 = (m_max * 13u + 255u) / 256u < w0 ? (m_max * 13u + 255u) / 256u : w0;
         const uint32_t pg1 = (m_max * 13u + 255u) / 256u < w1 ? (m_max * 13u + 255u) / 256u : w1;
 #define GP_ARGS                                                                                                        \
