@@ -54,11 +54,11 @@ PROFILE_ROUND = "r03"  # committed rocprofv3 summaries this line points at: prof
 WORKLOADS = {
     "kitti": dict(config="configs[1]: 120k-pt KITTI frames (three frames cycled), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                   seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
-                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=640, batch=32, contexts=20),
+                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=1280, batch=64, contexts=20),
     "stream": dict(config="configs[1] parameters on configs[3]'s frames: all 154 data/*.pcd 120k-pt KITTI frames in order "
-                          "(the sequence cycled: 704 frames per step), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
+                          "(the sequence cycled: 1280 frames per step), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                    seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
-                   clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=704, batch=32, contexts=22),
+                   clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=1280, batch=64, contexts=20),
     "synth1m": dict(config="configs[2]: synthetic 1M-pt plane + boxes, 12 segments, 3 iters, FEC d=0.3 m q=0.5",
                     seg=dict(number_of_planar_partitions=12, number_of_iterations=3),
                     clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=128, batch=16, contexts=8),
@@ -228,6 +228,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the one-core CPU baseline leg")
     ap.add_argument("--lists", action="store_true", help="A/B: materialise every radius list (LPX_NEIGHBOURS_LISTS)")
     ap.add_argument("--search", action="store_true", help="A/B: expansion-driven searches (LPX_NEIGHBOURS_SEARCH)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="batch contexts with lpx_set_overlap: replay + labels of a chain on a second stream beside the "
+                         "context's next chain (half the frames in flight for the same rate; use about 10 contexts: the "
+                         "device serves about 24 hardware queues at full speed)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default=None,
                     help="torch.distributed backend of the barrier / MAX / SUM (default nccl = RCCL; gloo with --dry-run)")
     ap.add_argument("--dry-run", action="store_true",
@@ -264,6 +268,7 @@ class Plan:
         wl = WORKLOADS[name]
         self.name, self.wl, self.torch = name, wl, torch
         self.lists = not args.search and (args.lists or wl.get("lists", False))
+        self.overlap = args.overlap
         self.scfg = lpx.SegmentationConfiguration(**wl["seg"])
         self.ccfg = lpx.ClusteringConfiguration(**wl["clu"])
         self.P, self.I = wl["seg"]["number_of_planar_partitions"], wl["seg"]["number_of_iterations"]
@@ -294,10 +299,12 @@ class Plan:
         self.T = max(1, min(args.threads, C))
         self.pool = concurrent.futures.ThreadPoolExecutor(self.T) if self.T > 1 else None
 
-    def new_context(self, lpx, batch, mode=None):
+    def new_context(self, lpx, batch, mode=None, overlap=None):
         c = lpx.Context(self.local_rank, batch=batch)
         c.set_neighbour_mode(mode or ("lists" if self.lists else "search"))  # a batch=1 context would default to lists
         c.reserve(self.pitch)
+        if batch > 1 and (self.overlap if overlap is None else overlap):
+            c.set_overlap(True)  # replay + labels of a chain beside the front end of the context's next chain
         return c
 
     def enqueue_frames(self, ctx, lo, hi):
@@ -524,16 +531,18 @@ def inflight_curve(plan, lpx, seconds=0.6):
     4-sensor rig (4 in flight) or a 32-frame backlog gets, between the two ends the headline and `latency` show."""
     import threading
     own = "lists" if plan.lists else "search"
-    shapes = [(1, 1, "lists"), (1, 1, "search"), (4, 1, "lists"), (4, 1, "search"), (1, 4, "search"),
-              (16, 1, "lists"), (2, 8, "search"), (1, 16, "search"), (8, 8, "search"), (2, 32, "search"),
-              (4, 32, "search"), (8, 32, "search"), (plan.C, plan.B, own)]  # the last row is the headline's own shape
+    shapes = [(1, 1, "lists", False), (1, 1, "search", False), (4, 1, "lists", False), (4, 1, "search", False),
+              (1, 4, "search", False), (16, 1, "lists", False), (2, 8, "search", False), (1, 16, "search", False),
+              (8, 8, "search", False), (2, 32, "search", False), (4, 32, "search", False), (8, 32, "search", False),
+              (20, 32, "search", False), (plan.C, plan.B, own, plan.overlap)]  # the last row: the headline's own shape
     rows = []
     F = plan.F
-    for C, B, mode in shapes:
-        if C * B > F or (rows and (C, B, mode) == shapes[-1] and rows[-1]["contexts"] == C and rows[-1]["frames_per_chain"] == B):
+    for C, B, mode, ovl in shapes:
+        if C * B > F or (rows and (C, B, mode, ovl) == shapes[-1] and rows[-1]["contexts"] == C
+                         and rows[-1]["frames_per_chain"] == B and rows[-1]["overlap"] == ovl):
             continue
-        reuse = (B == plan.B and mode == ("lists" if plan.lists else "search") and C <= plan.C)
-        ctxs = plan.ctxs[:C] if reuse else [plan.new_context(lpx, B, mode) for _ in range(C)]
+        reuse = (B == plan.B and mode == own and C <= plan.C and ovl == plan.overlap)
+        ctxs = plan.ctxs[:C] if reuse else [plan.new_context(lpx, B, mode, ovl) for _ in range(C)]
         lat = [[] for _ in range(C)]
         frames = [0] * C
         points = [0] * C
@@ -546,19 +555,29 @@ def inflight_curve(plan, lpx, seconds=0.6):
             for warm in (2, 1, 0):  # two untimed chains (allocation, table sizes), then the timed loop
                 if not warm:
                     start_evt.wait()
+                prev = None  # overlap: (enqueue time, points) of the chain still in flight
                 while True:
                     lo = k % (F - B + 1)
                     a = time.perf_counter()
                     plan.enqueue_frames(ctxs[i], lo, lo + B)
-                    ctxs[i].synchronize()
+                    if ovl:
+                        ctxs[i].wait_previous()  # chain k - 1 is complete; chain k stays in flight
+                    else:
+                        ctxs[i].synchronize()
                     b = time.perf_counter()
                     k += C * B
                     if warm:
+                        ctxs[i].synchronize()
                         break
-                    lat[i].append(b - a)
-                    frames[i] += B
-                    points[i] += int(plan.n_points[lo:lo + B].sum())
+                    done = (a, int(plan.n_points[lo:lo + B].sum()))
+                    if ovl:
+                        done, prev = prev, done
+                    if done is not None:
+                        lat[i].append(b - done[0])
+                        frames[i] += B
+                        points[i] += done[1]
                     if b >= stop:
+                        ctxs[i].synchronize()
                         break
 
         th = [threading.Thread(target=loop, args=(i,)) for i in range(C)]
@@ -572,7 +591,8 @@ def inflight_curve(plan, lpx, seconds=0.6):
             x.join()
         wall = time.perf_counter() - t0
         allat = np.concatenate([np.array(x) for x in lat]) * 1e3
-        rows.append({"frames_in_flight": C * B, "contexts": C, "frames_per_chain": B, "neighbour_mode": mode,
+        rows.append({"frames_in_flight": C * B * (2 if ovl else 1), "contexts": C, "frames_per_chain": B, "neighbour_mode": mode,
+                     "overlap": ovl,
                      "mpts_s": round(sum(points) / wall / 1e6, 1), "frames_per_s": round(sum(frames) / wall, 1),
                      "p50_frame_completion_ms": round(float(np.median(allat)), 3),
                      "p99_frame_completion_ms": round(float(np.percentile(allat, 99)), 3)})
@@ -580,7 +600,9 @@ def inflight_curve(plan, lpx, seconds=0.6):
             for c in ctxs:
                 c.close()
     return {"what": "closed loops: every context enqueues a chain of B frames and waits for it; C x B frames in flight; "
-                    "completion = enqueue of the chain -> all its results resident in HBM (device-resident inputs)",
+                    "completion = enqueue of the chain -> all its results resident in HBM (device-resident inputs); "
+                    "overlap = lpx_set_overlap (a context keeps TWO chains in flight: it waits for chain k - 1 after it "
+                    "has enqueued chain k)",
             "seconds_per_point": seconds, "curve": rows}
 
 
@@ -687,7 +709,7 @@ def main(argv=None):
     elapsed, counts = plan.timed(args.steps, args.warmup, barrier)
     elapsed, total_points_per_step, total_frames_per_step = aggregate(elapsed, plan.points_per_step, dev, world, plan.F)
 
-    roofline, latency, stream_info, inflight, sub = None, None, None, None, None
+    roofline, latency, stream_info, inflight, sub, overlap_sub = None, None, None, None, None, None
     stage_ms = {}
     if rank == 0:
         stage_ms, launches, per_launch = stage_profile(plan, args.steps)
@@ -707,6 +729,20 @@ def main(argv=None):
         del plan
         torch.cuda.empty_cache()
         plan = None
+        # ... and the same stream with lpx_set_overlap on 10 contexts: half the frames in flight of the headline
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "stream", "--overlap", "--contexts",
+                                "10", "--batch", "64", "--frames-per-step", "640", "--steps", str(args.steps), "--warmup",
+                                str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight", "--no-sub"],
+                               capture_output=True, text=True, timeout=600)
+            d4 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            overlap_sub = {"mpts_s": d4["value"], "ms_per_step": d4["ms_per_step"],
+                           "frames_per_step": d4["config"]["frames_per_step"], "contexts": d4["config"]["contexts_per_gpu"],
+                           "frames_per_launch_chain": d4["config"]["frames_per_launch_chain"],
+                           "what": "the same workload with lpx_set_overlap (replay + labels of a chain on a second stream "
+                                   "beside the context's next chain, two slot sets per context), own process"}
+        except Exception as e:
+            overlap_sub = {"error": repr(e)[:200]}
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "kitti", "--steps", str(args.steps),
                                 "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight",
@@ -738,6 +774,7 @@ def main(argv=None):
             "config": {"workload": wl["config"], "neighbour_mode": "lists" if (not args.search and (args.lists or wl.get("lists"))) else "search",
                        "frames_per_step_per_gpu": F, "frames_per_launch_chain": max(1, min(args.batch or wl["batch"], F)),
                        "contexts_per_gpu": max(1, min(args.contexts or wl["contexts"], -(-F // max(1, min(args.batch or wl["batch"], F))))),
+                       "overlap": bool(args.overlap),
                        "host_threads_per_gpu": args.threads, "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "points_per_step": int(total_points_per_step), "frames_per_step": int(total_frames_per_step),
                        "frames_per_s": round(total_frames_per_step * args.steps / elapsed, 2),
@@ -755,6 +792,8 @@ def main(argv=None):
             line["stream"] = stream_info
         if sub:
             line["kitti_3_frames_cycled"] = sub
+        if overlap_sub:
+            line["with_overlap"] = overlap_sub
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:

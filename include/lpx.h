@@ -113,6 +113,18 @@ const char *lpx_last_error(const lpx_ctx *ctx);
 /* blocks until everything enqueued on the context stream has finished */
 int lpx_synchronize(lpx_ctx *ctx);
 
+/* Overlapped tail for batch contexts (lpx_create_batch): with `on`, consecutive lpx_segment_cluster_batch_device calls
+ * alternate between two sets of frame slots (the workspace doubles), and the last part of a call -- the ordered
+ * replay of Clusterer::cluster and the label kernels -- runs on a second stream while the context's stream already
+ * takes the next call.  Results are the same; what changes is WHEN they are complete: the outputs of a call are
+ * final after lpx_synchronize (which waits for both streams), not in the order of the context's stream -- do not use
+ * it on a caller's stream whose later work reads the results without a host synchronisation.  Throughput only: a
+ * single call is not faster. */
+int lpx_set_overlap(lpx_ctx *ctx, int on);
+/* host wait until every batch call of an overlapped context but the LAST one is complete (a pipelined caller enqueues
+ * call k, then collects call k - 1); without overlap the same as lpx_synchronize */
+int lpx_wait_previous(lpx_ctx *ctx);
+
 /* ---- host entry points (synchronous; what the C++ wrappers call) ---------------------------- */
 
 /* Segmenter::segment (reference src/segmentation.cpp:311-345).

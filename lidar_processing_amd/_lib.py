@@ -68,6 +68,8 @@ def lib():
     L.lpx_last_error.argtypes = [vp]
     L.lpx_last_error.restype = C.c_char_p
     L.lpx_synchronize.argtypes = [vp]
+    L.lpx_set_overlap.argtypes = [vp, C.c_int]
+    L.lpx_wait_previous.argtypes = [vp]
     L.lpx_segment.argtypes = [vp, vp, sz, u32, C.POINTER(SegCfg), vp, vp, pu32, vp, pu32, vp]
     L.lpx_cluster.argtypes = [vp, vp, sz, u32, C.POINTER(CluCfg), vp, pu32]
     L.lpx_segment_cluster.argtypes = [vp, vp, sz, u32, C.POINTER(SegCfg), C.POINTER(CluCfg), vp, vp, pu32, vp, pu32,

@@ -123,6 +123,15 @@ class Context:
     def use_lists(self, on=True):
         self.set_neighbour_mode("lists" if on else "search")
 
+    def set_overlap(self, on=True):
+        """lpx_set_overlap: batch contexts alternate between two slot sets and run the replay + label kernels of a
+        call on a second stream (throughput; results are final after synchronize())"""
+        self.check(self._L.lpx_set_overlap(self._h, 1 if on else 0))
+
+    def wait_previous(self):
+        """lpx_wait_previous: every batch call but the last one is complete (overlapped contexts)"""
+        self.check(self._L.lpx_wait_previous(self._h))
+
     def synchronize(self):
         self.check(self._L.lpx_synchronize(self._h))
 

@@ -2,6 +2,7 @@
 #include "lpx_internal.h"
 
 #include <atomic>
+#include <mutex>
 #include <time.h>
 #include "lpx_debug.h"
 
@@ -49,6 +50,8 @@ int lpx_ensure(lpx_ctx *ctx, Buf &b, size_t bytes)
     b.bytes = bytes;
     return LPX_OK;
 }
+
+static int sync_all(lpx_ctx *ctx);  // host wait for everything a context enqueued (overlapped tails included)
 
 static inline size_t align256(size_t v)
 {
@@ -184,6 +187,13 @@ static int begin_call(lpx_ctx *ctx, uint32_t frames, uint32_t upitch)
 {
     if (frames == 0 || frames > ctx->batch)
         return lpx_fail(ctx, LPX_ERR_ARG, "%u frames in a call, the context has %u frame slots", frames, ctx->batch);
+    if (ctx->tail_pending)
+    {
+        // the tail of an earlier overlapped call still reads (and writes) this slot set
+        if (hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0) != hipSuccess)
+            return lpx_fail(ctx, LPX_ERR_HIP, "hipStreamWaitEvent on the overlapped tail failed");
+        ctx->tail_pending = false;
+    }
     ctx->cur_b = frames;
     ctx->upitch = upitch;
     ctx->seg_valid = false;  // set again at the end of a host segmentation call (what lpx_coloured_clouds serves)
@@ -284,19 +294,29 @@ extern "C" int lpx_profile_read(lpx_ctx *ctx, float *ms, uint32_t *launches, int
 {
     if (!ctx)
         return LPX_ERR_ARG;
-    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < ctx->n_pending; ++i)
     {
-        float t = 0.0f;
-        if (hipEventElapsedTime(&t, ctx->pending[i].a, ctx->pending[i].b) == hipSuccess)
-        {
-            ctx->st_ms[ctx->pending[i].stage] += t;
-            ctx->st_launches[ctx->pending[i].stage] += 1;
-        }
-        hipEventDestroy(ctx->pending[i].a);
-        hipEventDestroy(ctx->pending[i].b);
+        const int rc = sync_all(ctx);
+        if (rc)
+            return rc;
     }
-    ctx->n_pending = 0;
+    lpx_ctx *sets[2] = {ctx, ctx->twin};
+    for (lpx_ctx *c : sets)
+    {
+        if (!c)
+            continue;
+        for (int i = 0; i < c->n_pending; ++i)
+        {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, c->pending[i].a, c->pending[i].b) == hipSuccess)
+            {
+                ctx->st_ms[c->pending[i].stage] += t;
+                ctx->st_launches[c->pending[i].stage] += 1;
+            }
+            hipEventDestroy(c->pending[i].a);
+            hipEventDestroy(c->pending[i].b);
+        }
+        c->n_pending = 0;
+    }
     for (int s = 0; s < ST_COUNT; ++s)
     {
         if (ms)
@@ -441,6 +461,17 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
         return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->tail_pending)
+        hipEventSynchronize(ctx->ev_tail);
+    if (ctx->twin)
+    {
+        lpx_destroy(ctx->twin);
+        ctx->twin = nullptr;
+    }
+    if (ctx->ev_front)
+        hipEventDestroy(ctx->ev_front);
+    if (ctx->ev_tail)
+        hipEventDestroy(ctx->ev_tail);
     if (ctx->arena)
         hipFree(ctx->arena);
     if (ctx->nb_arena)
@@ -485,11 +516,136 @@ extern "C" int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point)
     return lpx_ensure_capacity(ctx, ctx->cap_n, ctx->cap_nb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Overlapped tail (lpx_set_overlap).  In a closed loop of N chains the replay is the one stage whose duration does not
+// shrink with the load it shares the device with: the wide kernels of a chain take N x their share of the device, the
+// replay -- a few latency-bound wavefronts per frame -- takes its ~10 ms whatever else runs, and while a context's
+// stream sits in it the context contributes nothing to the wide work.  With the tail on a second stream and a second
+// set of frame slots, the context's stream goes straight on to the front end of its next chain: the delay leaves the
+// cycle.  The tail streams are a small pool per device shared by all contexts (a tail stream is idle most of the
+// time; 22 contexts + 8 tail streams stay within the 32 hardware queues the bench asks for).
+// ------------------------------------------------------------------------------------------------
+constexpr int TAIL_POOL_MAX = 64;
+static hipStream_t g_tail_pool[16][TAIL_POOL_MAX];
+static std::atomic<int> g_tail_made[16];
+static std::atomic<uint32_t> g_tail_next[16];
+static std::mutex g_tail_mutex;
+
+static hipStream_t tail_stream_for(int device)
+{
+    static const int pool = [] {
+        const char *e = getenv("LPX_TAIL_STREAMS");
+        const int v = e ? atoi(e) : 12;
+        return v < 1 ? 1 : (v > TAIL_POOL_MAX ? TAIL_POOL_MAX : v);
+    }();
+    if (device < 0 || device >= 16)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(g_tail_mutex);
+    const uint32_t k = g_tail_next[device].fetch_add(1) % (uint32_t)pool;
+    while (g_tail_made[device].load() <= (int)k)
+    {
+        const int i = g_tail_made[device].load();
+        if (hipStreamCreateWithFlags(&g_tail_pool[device][i], hipStreamNonBlocking) != hipSuccess)
+            return nullptr;
+        g_tail_made[device].store(i + 1);
+    }
+    return g_tail_pool[device][k];
+}
+
+static int overlap_arm(lpx_ctx *c)
+{
+    if (c->tail_stream)
+        return LPX_OK;
+    c->tail_stream = tail_stream_for(c->device);
+    if (!c->tail_stream || hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess)
+        return lpx_fail(c, LPX_ERR_HIP, "the overlapped tail could not get its stream and events");
+    return LPX_OK;
+}
+
+// waits (on the host) for everything a context has enqueued, tails of both slot sets included
+static int sync_all(lpx_ctx *ctx)
+{
+    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lpx_ctx *sets[2] = {ctx, ctx->twin};
+    for (lpx_ctx *c : sets)
+        if (c && c->tail_pending)
+            LPX_HIP(ctx, hipEventSynchronize(c->ev_tail));  // (stays pending for the STREAM until begin_call waits)
+    return LPX_OK;
+}
+
+extern "C" int lpx_set_overlap(lpx_ctx *ctx, int on)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    if (ctx->batch < 2 && on)
+        return lpx_fail(ctx, LPX_ERR_ARG, "lpx_set_overlap serves batch contexts (lpx_create_batch)");
+    LPX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = sync_all(ctx);
+    if (rc)
+        return rc;
+    if (on && !ctx->twin)
+    {
+        if ((rc = overlap_arm(ctx)))
+            return rc;
+        lpx_ctx *t = nullptr;
+        if ((rc = create_common(ctx->device, ctx->stream, false, ctx->batch, &t)))
+            return lpx_fail(ctx, rc, "the second slot set of the overlapped context could not be created");
+        // both slot sets hand their tails to ONE stream: consecutive tails of a context may as well queue behind one
+        // another, and hardware queues are scarce (the device serves about 24 at full speed)
+        t->tail_stream = ctx->tail_stream;
+        if (hipEventCreateWithFlags(&t->ev_front, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&t->ev_tail, hipEventDisableTiming) != hipSuccess)
+        {
+            lpx_destroy(t);
+            return lpx_fail(ctx, LPX_ERR_HIP, "the overlapped tail could not get its events");
+        }
+        ctx->twin = t;
+    }
+    ctx->overlap = on != 0;
+    ctx->last = nullptr;
+    return LPX_OK;
+}
+
+// the slot set that serves the next overlapped batch call, with the primary's settings
+static lpx_ctx *overlap_pick(lpx_ctx *ctx)
+{
+    if (!ctx->overlap || !ctx->twin)
+    {
+        ctx->last = ctx;
+        return ctx;
+    }
+    lpx_ctx *t = (ctx->flip++ & 1u) ? ctx->twin : ctx;
+    if (t != ctx)
+    {
+        t->use_lists = ctx->use_lists;
+        t->nb_per_point = ctx->nb_per_point;
+        t->rs_per_point = ctx->rs_per_point;
+        t->profiling = ctx->profiling;
+        t->dbg_buf = ctx->dbg_buf;
+    }
+    ctx->last = t;
+    return t;
+}
+
 extern "C" int lpx_synchronize(lpx_ctx *ctx)
 {
     if (!ctx)
         return LPX_ERR_ARG;
-    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return sync_all(ctx);
+}
+
+// Overlapped contexts keep two batch calls in flight: this waits (on the host) until every call but the LAST one is
+// complete, i.e. for the tail of the slot set the last call did not use.  Without overlap it is lpx_synchronize.
+extern "C" int lpx_wait_previous(lpx_ctx *ctx)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    if (!ctx->overlap || !ctx->twin || !ctx->last)
+        return sync_all(ctx);
+    lpx_ctx *other = ctx->last == ctx ? ctx->twin : ctx;
+    if (other->tail_pending)
+        LPX_HIP(ctx, hipEventSynchronize(other->ev_tail));
     return LPX_OK;
 }
 
@@ -649,8 +805,16 @@ extern "C" int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames,
                                                 uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes,
                                                 int32_t *d_clabels, uint32_t *d_counts)
 {
-    return lpx_batch_impl(ctx, n_frames, d_pts, stride, nullptr, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels, d_gidx,
-                          d_oidx, d_planes, d_clabels, d_counts);
+    if (!ctx)
+        return LPX_ERR_ARG;
+    lpx_ctx *t = overlap_pick(ctx);
+    t->split_tail = t->tail_stream != nullptr && ctx->overlap;
+    const int rc = lpx_batch_impl(t, n_frames, d_pts, stride, nullptr, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels,
+                                  d_gidx, d_oidx, d_planes, d_clabels, d_counts);
+    t->split_tail = false;
+    if (rc && t != ctx)
+        lpx_fail(ctx, rc, "%s", t->err);
+    return rc;
 }
 
 // the same for n_frames PointCloud2-style buffers (records of point_step bytes, x / y / z at the given offsets)
@@ -943,6 +1107,8 @@ extern "C" int lpx_coloured_clouds_batch_device(lpx_ctx *ctx, uint32_t n_frames,
     LPX_HIP(ctx, hipSetDevice(ctx->device));
     if (n_frames == 0 || n_frames > ctx->batch)
         return lpx_fail(ctx, LPX_ERR_ARG, "%u frames, the context has %u frame slots", n_frames, ctx->batch);
+    if (ctx->last)
+        ctx = ctx->last;  // overlapped context: the slot set of the last batch call holds the frames
     ctx->cur_b = n_frames;
     ctx->upitch = frame_pitch;
     return lpx_run_colour(ctx, frame_pitch, d_gidx, d_oidx, d_ground_records, d_obstacle_records);
@@ -1107,6 +1273,13 @@ extern "C" int lpx_dbg_search_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *
 {
     if (!ctx || !out4 || slot >= ctx->batch)
         return LPX_ERR_ARG;
+    {
+        const int rc = sync_all(ctx);  // (an overlapped tail writes the statistics)
+        if (rc)
+            return rc;
+        if (ctx->last)
+            ctx = ctx->last;  // the slot set of the last batch call
+    }
     FrameState fs;
     LPX_HIP(ctx, hipMemcpyAsync(&fs, (const char *)ctx->frame.p + (size_t)slot * ctx->fstride, sizeof fs,
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -1122,6 +1295,13 @@ extern "C" int lpx_dbg_frame_stats_slot(lpx_ctx *ctx, uint32_t slot, uint32_t *o
 {
     if (!ctx || !out12 || slot >= ctx->batch)
         return LPX_ERR_ARG;
+    {
+        const int rc = sync_all(ctx);  // (an overlapped tail writes the statistics)
+        if (rc)
+            return rc;
+        if (ctx->last)
+            ctx = ctx->last;  // the slot set of the last batch call
+    }
     FrameState fs;
     LPX_HIP(ctx, hipMemcpyAsync(&fs, (const char *)ctx->frame.p + (size_t)slot * ctx->fstride, sizeof fs,
                                 hipMemcpyDeviceToHost, ctx->stream));

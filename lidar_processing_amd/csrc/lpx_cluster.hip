@@ -1289,6 +1289,35 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                            cc_lo, cc_hi, (uint32_t *)ctx->rpos.p, (int32_t *)ctx->seed_of.p, valid, prm.min_size,
                            prm.max_size, fv.fs);
     }
+    // Overlapped tail: everything from here on (the replay, the label scan, the relabel kernel and the counts) depends
+    // only on what the kernels above left in THIS slot set, and the caller's stream is free for the front end of its
+    // next chain (on the twin slot set).  The tail stream waits for the front end; the next call on this slot set waits
+    // for the tail (begin_call).  ctx->stream is swapped for the duration so that the stage timers and the scan helper
+    // follow.
+    hipStream_t const front_stream = ctx->stream;
+    struct TailScope
+    {
+        lpx_ctx *c;
+        hipStream_t front;
+        bool on;
+        ~TailScope()
+        {
+            if (on)
+            {
+                hipEventRecord(c->ev_tail, c->stream);
+                c->stream = front;
+                c->tail_pending = true;
+            }
+        }
+    } tail_scope{ctx, front_stream, false};
+    if (ctx->split_tail && ctx->tail_stream && ctx->ev_front && ctx->ev_tail)
+    {
+        LPX_HIP(ctx, hipEventRecord(ctx->ev_front, front_stream));
+        LPX_HIP(ctx, hipStreamWaitEvent(ctx->tail_stream, ctx->ev_front, 0));
+        ctx->stream = ctx->tail_stream;
+        st = ctx->tail_stream;
+        tail_scope.on = true;
+    }
     if (!ctx->use_lists && !skip_replay)
     {
         StageTimer tm(ctx, ST_REPLAY);

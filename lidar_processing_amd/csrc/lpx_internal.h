@@ -135,6 +135,17 @@ struct lpx_ctx
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // ---- overlapped tail (lpx_set_overlap, batch contexts): the replay and the label kernels of a chain run on a
+    // second stream while the context's stream already takes the front end of the next chain, which works on a SECOND
+    // set of frame slots (`twin`, a context of its own on the same stream).  See lpx_api.hip: overlap_*.
+    bool overlap = false;          // primary: calls alternate between this context and its twin
+    lpx_ctx *twin = nullptr;       // primary: the second slot set
+    lpx_ctx *last = nullptr;       // primary: the slot set of the last batch call (statistics, coloured clouds)
+    uint32_t flip = 0;
+    hipStream_t tail_stream = nullptr;  // where this slot set's tail runs (from the device's pool)
+    hipEvent_t ev_front = nullptr, ev_tail = nullptr;
+    bool split_tail = false;       // the call being enqueued hands its tail to tail_stream
+    bool tail_pending = false;     // a tail was enqueued since the stream last waited for ev_tail
     char err[512] = {0};
 
     uint32_t cap_n = 0;        // points per frame slot

@@ -273,3 +273,91 @@ def test_batch_of_large_frames_takes_the_multi_workgroup_kd_rounds(mode):
             assert np.array_equal(rr["ground_idx"], o["ground_idx"])
             assert np.array_equal(rr["planes"].view(np.uint32), o["planes"].view(np.uint32))
             assert np.array_equal(rr["cluster_labels"], lab) and rr["n_clusters"] == nc
+
+
+def _enqueue_only(bctx, clouds, seg_kw, clu_kw):
+    """like run_batch without the synchronisation: returns the device arrays and a reader"""
+    import torch
+    dev = torch.device("cuda:0")
+    B = len(clouds)
+    pitch = max(1, max(c.shape[0] for c in clouds)) + 7
+    P = seg_kw.get("number_of_planar_partitions", 2)
+    host = np.zeros((B, pitch, 4), np.float32)
+    for b, c in enumerate(clouds):
+        host[b, :c.shape[0], :4] = c[:, :4]
+    d = dict(pts=torch.from_numpy(host).to(dev),
+             labels=torch.full((B, pitch), 0x7eadbeef, dtype=torch.int32, device=dev),
+             gidx=torch.zeros((B, pitch), dtype=torch.int32, device=dev),
+             oidx=torch.zeros((B, pitch), dtype=torch.int32, device=dev),
+             planes=torch.full((B, 4 * P), 7.0, dtype=torch.float32, device=dev),
+             clab=torch.full((B, pitch), -77, dtype=torch.int32, device=dev),
+             counts=torch.zeros((B, 4), dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    n = [c.shape[0] for c in clouds]
+    bctx.segment_cluster_batch_device(n, d["pts"].data_ptr(), 16, pitch, SegmentationConfiguration(**seg_kw),
+                                      ClusteringConfiguration(**clu_kw), d["labels"].data_ptr(), d["gidx"].data_ptr(),
+                                      d["oidx"].data_ptr(), d["planes"].data_ptr(), d["clab"].data_ptr(),
+                                      d["counts"].data_ptr())
+
+    def read():
+        counts = d["counts"].cpu().numpy().view(np.uint32)
+        out = []
+        for b in range(B):
+            ng, no, nc, status = (int(v) for v in counts[b])
+            out.append(dict(status=status, n_clusters=nc, labels=d["labels"][b, :n[b]].cpu().numpy().view(np.uint32),
+                            ground_idx=d["gidx"][b, :ng].cpu().numpy().view(np.uint32),
+                            obstacle_idx=d["oidx"][b, :no].cpu().numpy().view(np.uint32),
+                            planes=d["planes"][b].cpu().numpy().reshape(P, 4),
+                            cluster_labels=d["clab"][b, :no].cpu().numpy(), tail_labels=d["clab"][b, no:].cpu().numpy()))
+        return out
+    return read
+
+
+@pytest.mark.parametrize("mode", ["search", "lists"])
+def test_overlapped_tail_gives_the_same_results(ctx, mode):
+    """lpx_set_overlap: five back-to-back calls alternate between the two slot sets, the replay and label kernels of
+    each run on the tail stream beside the front end of the next call, nothing is read before ONE synchronize at the
+    end -- every frame of every call must equal the single-frame path; then the context is switched back, and the
+    statistics / coloured clouds of the last call come from the slot set that served it"""
+    import torch
+    frames = [load_frame(f) for f in FRAMES]
+    rng = np.random.default_rng(7)
+    calls = []
+    for k in range(5):
+        calls.append([frames[(k + j) % 3][rng.integers(0, 3)::(2 + (k + j) % 3)].copy() for j in range(4)])
+    refs = {}
+    for k, clouds in enumerate(calls):
+        for j, c in enumerate(clouds):
+            refs[(k, j)] = single(ctx, c, SEG, CLU)
+    bctx = Context(0, batch=4)
+    try:
+        bctx.set_neighbour_mode(mode)
+        bctx.set_overlap(True)
+        readers = [_enqueue_only(bctx, clouds, SEG, CLU) for clouds in calls]  # no synchronisation in between
+        bctx.synchronize()
+        for k, read in enumerate(readers):
+            for j, res in enumerate(read()):
+                check_frame(res, refs[(k, j)])
+        # the statistics of the last call (served by the primary slot set: call 4 is even)
+        st = bctx.frame_stats(0)
+        assert st["n_obstacle"] == len(refs[(4, 0)]["obstacle_idx"]) and st["n_clusters"] == refs[(4, 0)]["n_clusters"]
+        # an odd number of further calls ends on the twin
+        read = _enqueue_only(bctx, calls[1], SEG, CLU)
+        st = bctx.frame_stats(1)  # synchronises, reads the twin
+        assert st["n_obstacle"] == len(refs[(1, 1)]["obstacle_idx"])
+        for j, res in enumerate(read()):
+            check_frame(res, refs[(1, j)])
+        bctx.set_overlap(False)
+        for j, res in enumerate(run_batch(bctx, calls[2], SEG, CLU)):
+            check_frame(res, refs[(2, j)])
+        bctx.set_overlap(True)  # and on again: the twin is kept
+        for k in (3, 0):
+            for j, res in enumerate(run_batch(bctx, calls[k], SEG, CLU)):
+                check_frame(res, refs[(k, j)])
+    finally:
+        bctx.close()
+
+
+def test_overlap_is_for_batch_contexts(ctx):
+    with pytest.raises(LpxError):
+        ctx.set_overlap(True)
