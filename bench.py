@@ -658,6 +658,37 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baselines(host_frames, wl, args.cpu_seconds)  # before the GPU is initialised (fork)
 
+    sub, overlap_sub = None, None
+    if rank == 0 and world == 1 and args.workload == "stream" and not args.no_sub and not args.dry_run:
+        # Two side measurements, each by a CHILD process that runs to completion before this process touches the GPU
+        # (a process that has initialised the GPU keeps its hardware queues: the device serves about 24 at full speed,
+        # and a child measured beside a live parent -- or a second set of contexts inside one process -- reads 10-25 %
+        # low): (1) the same stream with lpx_set_overlap on 10 contexts, half the frames in flight of the headline;
+        # (2) the round-1/2 headline shape, configs[1] on three frames cycled.
+        import subprocess
+
+        def child(extra):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup",
+                                str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight", "--no-sub"] + extra,
+                               capture_output=True, text=True, timeout=900)
+            return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        try:
+            d4 = child(["--workload", "stream", "--overlap", "--contexts", "10", "--batch", "64", "--frames-per-step", "640"])
+            overlap_sub = {"mpts_s": d4["value"], "ms_per_step": d4["ms_per_step"],
+                           "frames_per_step": d4["config"]["frames_per_step"], "contexts": d4["config"]["contexts_per_gpu"],
+                           "frames_per_launch_chain": d4["config"]["frames_per_launch_chain"],
+                           "what": "the same workload with lpx_set_overlap (replay + labels of a chain on a second stream "
+                                   "beside the context's next chain, two slot sets per context), own process"}
+        except Exception as e:  # a side measurement must never cost the line
+            overlap_sub = {"error": repr(e)[:200]}
+        try:
+            d3 = child(["--workload", "kitti"])
+            sub = {"mpts_s": d3["value"], "ms_per_step": d3["ms_per_step"],
+                   "frames_per_step": d3["config"]["frames_per_step"], "contexts": d3["config"]["contexts_per_gpu"],
+                   "what": WORKLOADS["kitti"]["config"] + " (own process)"}
+        except Exception as e:
+            sub = {"error": repr(e)[:200]}
+
     import torch
     import torch.distributed as dist
 
@@ -709,7 +740,7 @@ def main(argv=None):
     elapsed, counts = plan.timed(args.steps, args.warmup, barrier)
     elapsed, total_points_per_step, total_frames_per_step = aggregate(elapsed, plan.points_per_step, dev, world, plan.F)
 
-    roofline, latency, stream_info, inflight, sub, overlap_sub = None, None, None, None, None, None
+    roofline, latency, stream_info, inflight = None, None, None, None
     stage_ms = {}
     if rank == 0:
         stage_ms, launches, per_launch = stage_profile(plan, args.steps)
@@ -720,40 +751,6 @@ def main(argv=None):
             stream_info = feeder_rates(plan, host_frames, lpx, elapsed, args.steps, world)
         if not args.no_inflight and args.workload in ("stream", "kitti"):
             inflight = inflight_curve(plan, lpx)
-    if rank == 0 and world == 1 and args.workload == "stream" and not args.no_sub:
-        # the round-1/2 headline shape next to the stream: configs[1] on three frames cycled.  Measured by a CHILD
-        # process (started, not exec'd, once this process has released its contexts): a second set of contexts in a
-        # process that has already run one measures 15-25 % low.
-        import subprocess
-        plan.close()
-        del plan
-        torch.cuda.empty_cache()
-        plan = None
-        # ... and the same stream with lpx_set_overlap on 10 contexts: half the frames in flight of the headline
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "stream", "--overlap", "--contexts",
-                                "10", "--batch", "64", "--frames-per-step", "640", "--steps", str(args.steps), "--warmup",
-                                str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight", "--no-sub"],
-                               capture_output=True, text=True, timeout=600)
-            d4 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-            overlap_sub = {"mpts_s": d4["value"], "ms_per_step": d4["ms_per_step"],
-                           "frames_per_step": d4["config"]["frames_per_step"], "contexts": d4["config"]["contexts_per_gpu"],
-                           "frames_per_launch_chain": d4["config"]["frames_per_launch_chain"],
-                           "what": "the same workload with lpx_set_overlap (replay + labels of a chain on a second stream "
-                                   "beside the context's next chain, two slot sets per context), own process"}
-        except Exception as e:
-            overlap_sub = {"error": repr(e)[:200]}
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "kitti", "--steps", str(args.steps),
-                                "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight",
-                                "--no-sub"], capture_output=True, text=True, timeout=600)
-            d3 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-            sub = {"mpts_s": d3["value"], "ms_per_step": d3["ms_per_step"],
-                   "frames_per_step": d3["config"]["frames_per_step"], "contexts": d3["config"]["contexts_per_gpu"],
-                   "what": WORKLOADS["kitti"]["config"] + " (own process)"}
-        except Exception as e:  # the sub-measurement must never cost the line
-            sub = {"error": repr(e)[:200]}
-
     if rank == 0:
         value = total_points_per_step * args.steps / elapsed / 1e6
         real = args.workload in ("kitti", "stream")

@@ -183,13 +183,16 @@ int lpx_coloured_clouds(lpx_ctx *ctx, void *ground_records, void *obstacle_recor
 int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t *offsets, uint32_t *indices,
                        uint32_t *n_valid);
 
-/* Per-cluster 2-D convex hulls (N3): what findOrderedConcaveOutlines computes for clusters with fewer than 20
- * points (reference src/polygon_simplification.cpp:96-115; max_points = 20) and findOrderedConvexOutlines for all
- * of them (:32-80; max_points = UINT32_MAX) -- Andrew's monotone chain on (x, y), counter-clockwise from the
- * lowest (x, y) point, collinear points and duplicates are not vertices.  The reference takes the algorithm from
- * its Convex-Hull git submodule, which its checkout does not vendor: the published algorithm is restated, see
- * DESIGN.md.  Clusters with max_points or more points get an empty hull (the reference's concave branch is out
- * of scope).  Works on the labels of the LAST clustering call of this context: hull_offsets[n_clusters + 1],
+/* Per-cluster 2-D convex hulls (N3): the counterpart of the convex branch of findOrderedConcaveOutlines, clusters
+ * with fewer than 20 points (reference src/polygon_simplification.cpp:96-115; max_points = 20) -- Andrew's monotone
+ * chain on (x, y), counter-clockwise from the lowest (x, y) point, collinear points and duplicates are not vertices.
+ * RESTATED ALGORITHM, NOT VERIFIED AGAINST THE REFERENCE: the reference takes geom::constructConvexHull from its
+ * Convex-Hull git submodule, which its checkout does not vendor (empty directory), so vertex order and the
+ * collinear / duplicate conventions are this library's, checked against known answers and against
+ * scipy's qhull vertex sets only.  Documented parity is limited to that < 20-point branch: findOrderedConvexOutlines
+ * (:32-80) switches to Chan's algorithm above 1000 points in the same absent submodule -- max_points = UINT32_MAX
+ * gives monotone-chain hulls of every cluster, with no claim about the reference's output there.  Clusters with
+ * max_points or more points get an empty hull (the reference's concave branch is out of scope).  Works on the labels of the LAST clustering call of this context: hull_offsets[n_clusters + 1],
  * hull_indices (indices into the clustered cloud) and hull_xy (x, y pairs; may be NULL) hold up to m entries. */
 int lpx_cluster_hulls(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t max_points, uint32_t *hull_offsets,
                       uint32_t *hull_indices, float *hull_xy, uint32_t *n_hull_points);

@@ -1005,13 +1005,14 @@ __global__ void group_offsets_kernel(const uint32_t *__restrict__ skey, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// N3: per-cluster 2-D convex hull -- the convex branch of findOrderedConcaveOutlines (reference
-// src/polygon_simplification.cpp:96-115: clusters with fewer than 20 points) and findOrderedConvexOutlines
-// (:32-80).  The reference delegates to geom::constructConvexHull(ANDREW_MONOTONE_CHAIN, COUNTERCLOCKWISE) of
-// its Convex-Hull submodule, which is not vendored; the published algorithm is restated with the conventions
-// stated in DESIGN.md (points sorted by (x, y, index), duplicates skipped, collinear points are
-// not vertices, float32 cross product without contraction, CCW from the lowest (x, y) point).  The concave
-// branch (:116-131, Concave-Hull submodule) is out of scope: larger clusters get an empty hull.
+// N3: per-cluster 2-D convex hull -- the counterpart of the convex branch of findOrderedConcaveOutlines (reference
+// src/polygon_simplification.cpp:96-115: clusters with fewer than 20 points).  The reference delegates to
+// geom::constructConvexHull(ANDREW_MONOTONE_CHAIN, COUNTERCLOCKWISE) of its Convex-Hull submodule, which is not
+// vendored: the published algorithm is RESTATED, not verified against the submodule, with the conventions stated in
+// DESIGN.md (points sorted by (x, y, index), duplicates skipped, collinear points are not vertices, float32 cross
+// product without contraction, CCW from the lowest (x, y) point).  No parity is claimed beyond that branch
+// (findOrderedConvexOutlines, :32-80, switches to Chan's algorithm above 1000 points in the same absent submodule).
+// The concave branch (:116-131, Concave-Hull submodule) is out of scope: larger clusters get an empty hull.
 //
 // Input: the CSR of lpx_run_groups (clusters in label order).  Three stable radix sorts of the CSR's point list
 // -- by y key, by x key, by label -- leave every cluster's points in (x, y, index) order inside the cluster's

@@ -12,7 +12,7 @@ for W in $WORKLOADS; do
   case $W in kitti) S="--steps 10 --warmup 3";; stream) S="--steps 6 --warmup 2";; *) S="--steps 4 --warmup 1";; esac
   # counter passes: one context; the 5M-point workload with two frames per step (rocprofv3 --pmc crashed at start-up
   # with eight 5M-point frames resident)
-  case $W in synth5m) PF="--frames-per-step 2";; synth1m) PF="--frames-per-step 8";; *) PF="--frames-per-step 32";; esac
+  case $W in synth5m) PF="--frames-per-step 2";; synth1m) PF="--frames-per-step 8";; *) PF="--frames-per-step 64";; esac
   python3 $GRAFT_REPO_ROOT/bench.py --workload $W $S 2>$O/${TAG}_${W}_bench.err | tail -1 > $O/${TAG}_${W}_bench.json
   rm -rf /tmp/p1 /tmp/p2 /tmp/p3 /tmp/p4
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o a -- python3 $GRAFT_REPO_ROOT/bench.py --workload $W $S --no-cpu-baseline --no-latency --no-inflight --no-sub > $O/rocprof_${W}_default.log 2>&1
