@@ -101,14 +101,18 @@ def test_stream_154_frames_match_reference_goldens(stream, cname):
     assert not bad, bad[:3]
 
 
-def test_bench_shape_8_contexts_32_slots_2_threads(stream):
-    """the configuration bench.py times: 256 frames per step, 32 per chain, 8 contexts (streams) in flight, two
-    host threads enqueueing, three rounds back to back without a synchronisation in between; afterwards every
-    frame's labels, index lists, planes, cluster labels and counts equal the single-frame entry point's"""
+@pytest.mark.parametrize("shape", [(256, 32, 8, 2, False), (640, 64, 10, 4, False), (512, 64, 4, 2, True)],
+                         ids=["8x32", "10x64", "4x64-overlap"])
+def test_bench_shape_contexts_slots_threads(stream, shape):
+    """the configurations bench.py times -- round 2's 32-frame chains on 8 contexts, round 3's 64-frame chains on many
+    contexts, and lpx_set_overlap (two slot sets per context, the tail of a chain beside the next chain) -- several host
+    threads enqueueing, three rounds back to back without a synchronisation in between; afterwards every frame's labels,
+    index lists, planes, cluster labels and counts equal the single-frame entry point's"""
     cname = "p6i5_d025q05"
     skw, ckw = STREAM_CONFIGS[cname]
     scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
-    F, B, C, T, ROUNDS = 256, 32, 8, 2, 3
+    F, B, C, T, overlap = shape
+    ROUNDS = 3
     ids = [(5 * j) % len(stream) for j in range(F)]  # 154 distinct frames spread over the slots, some twice
     buf = Pitched([stream[i] for i in ids], skw["number_of_planar_partitions"])
     chains = [(k, min(k + B, F)) for k in range(0, F, B)]
@@ -116,6 +120,8 @@ def test_bench_shape_8_contexts_32_slots_2_threads(stream):
     try:
         for c in ctxs:
             c.reserve(buf.pitch)
+            if overlap:
+                c.set_overlap(True)
 
         def enqueue(tid):
             buf.torch.cuda.set_device(0)
