@@ -86,10 +86,17 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
     // larger -- or garbage -- count is an argument error, not a hang
     if (n >= (1u << 30))
         return lpx_fail(ctx, LPX_ERR_ARG, "%u points in a frame: the limit is 2^30 - 1", n);
-    if (n > ctx->cap_n || !ctx->arena)
+    // The tables of the expansion-driven search (chunk tables 256 B per point, the component grid's cell tables up to
+    // ~144 B per point, the point -> group / cell maps) are part of a slot only for contexts that search: a context in
+    // LPX_NEIGHBOURS_LISTS mode -- every single-frame context by default -- never touches them (44 MB less per 123k-point
+    // slot, 1.8 GB per 5M-point slot).  Switching a context to the search mode rebuilds the arena (before any work is
+    // enqueued, like every growth).
+    const bool want_search = !ctx->use_lists;
+    if (n > ctx->cap_n || !ctx->arena || (want_search && !ctx->arena_has_search))
     {
         if (n < ctx->cap_n)
             n = ctx->cap_n;
+        const bool with_search = want_search || ctx->arena_has_search;
         const size_t n4 = sizeof(uint32_t) * ((size_t)n + 16);
         const size_t sort_blocks = ((size_t)n + LPX_SORT_TILE - 1) / LPX_SORT_TILE + 1;
         size_t hist_bytes = 64 + 256 * sizeof(uint32_t) * sort_blocks + 64;
@@ -123,11 +130,15 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             {&ctx->seed_of, n4},  {&ctx->queue, n4},    {&ctx->valid, n4},   {&ctx->d_labels, n4}, {&ctx->d_gidx, n4},
             {&ctx->d_oidx, n4},   {&ctx->d_clabels, n4}, {&ctx->key64_a, 2 * n4}, {&ctx->key64_b, 2 * n4},
             {&ctx->nodes, 4 * n4}, {&ctx->nodes_pre, 4 * n4}, {&ctx->flags, (size_t)n + 64}, {&ctx->state, (size_t)n + 64},
-            {&ctx->grp_of, n4},   {&ctx->cell_of, n4},  {&ctx->chunks, chunk_bytes},
-            {&ctx->cell_key, sizeof(uint64_t) * cell_cap}, {&ctx->cell_rep, sizeof(uint32_t) * cell_cap},
-            {&ctx->cell_parent, sizeof(uint32_t) * cell_cap}, {&ctx->cell_xyz, sizeof(float4) * cell_cap},
-            {&ctx->cell_start, sizeof(uint32_t) * cell_cap},
             {&ctx->kd_state, 48 * 1024},  // 48-byte states of up to 1024 ranges (ten top levels)
+            // expansion-driven search only (with_search)
+            {&ctx->grp_of, with_search ? n4 : 0},   {&ctx->cell_of, with_search ? n4 : 0},
+            {&ctx->chunks, with_search ? chunk_bytes : 0},
+            {&ctx->cell_key, with_search ? sizeof(uint64_t) * cell_cap : 0},
+            {&ctx->cell_rep, with_search ? sizeof(uint32_t) * cell_cap : 0},
+            {&ctx->cell_parent, with_search ? sizeof(uint32_t) * cell_cap : 0},
+            {&ctx->cell_xyz, with_search ? sizeof(float4) * cell_cap : 0},
+            {&ctx->cell_start, with_search ? sizeof(uint32_t) * cell_cap : 0},
         };
         size_t total = 0;
         for (const Item &it : items)
@@ -152,6 +163,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         ctx->fstride = total;
         ctx->cap_n = n;
         ctx->cell_cap = cell_cap;
+        ctx->arena_has_search = with_search;
         ctx->fs_tag = total | lpx_remap_mask(n);
     }
     if (!ctx->use_lists && !ctx->nb_arena)

@@ -210,6 +210,7 @@ struct lpx_ctx
     Buf cell_of;               // u32 per point: its cell slot
     Buf cell_xyz;              // float4 [cell_cap]: the point that claimed the cell
     uint32_t cell_cap = 0;     // slots per frame slot (power of two >= 2 * cap_n)
+    bool arena_has_search = false;  // the arena holds the search tables above (contexts that have been in search mode)
     bool use_lists = false;    // lpx_dbg_use_lists: materialise every radius list (the round-1 path, kept for tests)
     Buf frame;                 // FrameState
     // ---- pinned host staging ----
