@@ -1,13 +1,13 @@
 """Soak test: many concurrent multi-frame chains, every output of every frame checked against the single-frame
 path after each round (races in the union-find, the histogram tickets or the workspace allocators would show
-up as a differing label).  usage: soak.py [seconds] [batch] [contexts]"""
+up as a differing label).  usage: soak.py [seconds] [batch] [contexts] [overlap]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -23,6 +23,7 @@ def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     C = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    overlap = len(sys.argv) > 4 and sys.argv[4] == "overlap"
     dev = torch.device("cuda:0")
     scfg, ccfg = SegmentationConfiguration(**SEG), ClusteringConfiguration(**CLU)
     frames = [load_frame(f) for f in FRAMES]
@@ -46,6 +47,8 @@ def main():
     ctxs = [Context(0, batch=B) for _ in range(C)]
     for c in ctxs:
         c.reserve(pitch)
+        if overlap:
+            c.set_overlap(True)
     t_end = time.time() + seconds
     rounds = 0
     while time.time() < t_end:
@@ -71,7 +74,8 @@ def main():
             assert np.array_equal(h_oi[j, :no].view(np.uint32), r["obstacle_idx"]), (rounds, j, "obstacle_idx")
             assert np.array_equal(h_cl[j, :no], r["cluster_labels"]), (rounds, j, "cluster labels")
         rounds += 1
-    print(f"soak ok: {rounds} rounds x 3 x {F} frames, every output identical to the single-frame path")
+    print(f"soak ok ({C} contexts x {B} frames{', overlapped tails' if overlap else ''}): {rounds} rounds x 3 x {F} frames, "
+          "every output identical to the single-frame path")
     for c in ctxs:
         c.close()
 
