@@ -115,7 +115,7 @@ def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=Non
     }[stage]
 
 
-def pmc_traffic(stage, workload):
+def pmc_traffic(stage, workload, kernel=None):
     """HBM bytes per launch of the stage's dominant kernel from the COMMITTED rocprofv3 --pmc summary of this same
     command (profiles/<round>_<workload>_pmc_fetch_write_per_kernel.json): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 --
     FETCH_SIZE counts half of a coalesced read on gfx950 (guides/MI355X_MICROARCH.md, HBM).  None when no summary
@@ -125,9 +125,19 @@ def pmc_traffic(stage, workload):
         d = json.load(open(path))
         # (template variants of one kernel: the one that moved the data)
         return max(int((2 * v["FETCH_SIZE"]["avg"] + v["WRITE_SIZE"]["avg"]) * 1024)
-                   for name, v in d.items() if name.startswith(STAGE_KERNEL[stage][:40]))
+                   for name, v in d.items() if name.startswith((kernel or STAGE_KERNEL[stage])[:40]))
     except Exception:
         return None
+
+
+PMC_FRAMES_PER_LAUNCH = {"stream": 64, "kitti": 64, "synth1m": 8, "synth5m": 1}  # launch shape of the committed --pmc runs
+
+
+def pmc_moved_per_frame(stage, workload, kernel=None):
+    """bytes one frame makes the stage's dominant kernel MOVE through the fabric (same committed summary and formula as
+    pmc_traffic), or None"""
+    t = pmc_traffic(stage, workload, kernel)
+    return None if t is None else t / PMC_FRAMES_PER_LAUNCH.get(workload, 1)
 
 
 def frame_ids_for_rank(rank, world, frames_per_step, n_frames):
@@ -423,9 +433,19 @@ def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_lau
         algo = frames_per_launch * algorithmic_bytes(stage, Nn, Mm, E, I, P, E_replay, cand, groups, per_pass)
         ms = per_launch[stage]
         ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"kernel": kern.get(stage, stage), "avg_launch_ms": round(ms, 5),
-                "algorithmic_bytes_per_launch": int(algo), "achieved": round(ach, 2),
-                "frac": round(ach / HBM_PEAK_GBS, 5)}
+        row = {"kernel": kern.get(stage, stage), "avg_launch_ms": round(ms, 5),
+               "algorithmic_bytes_per_launch": int(algo), "achieved": round(ach, 2),
+               "frac": round(ach / HBM_PEAK_GBS, 5)}
+        # what the kernel really moves (committed PMC summary, scaled to this launch's frames): a kernel that is far
+        # below the roofline by algorithmic bytes but near it by MOVED bytes is at the floor of its access pattern
+        # (scattered 4- / 16-byte accesses that cost whole 64-byte requests), not under-using the memory system
+        mv = pmc_moved_per_frame(stage, plan.name, kern.get(stage))
+        if mv is not None and ms > 0:
+            moved = mv * frames_per_launch
+            row.update(moved_bytes_per_launch=int(moved), moved_gbs=round(moved / (ms * 1e-3) / 1e9, 1),
+                       moved_frac=round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       moved_source=f"profiles/{PROFILE_ROUND}_{plan.name}_pmc summary (not measured in this run)")
+        return row
 
     step_ms = elapsed / steps * 1e3
     fb = frame_bytes(Nn, Mm, I)
@@ -438,9 +458,10 @@ def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_lau
             "achieved": round(dom_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 5),
             "what": "SURVEY 8(d) bytes of a frame, N (44 + 12 I) + 80 M, x frames per launch / launch duration of the "
                     "dominant kernel alone on the device (HIP events on its stream)",
-            "traffic": pmc_traffic(dom, plan.name),
+            "traffic": (lambda mv: None if mv is None else int(mv * frames_per_launch))(pmc_moved_per_frame(dom, plan.name, kern.get(dom))),
             "traffic_source": f"committed profiles/{PROFILE_ROUND}_{plan.name}_pmc summary of this command "
-                              "(rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes; not measured in this run)",
+                              "(rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE per frame x the "
+                              "frames of this launch; not measured in this run)",
             "avg_launch_ms": round(dom_ms, 5),
             "avg_launch_ms_under_load": round(stage_ms[dom] / max(1, launches[dom]), 5),
             "algorithmic_bytes_per_launch": int(fb * frames_per_launch), "frames_per_launch": frames_per_launch,
