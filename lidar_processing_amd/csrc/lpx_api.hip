@@ -62,18 +62,18 @@ static inline size_t align256(size_t v)
 //   * 1M-point frames, 8 chains of 8 in flight: every family re-read +11 % throughput (a frame's hash cells, kd nodes
 //     and chunk tables are fetched into one L2 instead of eight; the replay alone 13.2 -> 10.0 ms per chain);
 //   * 120k-point frames, 20 chains of 64 in flight (rocprofv3 FETCH_SIZE / WRITE_SIZE per frame, stream throughput):
-//     none 173 MB, 2040 Mpts/s with the sorts alone (their traffic -36 %); every family 111 MB (the far linking pass of
-//     the component grid 22 -> 2.2 MB, the replay 43 -> 22, the chunk tables 13 -> 6, the x gather 7.4 -> 3.5) but
-//     1985 Mpts/s: the component grid on one XCD per frame costs 3.5 % -- its few resident workgroups per frame
-//     (lpx_grid_components) then share 32 CUs instead of 256 and frames with more cells finish late; sorts + chunk
-//     tables + replay (0x92) take their share of the saving for nothing: 2045 Mpts/s.
-// Hence by frame size.  LPX_REMAP=<hex mask> overrides.
+//     none 173 MB; every family 111 MB (the far linking pass of the component grid 22 -> 2.2 MB, the replay 43 -> 22,
+//     the chunk tables 13 -> 6, the x gather 7.4 -> 3.5, the sorts -36 %) but -3.5 % throughput -- and all of that
+//     loss belongs to family 6, the component grid's per-point and per-cell kernels (insert with its atomics, clear,
+//     alloc, scatter, flatten) and the small label kernels, which save nothing: every OTHER family on (0xbf) gives
+//     115 MB per frame at the throughput of none (2055-2063 against 2032-2062 Mpts/s).
+// Hence family 6 only for large frames.  LPX_REMAP=<hex mask> overrides.
 static uint32_t lpx_remap_mask(uint32_t points_per_slot)
 {
     static const char *env = getenv("LPX_REMAP");
     if (env)
         return (uint32_t)strtoul(env, nullptr, 16) & 0xffu;
-    return points_per_slot >= 400000u ? 0xffu : 0x92u;
+    return points_per_slot >= 400000u ? 0xffu : 0xbfu;
 }
 
 // One arena per frame slot: every internal buffer is a fixed sub-range of it, so slot b of any buffer is

@@ -341,7 +341,8 @@ int lpx_ensure_lists(lpx_ctx *ctx);
 // gridDim.z & ~7 frames, the identity for the rest (and for single-frame launches); placement is a matter of
 // speed only, nothing depends on which XCD a workgroup really gets.
 // Kernel families (template argument of lpx_block): 0 streaming kernels of the segmentation, 1 sorts and scans, 2 seeds
-// and plane passes, 3 kd build, 4 neighbour tables, 5 component grid, 6 component ranges / labels / groups, 7 replay.
+// and plane passes, 3 kd build, 4 neighbour tables, 5 cell linking of the component grid, 6 the grid's per-point /
+// per-cell kernels, component ranges / labels / groups, 7 replay.
 // Which families re-read their workgroup number is a property of the LAUNCH (every workgroup of a launch must agree):
 // the host passes it in the low byte of the frame-arena stride that every kernel receives (the stride is a multiple of
 // 256): bit g = family g.  The host's choice: lpx_remap_mask() in lpx_api.hip.

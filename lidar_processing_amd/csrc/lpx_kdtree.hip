@@ -2346,7 +2346,7 @@ __global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long 
                                   uint32_t *__restrict__ tparent, uint32_t *__restrict__ thead, uint32_t cap_max,
                                   size_t fs)
 {
-    const LpxBlock lpx_blk = lpx_block<5>(fs);
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
     frame = lpx_slot(frame, fs);
     tkey = lpx_slot(tkey, fs);
     tparent = lpx_slot(tparent, fs);
@@ -2373,7 +2373,7 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
                                    uint32_t *__restrict__ cells, uint32_t *__restrict__ cell_of,
                                    float4 *__restrict__ trep, uint32_t cap_max, size_t fs)
 {
-    const LpxBlock lpx_blk = lpx_block<5>(fs);
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
     trep = lpx_slot(trep, fs);
     frame = lpx_slot(frame, fs);
     OX = lpx_slot(OX, fs);
@@ -2454,7 +2454,7 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
 __global__ void grid_alloc_kernel(FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
                                   const uint32_t *__restrict__ tcount, uint32_t *__restrict__ tstart, size_t fs)
 {
-    const LpxBlock lpx_blk = lpx_block<5>(fs);
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
     frame = lpx_slot(frame, fs);
     cells = lpx_slot(cells, fs);
     tcount = lpx_slot(tcount, fs);
@@ -2472,7 +2472,7 @@ __global__ void grid_scatter_kernel(const FrameState *__restrict__ frame, const 
                                     const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ rank,
                                     const uint32_t *__restrict__ tstart, float4 *__restrict__ cpts, size_t fs)
 {
-    const LpxBlock lpx_blk = lpx_block<5>(fs);
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
     frame = lpx_slot(frame, fs);
     OX = lpx_slot(OX, fs);
     OY = lpx_slot(OY, fs);
@@ -2675,7 +2675,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
 __global__ void grid_compress_kernel(const FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
                                      uint32_t *tparent, size_t fs)
 {
-    const LpxBlock lpx_blk = lpx_block<5>(fs);
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
     frame = lpx_slot(frame, fs);
     cells = lpx_slot(cells, fs);
     tparent = lpx_slot(tparent, fs);
@@ -2699,7 +2699,7 @@ __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32
                                     uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
                                     uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi, size_t fs)
 {
-    const LpxBlock lpx_blk = lpx_block<5>(fs);
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
     frame = lpx_slot(frame, fs);
     tparent = lpx_slot(tparent, fs);
     tstart = lpx_slot(tstart, fs);
