@@ -361,3 +361,21 @@ def test_overlapped_tail_gives_the_same_results(ctx, mode):
 def test_overlap_is_for_batch_contexts(ctx):
     with pytest.raises(LpxError):
         ctx.set_overlap(True)
+
+
+@pytest.mark.parametrize("mask", ["ff", "bf", "40", "0"])
+def test_xcd_affine_launch_geometry_is_a_bijection(mask):
+    """lpx_block re-reads the linear workgroup number so that a frame's workgroups share an XCD; which kernel families do
+    so is chosen per launch (LPX_REMAP, read once per process -- hence the subprocess).  Every family on, the library's
+    default for small frames, only the family the default leaves out, and none: ragged batches of 8, 13, 16 and 19
+    frames (partial groups of eight, empty frames, frames with fewer points than partitions) in both neighbour modes
+    must equal the single-frame path, which is never re-read"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, LPX_REMAP=mask, PYTHONPATH=os.pathsep.join([os.path.dirname(here), here,
+                                                                       os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(here, "remap_check.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "remap check ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
