@@ -347,6 +347,18 @@ def test_overlapped_tail_gives_the_same_results(ctx, mode):
         assert st["n_obstacle"] == len(refs[(1, 1)]["obstacle_idx"])
         for j, res in enumerate(read()):
             check_frame(res, refs[(1, j)])
+        # lpx_wait_previous: a pipelined caller enqueues call k, then collects call k - 1 while k is still in flight
+        prev = None
+        for k in (0, 3, 1, 4):
+            cur = _enqueue_only(bctx, calls[k], SEG, CLU)
+            bctx.wait_previous()
+            if prev is not None:
+                for j, res in enumerate(prev[1]()):
+                    check_frame(res, refs[(prev[0], j)])
+            prev = (k, cur)
+        bctx.synchronize()
+        for j, res in enumerate(prev[1]()):
+            check_frame(res, refs[(prev[0], j)])
         bctx.set_overlap(False)
         for j, res in enumerate(run_batch(bctx, calls[2], SEG, CLU)):
             check_frame(res, refs[(2, j)])
