@@ -61,7 +61,7 @@ WORKLOADS = {
                    clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=1280, batch=64, contexts=20),
     "synth1m": dict(config="configs[2]: synthetic 1M-pt plane + boxes, 12 segments, 3 iters, FEC d=0.3 m q=0.5",
                     seg=dict(number_of_planar_partitions=12, number_of_iterations=3),
-                    clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=128, batch=16, contexts=8),
+                    clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=256, batch=32, contexts=8),
     "synth5m": dict(config="configs[4]: synthetic 5M-pt plane + boxes, 24 segments, 3 iters, FEC d=0.2 m q=0.5",
                     seg=dict(number_of_planar_partitions=24, number_of_iterations=3),
                     clu=dict(distance_squared=0.04, cluster_quality=0.5), frames_per_step=12, batch=1, contexts=12,
