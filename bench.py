@@ -751,6 +751,9 @@ def main(argv=None):
     import lidar_processing_amd as lpx
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback (--dry-run walks the launch only)")
+    # one rank per GPU; on a box with fewer GPUs than ranks (the 1-GPU test boxes: `--gpus 2 --backend gloo` walks the
+    # N > 1 path with both ranks on the one device -- RCCL itself refuses two ranks on one GPU) ranks share devices
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
