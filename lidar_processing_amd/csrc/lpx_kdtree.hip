@@ -593,7 +593,12 @@ struct KdTopState
 };
 constexpr int TOP_TILE = 8192;        // positions per workgroup in the flag / list passes
 constexpr int TOP_THREADS = 256;
-constexpr int TOP_HAND = 4096;        // ranges at or below this are left to kd_block_kernel (they fit its LDS)
+// A round of the multi-workgroup form is four launches (~38 us), a round inside kd_block_kernel's single workgroup ~10 us
+// on 32k nodes: ranges at or below TOP_HAND are left to kd_block_kernel, and only TOP_EXTRA rounds are added to the
+// expected number (a range that shrinks slower than 0.6 per round is simply handed over larger).  Measured on 5M-point
+// frames: 4096 / 6 (round 2) kd build 4.46 ms, 599 Mpts/s, ~410 launches per frame; 32768 / 1: 3.78 ms, 653 Mpts/s, ~190.
+constexpr int TOP_HAND = 32768;
+constexpr int TOP_EXTRA = 1;
 constexpr uint32_t TOP_MIN = 131072;  // levels whose ranges can exceed this take the multi-workgroup rounds
 
 constexpr int BLK_G_MAX = 1024;
@@ -766,7 +771,8 @@ __global__ __launch_bounds__(BLK_G) void kd_block_kernel(Node *nodes, uint32_t *
 // permutation as before -- the rounds only run on more CUs.
 // ------------------------------------------------------------------------------------------------
 __global__ void kd_top_pivot(Node *nodes, const uint32_t *__restrict__ lpos, const uint32_t *__restrict__ rasc,
-                             const FrameState *__restrict__ frame, KdTopState *state, int level, int init, size_t fs)
+                             const FrameState *__restrict__ frame, KdTopState *state, int level, int init, int hand,
+                             size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<3>(fs);
     nodes = lpx_slot(nodes, fs);
@@ -809,7 +815,7 @@ __global__ void kd_top_pivot(Node *nodes, const uint32_t *__restrict__ lpos, con
     }
     // the range stays here while it is large and the depth limit has not run out (heap_select, rare, is left to
     // kd_block_kernel together with everything small)
-    if (st.active && (st.last - st.first <= TOP_HAND || st.depth == 0))
+    if (st.active && (st.last - st.first <= hand || st.depth == 0))
         st.active = 0;
     if (st.active && init != 2)  // init == 2: the last call only applies the last cut, it starts no round
     {
@@ -2800,8 +2806,13 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
             const uint32_t ranges = 1u << level;
             if (sizeof(uint2) * (size_t)tiles * ranges <= ctx->key64_b.bytes)
             {
-                int rounds = 6;  // the active range shrinks by ~0.6 per round; kd_block_kernel finishes the rest
-                for (uint32_t sz = size; sz > (uint32_t)TOP_HAND; sz = sz * 3 / 5)
+                // the active range shrinks by ~0.6 per round; kd_block_kernel finishes whatever is left (from any state:
+                // LPX_KD_HAND / LPX_KD_EXTRA only move work between the four-launch rounds and its single workgroup)
+                static const int hand_env = getenv("LPX_KD_HAND") ? atoi(getenv("LPX_KD_HAND")) : TOP_HAND;
+                static const int extra_env = getenv("LPX_KD_EXTRA") ? atoi(getenv("LPX_KD_EXTRA")) : TOP_EXTRA;
+                const int hand = hand_env;
+                int rounds = extra_env;
+                for (uint32_t sz = size; sz > (uint32_t)hand; sz = sz * 3 / 5)
                     ++rounds;
                 const dim3 gp((ranges + 63) / 64, 1, ctx->cur_b), gt(tiles, ranges, ctx->cur_b);
                 const dim3 gs(tiles < 64 ? tiles : 64, ranges, ctx->cur_b);
@@ -2809,7 +2820,7 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
                 {
                     hipLaunchKernelGGL(kd_top_pivot, gp, dim3(64), 0, ctx->stream, nodes, (const uint32_t *)lpos,
                                        (const uint32_t *)rasc, frame, state, level, r == 0 ? 1 : (r == rounds ? 2 : 0),
-                                       ctx->fs_tag);
+                                       hand, ctx->fs_tag);
                     if (r == rounds)
                         break;  // the last call only applies the last cut
                     hipLaunchKernelGGL(kd_top_flags, gt, dim3(TOP_THREADS), 0, ctx->stream, (const Node *)nodes,
