@@ -826,6 +826,13 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 const float wx = OX[ci], wy = OY[ci], wz = OZ[ci];
                 const uint32_t wg = grp_of[ci];  // gathered with the coordinates: no extra round trip per search
                 unsigned long long am = __ballot(alive), em = 0;
+                // The first alive candidate of a window is always expanded (nothing before it can absorb it): its chunk
+                // table is requested BEFORE the selection loop below, which only needs the coordinates and then runs
+                // under that load instead of in front of it.
+                ChunkRec ch_first;
+                if (am)
+                    ch_first = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, __ffsll((long long)am) - 1) *
+                                          LPX_GROUP_CHUNKS + lane];
                 while (am)
                 {
                     const int h = __ffsll((long long)am) - 1;
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 // goes out before the hits of i are applied (the LDS work of the apply then runs under those loads).
                 int e = __ffsll((long long)em) - 1;
                 em &= em - 1;
-                ChunkRec ch = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, e) * LPX_GROUP_CHUNKS + lane];
+                ChunkRec ch = ch_first;
                 float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), e));
                 float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), e));
                 float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), e));
