@@ -235,6 +235,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-inflight", action="store_true", help="skip the frames-in-flight curve")
     ap.add_argument("--no-sub", action="store_true", help="skip the three-frames-cycled sub-measurement of the stream line")
+    ap.add_argument("--inflight-only", action="store_true",
+                    help="(child of the default run) only the frames-in-flight curve, in a process of its own")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the one-core CPU baseline leg")
     ap.add_argument("--lists", action="store_true", help="A/B: materialise every radius list (LPX_NEIGHBOURS_LISTS)")
     ap.add_argument("--search", action="store_true", help="A/B: expansion-driven searches (LPX_NEIGHBOURS_SEARCH)")
@@ -562,7 +564,7 @@ def inflight_curve(plan, lpx, seconds=0.6):
         if C * B > F or (rows and (C, B, mode, ovl) == shapes[-1] and rows[-1]["contexts"] == C
                          and rows[-1]["frames_per_chain"] == B and rows[-1]["overlap"] == ovl):
             continue
-        reuse = (B == plan.B and mode == own and C <= plan.C and ovl == plan.overlap)
+        reuse = (B == plan.B and mode == own and C <= len(plan.ctxs) and ovl == plan.overlap)
         ctxs = plan.ctxs[:C] if reuse else [plan.new_context(lpx, B, mode, ovl) for _ in range(C)]
         lat = [[] for _ in range(C)]
         frames = [0] * C
@@ -679,8 +681,9 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baselines(host_frames, wl, args.cpu_seconds)  # before the GPU is initialised (fork)
 
-    sub, overlap_sub = None, None
-    if rank == 0 and world == 1 and args.workload == "stream" and not args.no_sub and not args.dry_run:
+    sub, overlap_sub, inflight_child = None, None, None
+    if rank == 0 and world == 1 and args.workload == "stream" and not args.no_sub and not args.dry_run \
+            and not args.inflight_only:
         # Two side measurements, each by a CHILD process that runs to completion before this process touches the GPU
         # (a process that has initialised the GPU keeps its hardware queues: the device serves about 24 at full speed,
         # and a child measured beside a live parent -- or a second set of contexts inside one process -- reads 10-25 %
@@ -693,6 +696,11 @@ def main(argv=None):
                                 str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight", "--no-sub"] + extra,
                                capture_output=True, text=True, timeout=900)
             return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        if not args.no_inflight:
+            try:
+                inflight_child = child(["--workload", args.workload, "--inflight-only"])["throughput_vs_inflight"]
+            except Exception as e:
+                inflight_child = {"error": repr(e)[:200]}
         try:
             d4 = child(["--workload", "stream", "--overlap", "--contexts", "10", "--batch", "64", "--frames-per-step", "640"])
             overlap_sub = {"mpts_s": d4["value"], "ms_per_step": d4["ms_per_step"],
@@ -760,6 +768,15 @@ def main(argv=None):
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": dev} if backend == "nccl" else {}))
 
+    if args.inflight_only:
+        # the curve alone: no other contexts alive in this process (idle contexts keep their hardware queues, and with
+        # the headline's twenty beside them the small rows showed 14 ms p99 outliers that a clean loop does not have)
+        args.contexts, args.batch = 1, 1
+        plan = Plan(args.workload, host_frames, args, rank, world, local_rank, torch, lpx)
+        plan.close()
+        plan.C, plan.B = WORKLOADS[args.workload]["contexts"], WORKLOADS[args.workload]["batch"]
+        print(json.dumps({"throughput_vs_inflight": inflight_curve(plan, lpx)}))
+        return 0
     plan = Plan(args.workload, host_frames, args, rank, world, local_rank, torch, lpx)
     elapsed, counts = plan.timed(args.steps, args.warmup, barrier)
     elapsed, total_points_per_step, total_frames_per_step = aggregate(elapsed, plan.points_per_step, dev, world, plan.F)
@@ -773,7 +790,9 @@ def main(argv=None):
             latency = latency_of(plan, host_frames, lpx)
         if args.workload == "stream":
             stream_info = feeder_rates(plan, host_frames, lpx, elapsed, args.steps, world)
-        if not args.no_inflight and args.workload in ("stream", "kitti"):
+        if inflight_child is not None:
+            inflight = inflight_child
+        elif not args.no_inflight and args.workload in ("stream", "kitti"):
             inflight = inflight_curve(plan, lpx)
     if rank == 0:
         value = total_points_per_step * args.steps / elapsed / 1e6
