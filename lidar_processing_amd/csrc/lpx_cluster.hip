@@ -139,10 +139,13 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
                                                                  const uint32_t *__restrict__ nb_len,
                                                                  const uint32_t *__restrict__ nb_idx, uint8_t *state,
                                                                  int32_t *seed_of, uint32_t *queue, uint32_t *valid,
-                                                                 ReplayParams prm, uint64_t cap, FV fv)
+                                                                 ReplayParams prm, uint64_t cap, FrameState *fstate,
+                                                                 const uint32_t *__restrict__ roots, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<7>(fv.fs);
     frame = lpx_slot(frame, fv.fs);
+    fstate = lpx_slot(fstate, fv.fs);
+    roots = lpx_slot(roots, fv.fs);
     cc_lo = lpx_slot(cc_lo, fv.fs);
     cc_hi = lpx_slot(cc_hi, fv.fs);
     members = lpx_slot(members, fv.fs);
@@ -153,19 +156,30 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
     seed_of = lpx_slot(seed_of, fv.fs);
     queue = lpx_slot(queue, fv.fs);
     valid = lpx_slot(valid, fv.fs);
-    const uint32_t r = lpx_blk.x * RP_WAVES + threadIdx.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
-    const uint32_t M = frame->n_obstacle;
-    if (r >= M || frame->nb_total > cap)
+    const uint32_t n_roots = frame->n_roots;
+    if (frame->nb_total > cap || lpx_blk.x * RP_WAVES >= n_roots)
         return;
-    const uint32_t lo = cc_lo[r], hi = cc_hi[r];
-    if (hi <= lo)
-        return;  // r is not a root
     const unsigned long long lt = lpx_lanemask_lt();
-    uint32_t *q = queue + lo;  // one slot per member
-    uint32_t cursor = lo;
+    // persistent: every wavefront pulls component sets from the frame's work list (cc_ranges_kernel), like the LDS
+    // variants -- one workgroup per four POINT indices, of which one in a thousand is a root, made a 5M-point frame
+    // launch 750 000 workgroups that exit after three loads
     for (;;)
     {
+      uint32_t ticket = 0;
+      if (lane == 0)
+          ticket = atomicAdd(&fstate->root_cursor, 1u);
+      ticket = __shfl(ticket, 0, 64);
+      if (ticket >= n_roots)
+          break;
+      const uint32_t r = roots[ticket];
+      const uint32_t lo = cc_lo[r], hi = cc_hi[r];
+      if (hi <= lo)
+          continue;
+      uint32_t *q = queue + lo;  // one slot per member
+      uint32_t cursor = lo;
+      for (;;)
+      {
         // next seed: first member (ascending index) that is not removed (:70-75)
         uint32_t seed = 0xffffffffu;
         while (cursor < hi)
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(RP_WAVES *WAVE) void replay_kernel(const FrameState
         }
         if (lane == 0)
             valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;  // :113
+      }
     }
 }
 
@@ -1414,11 +1429,15 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
                                (const uint32_t *)ctx->rpos.p, (uint32_t *)ctx->dbg_buf, fv);
         }
         else
-            hipLaunchKernelGGL(replay_kernel, dim3((m_max + RP_WAVES - 1) / RP_WAVES, 1, ctx->cur_b),
+        {
+            // persistent grid over the work list of component sets (at most 2048 workgroups of four sequencers)
+            const uint32_t want = (m_max + RP_WAVES - 1) / RP_WAVES;
+            hipLaunchKernelGGL(replay_kernel, dim3(want < 2048u ? want : 2048u, 1, ctx->cur_b),
                                dim3(RP_WAVES * WAVE), 0, st,
                                frame, cc_lo, cc_hi, members, (const uint32_t *)ctx->nb_off.p,
                                (const uint32_t *)ctx->nb_len.p, (const uint32_t *)ctx->nb_idx.p, (uint8_t *)ctx->state.p, (int32_t *)ctx->seed_of.p,
-                               (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb, fv);
+                               (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb, frame, (const uint32_t *)ctx->rpos.p, fv);
+        }
     }
     {
         StageTimer tm(ctx, ST_LABELS);
