@@ -1381,7 +1381,12 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // the cap a second launch with one byte per point in HBM serves the frames that really are that large; each
         // launch checks the frame's obstacle count on the device (a 1M-point cloud usually has < 440k obstacles).
         static const int rs_state = getenv("LPX_RS_STATE") ? atoi(getenv("LPX_RS_STATE")) : 0;  // 1: states in HBM
-        const uint32_t lds_pts = rs_state == 1 ? 0u : (uint32_t)(((152 * 1024 - fixed) / sizeof(uint32_t) - 4) * 16);
+        // (LPX_RS_STATE: 1 states in HBM, 2 in LDS up to its capacity.)  Default: the LDS bitmap while it is at most 64 KiB
+        // (262 144 points): a larger one leaves room for one replay workgroup per CU and costs more than it saves --
+        // 1M-point frames (100 KiB bitmaps): 1060 Mpts/s with the states in LDS, 1125 with one byte per point in HBM;
+        // 120k-point frames (31 KiB): 1587 against 1505.
+        const uint32_t lds_fit = (uint32_t)(((152 * 1024 - fixed) / sizeof(uint32_t) - 4) * 16);
+        const uint32_t lds_pts = rs_state == 1 ? 0u : (rs_state == 2 ? lds_fit : (lds_fit < 262144u ? lds_fit : 262144u));
         uint32_t m_lds = m_max < lds_pts ? m_max : lds_pts;
         // The bound m_max is the INPUT size of the largest frame; the obstacle cloud is about half of it.  With many
         // chains in flight the replay workgroups of all of them are resident together for milliseconds, and what their
