@@ -424,7 +424,7 @@ def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_lau
     kern = dict(STAGE_KERNEL)
     if plan.lists:
         kern.update(cc_hook="cc_hook_kernel", neighbours="nb_group_kernel", components="cc_flatten_kernel",
-                    replay="replay_lds_kernel" if Mm <= 393216 else "replay_kernel")  # LDS bitmap limit
+                    replay="replay_lds_kernel<true>" if Mm <= 393216 else "replay_lds_kernel<false>")  # LDS bitmap limit
     per_pass = B > 1 or Nn / P > 24576  # which plane kernel ran (csrc/lpx_segment.hip)
     if not per_pass:
         kern["plane_passes"] = "plane_single_kernel"

@@ -567,3 +567,18 @@ def test_search_tables_adapt_their_group_size_to_the_scene():
         c.close()
     assert cand[1] < 0.9 * cand[0] and cand[2] == cand[1], cand  # 64 -> 32 nodes after the first dense call
     assert cand[3] < 0.9 * cand[4] and cand[5] == cand[4], cand  # the first frame still with 32, then back to 64
+
+
+def test_point_states_in_hbm_give_the_same_labels():
+    """the replay kernels keep their point states in an LDS bitmap while it fits and in HBM (one byte per point) beyond;
+    LPX_RP_STATE=1 / LPX_RS_STATE=1 (read once per process -- hence the subprocess) force the HBM form on the real
+    frames and on a ragged batch: every output equals the C restatement's / the single-frame path's"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, LPX_RP_STATE="1", LPX_RS_STATE="1",
+               PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(here, "state_check.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "state check ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
