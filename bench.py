@@ -235,6 +235,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-inflight", action="store_true", help="skip the frames-in-flight curve")
     ap.add_argument("--no-sub", action="store_true", help="skip the three-frames-cycled sub-measurement of the stream line")
+    ap.add_argument("--feeder-only", action="store_true",
+                    help="print only the PCIe-inclusive feeder rates of the stream (own process: side measurement of the default run)")
     ap.add_argument("--inflight-only", action="store_true",
                     help="(child of the default run) only the frames-in-flight curve, in a process of its own")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the one-core CPU baseline leg")
@@ -629,7 +631,7 @@ def inflight_curve(plan, lpx, seconds=0.6):
             "seconds_per_point": seconds, "curve": rows}
 
 
-def feeder_rates(plan, host_frames, lpx, elapsed, steps, world):
+def feeder_rates(plan, host_frames, lpx):
     """the same frames through the feeder (PCIe-inclusive): files -> pinned -> H2D -> chains -> D2H"""
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
@@ -645,15 +647,19 @@ def feeder_rates(plan, host_frames, lpx, elapsed, steps, world):
         for _ in range(passes):
             feeder.run(plan.ctxs[0], ids, plan.scfg, plan.ccfg, out)
         tf = (time.perf_counter() - a) / passes
-        # all contexts of the bench, one pipeline each (lpx_feeder_run_multi), the same frame list
-        out3 = feeder.run(plan.ctxs, ids, plan.scfg, plan.ccfg)
+        # ten of the bench's contexts, one pipeline each (lpx_feeder_run_multi), the frame list twice: with chains of 64
+        # a lane then runs four chains per pass (one chain per lane is all fill and drain; ten lanes were the best of
+        # 1 / 4 / 10 / 20: tools/feeder_scan.py)
+        lanes = plan.ctxs[:10]
+        ids_m = np.tile(ids, 2) if len(ids) <= 2048 else ids
+        out3 = feeder.run(lanes, ids_m, plan.scfg, plan.ccfg)
         a = time.perf_counter()
         for _ in range(passes):
-            feeder.run(plan.ctxs, ids, plan.scfg, plan.ccfg, out3)
-        tm = (time.perf_counter() - a) / passes
+            feeder.run(lanes, ids_m, plan.scfg, plan.ccfg, out3)
+        tm = (time.perf_counter() - a) / passes * len(ids) / len(ids_m)  # per len(ids) frames
         del out, out3
         feeder.close()
-    return {"frames": len(plan.my_ids), "device_resident_frames_per_s": round(plan.F * world * steps / elapsed, 1),
+    return {"frames": len(plan.my_ids),
             "feeder_frames_per_s": round(len(ids) / tf, 1),
             "feeder_mpts_s": round(plan.points_per_step / tf / 1e6, 2),
             "feeder_what": "lpx_feeder_run on ONE batch context: pinned records H2D, chains of "
@@ -661,8 +667,8 @@ def feeder_rates(plan, host_frames, lpx, elapsed, steps, world):
                            "two buffer sets (PCIe-inclusive; never the headline value)",
             "feeder_multi_frames_per_s": round(len(ids) / tm, 1),
             "feeder_multi_mpts_s": round(plan.points_per_step / tm / 1e6, 2),
-            "feeder_multi_what": f"lpx_feeder_run_multi on the {len(plan.ctxs)} contexts of this run (one "
-                                 "pipeline and host thread per context), the same frames"}
+            "feeder_multi_what": f"lpx_feeder_run_multi on {len(lanes)} of the contexts of this run (one pipeline "
+                                 f"and host thread per context, shared copy streams), {len(ids_m)} frames per pass"}
 
 
 def main(argv=None):
@@ -681,9 +687,9 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baselines(host_frames, wl, args.cpu_seconds)  # before the GPU is initialised (fork)
 
-    sub, overlap_sub, inflight_child = None, None, None
+    sub, overlap_sub, inflight_child, feeder_child = None, None, None, None
     if rank == 0 and world == 1 and args.workload == "stream" and not args.no_sub and not args.dry_run \
-            and not args.inflight_only:
+            and not args.inflight_only and not args.feeder_only:
         # Two side measurements, each by a CHILD process that runs to completion before this process touches the GPU
         # (a process that has initialised the GPU keeps its hardware queues: the device serves about 24 at full speed,
         # and a child measured beside a live parent -- or a second set of contexts inside one process -- reads 10-25 %
@@ -701,6 +707,10 @@ def main(argv=None):
                 inflight_child = child(["--workload", args.workload, "--inflight-only"])["throughput_vs_inflight"]
             except Exception as e:
                 inflight_child = {"error": repr(e)[:200]}
+        try:
+            feeder_child = child(["--workload", "stream", "--feeder-only"])["stream"]
+        except Exception as e:
+            feeder_child = {"error": repr(e)[:200]}
         try:
             d4 = child(["--workload", "stream", "--overlap", "--contexts", "10", "--batch", "64", "--frames-per-step", "640"])
             overlap_sub = {"mpts_s": d4["value"], "ms_per_step": d4["ms_per_step"],
@@ -777,6 +787,13 @@ def main(argv=None):
         plan.C, plan.B = WORKLOADS[args.workload]["contexts"], WORKLOADS[args.workload]["batch"]
         print(json.dumps({"throughput_vs_inflight": inflight_curve(plan, lpx)}))
         return 0
+    if args.feeder_only:
+        # files -> pinned -> H2D -> chains -> D2H on ten contexts, nothing else alive in this process
+        args.contexts, args.batch = 10, WORKLOADS["stream"]["batch"]
+        plan = Plan("stream", host_frames, args, rank, world, local_rank, torch, lpx)
+        print(json.dumps({"stream": feeder_rates(plan, host_frames, lpx)}))
+        plan.close()
+        return 0
     plan = Plan(args.workload, host_frames, args, rank, world, local_rank, torch, lpx)
     elapsed, counts = plan.timed(args.steps, args.warmup, barrier)
     elapsed, total_points_per_step, total_frames_per_step = aggregate(elapsed, plan.points_per_step, dev, world, plan.F)
@@ -788,8 +805,12 @@ def main(argv=None):
         roofline = roofline_of(plan, counts, elapsed, args.steps, world, stage_ms, launches, per_launch)
         if not args.no_latency:
             latency = latency_of(plan, host_frames, lpx)
-        if args.workload == "stream":
-            stream_info = feeder_rates(plan, host_frames, lpx, elapsed, args.steps, world)
+        if feeder_child is not None:
+            stream_info = dict(feeder_child)
+        elif args.workload == "stream" and not args.no_sub:
+            stream_info = feeder_rates(plan, host_frames, lpx)
+        if stream_info is not None and "error" not in stream_info:
+            stream_info = dict(device_resident_frames_per_s=round(plan.F * world * args.steps / elapsed, 1), **stream_info)
         if inflight_child is not None:
             inflight = inflight_child
         elif not args.no_inflight and args.workload in ("stream", "kitti"):

@@ -302,8 +302,10 @@ typedef struct
 int lpx_feeder_run(lpx_feeder *f, lpx_ctx *batch_ctx, const uint32_t *frame_ids, uint32_t n_frames,
                    const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg, const lpx_stream_out *out);
 /* The same over n_ctx batch contexts of equal slot count B: chain k (frames [k B, (k+1) B) of frame_ids) runs on
- * context k % n_ctx, every context with its own copy streams, buffer sets and host thread, so several chains
- * compute at once while PCIe moves the others' data.  Same results, same output layout. */
+ * context k % n_ctx, every context with its own buffer sets and host thread, so several chains compute at once while
+ * PCIe moves the others' data; the copy streams are shared by the pipelines (two per direction; nothing ever waits
+ * on them).  Same results, same output layout.  Keep GPU_MAX_HW_QUEUES above the number of contexts (the library
+ * sets 32 when it is loaded and the variable is unset): streams that share a hardware queue run one after the other. */
 int lpx_feeder_run_multi(lpx_feeder *f, lpx_ctx *const *batch_ctxs, uint32_t n_ctx, const uint32_t *frame_ids,
                          uint32_t n_frames, const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
                          const lpx_stream_out *out);

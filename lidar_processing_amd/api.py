@@ -370,6 +370,18 @@ class PinnedArray:
             pass
 
 
+class _PlainArray:
+    """ordinary (pageable) host memory with the interface of PinnedArray"""
+
+    def __init__(self, shape, dtype):
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.array = np.zeros(self.shape, self.dtype)
+
+    def free(self):
+        self.array = None
+
+
 def pcd_info(path):
     """lpx_pcd_info_read: dict(n_points, point_step, offsets=(x, y, z), n_fields) of a binary PCD v0.7 file"""
     inf = _lib.PcdInfo()
@@ -429,7 +441,7 @@ class Feeder:
         return np.frombuffer(buf, dtype=np.float32, count=inf.n_points * inf.point_step // 4).reshape(
             inf.n_points, inf.point_step // 4)
 
-    def run(self, ctx, frame_ids, seg_cfg, clu_cfg, out=None):
+    def run(self, ctx, frame_ids, seg_cfg, clu_cfg, out=None, pinned=True):
         """lpx_feeder_run through the batch context `ctx` -- or lpx_feeder_run_multi through a list of batch
         contexts of equal slot count (chain k on context k % len(ctx)); returns the dict of pinned, pitched result
         arrays (labels, ground_idx, obstacle_idx, cluster_labels (F, pitch); planes (F, 4P); counts (F, 4))"""
@@ -440,10 +452,13 @@ class Feeder:
             raise LpxError(-1, f"frame id {int(ids.max())} out of range: the feeder holds {self.n_frames} frames")
         if out is None:
             pitch = max([self.info[i]["n_points"] for i in ids.tolist()] + [1])
+            # pinned arrays are written by the device itself (one launch per chain); ordinary memory (pinned=False)
+            # goes through the copy engine, one exact-size copy per frame and array
+            arr = PinnedArray if pinned else _PlainArray
             out = dict(pitch=pitch,
-                       labels=PinnedArray((F, pitch), np.uint32), ground_idx=PinnedArray((F, pitch), np.uint32),
-                       obstacle_idx=PinnedArray((F, pitch), np.uint32), cluster_labels=PinnedArray((F, pitch), np.int32),
-                       planes=PinnedArray((F, 4 * P), np.float32), counts=PinnedArray((F, 4), np.uint32))
+                       labels=arr((F, pitch), np.uint32), ground_idx=arr((F, pitch), np.uint32),
+                       obstacle_idx=arr((F, pitch), np.uint32), cluster_labels=arr((F, pitch), np.int32),
+                       planes=arr((F, 4 * P), np.float32), counts=arr((F, 4), np.uint32))
         so = _lib.StreamOut(*[out[k].array.ctypes.data for k in ("labels", "ground_idx", "obstacle_idx", "cluster_labels",
                                                                  "planes", "counts")], out["pitch"])
         sc, cc = seg_cfg._c(), clu_cfg._c()

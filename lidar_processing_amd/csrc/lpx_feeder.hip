@@ -16,7 +16,16 @@
 //                copies of labels / index lists / cluster labels / planes on a second copy stream.
 // PCIe moves in both directions next to the compute; the device never waits for the host between chains.
 // lpx_feeder_run_multi runs one such pipeline per context (chain k belongs to context k % C, one host thread each), so
-// that several chains compute at once like in the device-resident case.
+// that several chains compute at once like in the device-resident case.  The lanes SHARE the copy streams (a small
+// pool per direction, LPX_FEEDER_COPY_STREAMS): the link is one resource whatever the number of streams, the device
+// serves about 24 hardware queues at full speed (three streams per lane made 20 lanes slower than 4), and nothing
+// ever WAITS on a copy stream -- a lane issues a copy only when the host already knows that its buffer set is free
+// (it has waited for that chain's compute event itself), so one lane's copies never hold up another's behind an
+// event.  The 4-word frame counts are written by the chain's last kernel straight into pinned host memory.
+// (Measured with GPU_MAX_HW_QUEUES=32, 2560 frames, chains of 64: 4.9 / 10.7 / 12.2 / 10.7 k frames/s on 1 / 4 / 10 /
+// 20 lanes against 14.7 k device-resident on ten contexts; the link alone carries 22 k frames/s of this traffic.
+// Replacing the 320 copies of a chain by two kernels that read / write the pinned memory themselves was built and
+// measured: 8.0-8.7 k frames/s -- their workgroups queue for CUs behind the chains' -- so the copy engines stay.)
 #include "lpx_internal.h"
 
 #include <errno.h>
@@ -30,12 +39,13 @@
 // device side of one pipeline: its copy streams, two buffer sets and their events
 struct FeederLane
 {
-    hipStream_t h2d = nullptr, d2h = nullptr;
+    hipStream_t h2d = nullptr, d2h = nullptr;  // borrowed from the feeder's pools
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_compute[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
     void *d_in[2] = {nullptr, nullptr};
     void *d_out[2] = {nullptr, nullptr};
     size_t in_bytes = 0, out_bytes = 0;
-    uint32_t *h_counts = nullptr;  // pinned, 2 sets x B x 4
+    uint32_t *h_counts = nullptr;  // pinned, 2 sets x B x 4: written by the device (relabel_kernel), read by the host
+    uint32_t *d_counts = nullptr;  // the device's address of h_counts
     uint32_t cap_b = 0, cap_pitch = 0, cap_P = 0;
     int rc = 0;
     char err[512] = {0};
@@ -51,6 +61,7 @@ struct lpx_feeder
     uint32_t max_points = 0, max_step = 0;
     char err[512] = {0};
     std::vector<FeederLane *> lanes;  // device side of lpx_feeder_run*, one lane per context (sized on first use)
+    std::vector<hipStream_t> h2d_pool, d2h_pool;  // copy streams shared by the lanes (lane c uses stream c % size)
 };
 
 static int ffail(lpx_feeder *f, int code, const char *fmt, const char *a, const char *b = "")
@@ -284,11 +295,7 @@ static void lane_release(FeederLane *f)
     if (f->h_counts)
         hipHostFree(f->h_counts);
     f->h_counts = nullptr;
-    if (f->h2d)
-        hipStreamDestroy(f->h2d);
-    if (f->d2h)
-        hipStreamDestroy(f->d2h);
-    f->h2d = f->d2h = nullptr;
+    f->d_counts = nullptr;
     f->cap_b = f->cap_pitch = f->cap_P = 0;
 }
 
@@ -300,6 +307,12 @@ static void feeder_release_device(lpx_feeder *f)
         delete l;
     }
     f->lanes.clear();
+    for (hipStream_t st : f->h2d_pool)
+        hipStreamDestroy(st);
+    for (hipStream_t st : f->d2h_pool)
+        hipStreamDestroy(st);
+    f->h2d_pool.clear();
+    f->d2h_pool.clear();
 }
 
 extern "C" void lpx_feeder_destroy(lpx_feeder *f)
@@ -370,8 +383,6 @@ static int lane_prepare(FeederLane *f, uint32_t max_step, uint32_t B, uint32_t p
         return LPX_OK;
     hipDeviceSynchronize();
     lane_release(f);
-    FHIP(f, hipStreamCreateWithFlags(&f->h2d, hipStreamNonBlocking));
-    FHIP(f, hipStreamCreateWithFlags(&f->d2h, hipStreamNonBlocking));
     f->in_bytes = (size_t)B * pitch * max_step;
     f->out_bytes = sizeof(uint32_t) * ((size_t)B * pitch * 4 + (size_t)B * 4 * P + (size_t)B * 4) + 256;
     for (int s = 0; s < 2; ++s)
@@ -383,6 +394,8 @@ static int lane_prepare(FeederLane *f, uint32_t max_step, uint32_t B, uint32_t p
         FHIP(f, hipEventCreateWithFlags(&f->ev_d2h[s], hipEventDisableTiming));
     }
     FHIP(f, hipHostMalloc((void **)&f->h_counts, sizeof(uint32_t) * 2 * (size_t)B * 4, hipHostMallocDefault));
+    FHIP(f, hipHostGetDevicePointer((void **)&f->d_counts, f->h_counts, 0));
+    memset(f->h_counts, 0, sizeof(uint32_t) * 2 * (size_t)B * 4);
     f->cap_b = B;
     f->cap_pitch = pitch;
     f->cap_P = P;
@@ -418,10 +431,8 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
         const uint32_t k = first + j * stride;
         const uint32_t lo = k * B, nb = (a.n_frames - lo < B) ? a.n_frames - lo : B;
         const OutSet o = out_set(l->d_out[s], B, l->cap_pitch, l->cap_P);
-        uint32_t *hc = l->h_counts + (size_t)s * B * 4;
+        const uint32_t *hc = l->h_counts + (size_t)s * B * 4;  // written by the chain's last kernel
         FHIP(l, hipEventSynchronize(l->ev_compute[s]));
-        FHIP(l, hipMemcpyAsync(hc, o.counts, sizeof(uint32_t) * 4 * nb, hipMemcpyDeviceToHost, l->d2h));
-        FHIP(l, hipStreamSynchronize(l->d2h));
         for (uint32_t b = 0; b < nb; ++b)
         {
             const uint32_t fid = a.frame_ids[lo + b], n = f->info[fid].n_points;
@@ -463,9 +474,8 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
     {
         const int s = (int)(j & 1u);
         const uint32_t lo = k * B, nb = (a.n_frames - lo < B) ? a.n_frames - lo : B;
-        // inputs of set s are free once the lane's chain j - 2 has computed
-        if (j >= 2)
-            FHIP(l, hipStreamWaitEvent(l->h2d, l->ev_compute[s], 0));
+        // inputs of set s are free once the lane's chain j - 2 has computed: drain(j - 2) has waited for exactly that
+        // on the host already, so the shared copy stream is never made to wait
         for (uint32_t b = 0; b < nb; ++b)
         {
             const uint32_t fid = a.frame_ids[lo + b];
@@ -480,7 +490,7 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
             FHIP(l, hipStreamWaitEvent(ctx->stream, l->ev_d2h[s], 0));  // chain j - 2's results have left set s
         const OutSet o = out_set(l->d_out[s], B, l->cap_pitch, l->cap_P);
         rc = lpx_batch_impl(ctx, nb, l->d_in[s], step, a.offs, l->cap_pitch, n_pts, a.seg_cfg, a.clu_cfg, o.labels, o.gidx,
-                            o.oidx, o.planes, o.clabels, o.counts);
+                            o.oidx, o.planes, o.clabels, l->d_counts + (size_t)s * B * 4);
         if (rc)
             return ffail(l, rc, "%s", lpx_last_error(ctx));
         FHIP(l, hipEventRecord(l->ev_compute[s], ctx->stream));
@@ -489,7 +499,8 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
     }
     if (j && (rc = drain(j - 1)))
         return rc;
-    FHIP(l, hipStreamSynchronize(l->d2h));
+    for (int s = 0; s < 2 && (uint32_t)s < j; ++s)  // the lane's own last copies (the stream is shared)
+        FHIP(l, hipEventSynchronize(l->ev_d2h[s]));
     return LPX_OK;
 }
 }  // namespace
@@ -550,14 +561,27 @@ extern "C" int lpx_feeder_run_multi(lpx_feeder *f, lpx_ctx *const *ctxs, uint32_
     a.offs[1] = lay.off_y;
     a.offs[2] = lay.off_z;
     a.n_chains = (n_frames + a.B - 1) / a.B;
-    const uint32_t lanes = n_ctx < a.n_chains ? n_ctx : a.n_chains;
     if (hipSetDevice(f->device) != hipSuccess)
         return ffail(f, LPX_ERR_HIP, "%s", "hipSetDevice failed");
+    const uint32_t lanes = n_ctx < a.n_chains ? n_ctx : a.n_chains;
     while (f->lanes.size() < lanes)
         f->lanes.push_back(new FeederLane());
+    static const int pool_env = getenv("LPX_FEEDER_COPY_STREAMS") ? atoi(getenv("LPX_FEEDER_COPY_STREAMS")) : 2;
+    const size_t pool = (size_t)(pool_env < 1 ? 1 : (pool_env > 16 ? 16 : pool_env));
+    while (f->h2d_pool.size() < pool)
+    {
+        hipStream_t up = nullptr, down = nullptr;
+        if (hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&down, hipStreamNonBlocking) != hipSuccess)
+            return ffail(f, LPX_ERR_HIP, "%s", "hipStreamCreateWithFlags failed");
+        f->h2d_pool.push_back(up);
+        f->d2h_pool.push_back(down);
+    }
     int rc;
     for (uint32_t c = 0; c < lanes; ++c)
     {
+        f->lanes[c]->h2d = f->h2d_pool[c % pool];
+        f->lanes[c]->d2h = f->d2h_pool[c % pool];
         if ((rc = lane_prepare(f->lanes[c], f->max_step, a.B, pitch, a.P)))
             return ffail(f, rc, "%s", f->lanes[c]->err);
         if ((rc = lpx_reserve(ctxs[c], pitch, 0)))

@@ -151,3 +151,35 @@ def test_feeder_over_several_contexts_gives_the_single_context_results(pcd_dir, 
             assert np.array_equal(out2[key].array[j, :cnt], out[key].array[fid, :cnt]), (key, fid)
         assert np.array_equal(out2["planes"].array[j].view(np.uint32), out["planes"].array[fid].view(np.uint32))
     feeder.close()
+
+
+def test_feeder_results_in_ordinary_memory_equal_the_pinned_ones(pcd_dir):
+    """pinned result arrays are filled by the device (one push launch per chain, records pulled by one launch per chain);
+    ordinary host memory takes the copy-engine path, one exact-size copy per frame and array: same bytes, ragged
+    frame list, one and several contexts"""
+    cname = "p6i5_d025q05"
+    skw, ckw = STREAM_CONFIGS[cname]
+    scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
+    names = stream_names()[:24]
+    feeder = Feeder([pcd_dir / f"{n}.pcd" for n in names])
+    ctxs = [Context(0, batch=8) for _ in range(3)]
+    try:
+        ids = np.array([23, 0, 7, 7, 12, 1, 19, 5, 3, 22, 8, 8, 8, 14, 2, 11, 6, 21, 9])
+        for who in (ctxs[0], ctxs):
+            a = feeder.run(who, ids, scfg, ccfg)
+            b = feeder.run(who, ids, scfg, ccfg, pinned=False)
+            assert np.array_equal(a["counts"].array, b["counts"].array)
+            assert np.array_equal(a["planes"].array.view(np.uint32), b["planes"].array.view(np.uint32))
+            for j in range(len(ids)):
+                n = feeder.info[int(ids[j])]["n_points"]
+                ng, no = a["counts"].array[j, 0], a["counts"].array[j, 1]
+                assert np.array_equal(a["labels"].array[j, :n], b["labels"].array[j, :n])
+                assert np.array_equal(a["ground_idx"].array[j, :ng], b["ground_idx"].array[j, :ng])
+                assert np.array_equal(a["obstacle_idx"].array[j, :no], b["obstacle_idx"].array[j, :no])
+                assert np.array_equal(a["cluster_labels"].array[j, :no], b["cluster_labels"].array[j, :no])
+                # nothing is written past the exact sizes (the arrays start zeroed)
+                assert not b["ground_idx"].array[j, ng:].any() and not a["ground_idx"].array[j, ng:].any()
+    finally:
+        for c in ctxs:
+            c.close()
+        feeder.close()
