@@ -23,12 +23,15 @@ _stream_gold = None
 def load_frame(name):
     """(n,4) float32 x y z intensity, bit-identical to the reference's data/<name>.pcd payload"""
     global _frames
-    if _frames is None:
-        _frames = np.load(os.path.join(GOLDEN, "frames.npz"))
-    pts = np.empty((_frames[f"{name}_xyz_mm"].shape[0], 4), np.float32)
-    pts[:, :3] = (_frames[f"{name}_xyz_mm"] / 1000.0).astype(np.float32)
-    pts[:, 3] = (_frames[f"{name}_intensity_c"] / 100.0).astype(np.float32)
-    for r, c in _frames[f"{name}_negzero"]:
+    # the lazily read archive keeps a file handle: a forked worker (tests/golden/make_eigen_bound.py) that inherited
+    # the parent's would share its file OFFSET with its siblings and read garbage, so the handle is per process
+    if _frames is None or _frames[0] != os.getpid():
+        _frames = (os.getpid(), np.load(os.path.join(GOLDEN, "frames.npz")))
+    z = _frames[1]
+    pts = np.empty((z[f"{name}_xyz_mm"].shape[0], 4), np.float32)
+    pts[:, :3] = (z[f"{name}_xyz_mm"] / 1000.0).astype(np.float32)
+    pts[:, 3] = (z[f"{name}_intensity_c"] / 100.0).astype(np.float32)
+    for r, c in z[f"{name}_negzero"]:
         pts[r, c] = -0.0
     return pts
 
@@ -94,7 +97,8 @@ def stream_gold():
 def gold():
     global _gold
     if _gold is None:
-        _gold = np.load(os.path.join(GOLDEN, "golden.npz"))
+        with np.load(os.path.join(GOLDEN, "golden.npz")) as z:
+            _gold = {k: z[k] for k in z.files}  # materialised: no file handle to share with forked workers
     return _gold
 
 
