@@ -71,7 +71,7 @@ WORKLOADS = {
 # stage -> kernel that dominates it (names as rocprofv3 prints them), for the PMC traffic lookup
 STAGE_KERNEL = {"ingest": "ingest_kernel", "xsort": "radix_scatter_kernel<unsigned int, true>", "gather": "gather_kernel",
                 "zsort": "radix_scatter_kernel<unsigned long, false>", "seeds": "seed_select_kernel",
-                "plane_passes": "plane_single_kernel", "compact": "compact_kernel", "kd_build": "kd_block_kernel",
+                "plane_passes": "plane_pass_kernel", "compact": "compact_kernel", "kd_build": "kd_block_kernel",
                 "cc_hook": "grid_pairs_kernel", "neighbours": "nb_index_kernel",
                 "components": "radix_scatter_kernel<unsigned int, true>", "replay": "replay_search_kernel",
                 "labels": "relabel_kernel"}
@@ -83,7 +83,7 @@ def frame_bytes(N, M, I):
     return N * (44 + 12 * I) + 80 * M
 
 
-def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=None, plane_per_pass=True):
+def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=None):
     """Algorithmic HBM bytes of `stage` for ONE frame with N points, M obstacle points (kernel table).
     Expansion-driven path: `cand` candidates distance-tested by the replay's searches, `groups` kd groups.  List
     path (E neighbour-list entries, E_replay of them read by the replay) when cand is None."""
@@ -98,9 +98,8 @@ def algorithmic_bytes(stage, N, M, E, I, P, E_replay=None, cand=None, groups=Non
         "gather": N * (4 + 12 + 12),                 # index, gather, x-sorted SoA
         "zsort": 5 * N * (8 + 8 + 8),
         "seeds": N * 4 + P * 64,                     # the selection kernel reads the x-sorted z once
-        # one launch per pass (batches, large segments): the x-sorted SoA is read by every pass (12 B per
-        # point per pass, I + 1 passes); plane_single_kernel (one frame) reads it once and keeps it in registers
-        "plane_passes": (N * 12 * (I + 1) + N) if plane_per_pass else (N * 12 + N),
+        # one launch per pass: the x-sorted SoA is read by every pass (12 B per point per pass, I + 1 passes)
+        "plane_passes": N * 12 * (I + 1) + N,
         "compact": N * (1 + 4 + 4 + 4) + M * (12 + 16),  # flag, index, label, list, obstacle SoA + kd nodes
         "kd_build": M * 16 * 2 * 17,                 # ~log2(M) levels, each reads + writes the node array
         # components: (search) cell table insert + 13 lookups per cell + root per point / (lists) every list re-read
@@ -427,14 +426,10 @@ def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_lau
     if plan.lists:
         kern.update(cc_hook="cc_hook_kernel", neighbours="nb_group_kernel", components="cc_flatten_kernel",
                     replay="replay_lds_kernel<true>" if Mm <= 393216 else "replay_lds_kernel<false>")  # LDS bitmap limit
-    per_pass = B > 1 or Nn / P > 24576  # which plane kernel ran (csrc/lpx_segment.hip)
-    if not per_pass:
-        kern["plane_passes"] = "plane_single_kernel"
-    else:
-        kern["plane_passes"] = "plane_pass_kernel"
+    kern["plane_passes"] = "plane_pass_kernel"
 
     def stage_row(stage):
-        algo = frames_per_launch * algorithmic_bytes(stage, Nn, Mm, E, I, P, E_replay, cand, groups, per_pass)
+        algo = frames_per_launch * algorithmic_bytes(stage, Nn, Mm, E, I, P, E_replay, cand, groups)
         ms = per_launch[stage]
         ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         row = {"kernel": kern.get(stage, stage), "avg_launch_ms": round(ms, 5),

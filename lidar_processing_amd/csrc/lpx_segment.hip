@@ -1074,245 +1074,6 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
 }
 
 // ------------------------------------------------------------------------------------------------
-// All I+1 passes in ONE launch for segments of up to ONE_MAX_POINTS points: one workgroup of 1024
-// threads per segment keeps its points in registers (read from HBM once), reduces the moments through
-// LDS, lets one lane solve the 3x3 problem and broadcasts the plane through LDS.  Nothing leaves the CU
-// between passes and no workgroup ever waits for another one, so any number of frames can share the
-// device.  Per-block ground/obstacle counts are produced for the same SEG_CHUNK blocks the compaction
-// uses.  Larger segments take the launch-per-pass path above.
-// ------------------------------------------------------------------------------------------------
-constexpr int ONE_THREADS = 1024;
-constexpr int ONE_WAVES = ONE_THREADS / WAVE;
-constexpr int ONE_PTS = 24;
-constexpr uint32_t ONE_MAX_POINTS = ONE_THREADS * ONE_PTS;  // 24576
-constexpr int ONE_CHUNKS = ONE_MAX_POINTS / SEG_CHUNK;      // 6
-constexpr int ONE_U_PER_CHUNK = SEG_CHUNK / ONE_THREADS;    // 4: point slot u of any thread lies in chunk u / 4
-static_assert(SEG_CHUNK % ONE_THREADS == 0, "chunk of a register slot must not depend on the thread");
-
-__global__ __launch_bounds__(ONE_THREADS) void plane_single_kernel(const float *__restrict__ XS,
-                                                                    const float *__restrict__ YS,
-                                                                    const float *__restrict__ ZS, SegParams prm,
-                                                                    SegState *__restrict__ st,
-                                                                    long long *facc,
-                                                                    uint8_t *__restrict__ flags,
-                                                                    uint32_t *__restrict__ blk_counts,
-                                                                    const FrameState *__restrict__ frame, size_t fs)
-{
-    const LpxBlock lpx_blk = lpx_block<2>(fs);
-    __shared__ long long red[ONE_WAVES][LPX_ACC_WORDS];
-    __shared__ float s_plane[6];  // a, b, c, d, thr, failed
-    XS = lpx_slot(XS, fs);
-    YS = lpx_slot(YS, fs);
-    ZS = lpx_slot(ZS, fs);
-    st = lpx_slot(st, fs);
-    facc = lpx_slot(facc, fs);
-    flags = lpx_slot(flags, fs);
-    blk_counts = lpx_slot(blk_counts, fs);
-    frame = lpx_slot(frame, fs);
-    seg_bind(prm, frame);
-    const bool any_far = frame->has_far != 0;
-    const uint32_t s = lpx_blk.x;
-    long long *fa = facc + (size_t)s * LPX_FAR_WORDS;
-    const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
-    const uint32_t lo = s * prm.n_per, hi = lo + prm.n_per;
-    const SegState sst = st[s];  // written by seed_kernel in the previous launch
-    const bool skip = sst.failed == 2;
-    const bool seeds_ok = sst.has_seeds != 0;
-    bool dead = sst.failed != 0;
-    float pa = 0.0f, pb = 0.0f, pc = 0.0f, pd = 0.0f, thr = 0.0f;
-
-    float xs[ONE_PTS], ys[ONE_PTS], zs[ONE_PTS];
-#pragma unroll
-    for (int u = 0; u < ONE_PTS; ++u)
-    {
-        const uint32_t p = lo + tid + u * ONE_THREADS;
-        const bool in = p < hi;
-        xs[u] = in ? XS[p] : 0.0f;
-        ys[u] = in ? YS[p] : 0.0f;
-        zs[u] = in ? ZS[p] : 0.0f;
-    }
-
-    for (uint32_t t = 0;; ++t)
-    {
-        const bool final_pass = (t == prm.I);
-        long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
-        uint32_t cnt[ONE_CHUNKS];  // ground | obstacle << 16 per SEG_CHUNK block of the segment
-#pragma unroll
-        for (int c = 0; c < ONE_CHUNKS; ++c)
-            cnt[c] = 0;
-#pragma unroll
-        for (int u = 0; u < ONE_PTS; ++u)
-        {
-            const uint32_t p = lo + tid + u * ONE_THREADS;
-            const bool in = p < hi;
-            float x = xs[u], y = ys[u], z = zs[u];
-            // keep the fixed-point conversions and products inside the pass: hoisted out of the t loop
-            // they would cost 15 more registers per point and this kernel is limited to 128
-            asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-            bool member;
-            if (t == 0)
-                member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
-            else
-            {
-                const float dist = ((x * pa + y * pb) + z * pc) - pd;
-                member = dist < thr;
-            }
-            member = member && !dead && in;
-            if (final_pass)
-            {
-                if (in)
-                {
-                    // number_of_iterations == 0: seeds are ground, the rest stays UNKNOWN (:243-247)
-                    const uint8_t f = skip ? 0 : (member ? 1 : ((prm.I == 0 && !dead) ? 0 : 2));
-                    flags[p] = f;
-                    cnt[u / ONE_U_PER_CHUNK] += (f == 1 ? 1u : 0u) + (f == 2 ? 0x10000u : 0u);
-                }
-            }
-            else if (member && any_far && !is_near(x, y, z))
-                far_accumulate(fa, x, y, z);
-            else if (member)
-            {
-                const int qx = __float2int_rn(x * FIX_SCALE);
-                const int qy = __float2int_rn(y * FIX_SCALE);
-                const int qz = __float2int_rn(z * FIX_SCALE);
-                a_n += 1;
-                a_x += qx;
-                a_y += qy;
-                a_z += qz;
-                a_xx += (long long)qx * qx;
-                a_xy += (long long)qx * qy;
-                a_xz += (long long)qx * qz;
-                a_yy += (long long)qy * qy;
-                a_yz += (long long)qy * qz;
-                a_zz += (long long)qz * qz;
-            }
-        }
-        if (final_pass)
-        {
-#pragma unroll
-            for (int c = 0; c < ONE_CHUNKS; ++c)
-            {
-                const uint32_t tot = lpx_wave_sum_u32(cnt[c]);  // <= 4 per lane: no carry into the high half
-                if (lane == 0)
-                    red[w][c] = tot;
-            }
-            __syncthreads();
-            const uint32_t nb = prm.P * prm.bps;
-            if (tid < prm.bps && tid < (uint32_t)ONE_CHUNKS)
-            {
-                uint32_t g = 0, o = 0;
-                for (int i = 0; i < ONE_WAVES; ++i)
-                {
-                    const uint32_t v = (uint32_t)red[i][tid];
-                    g += v & 0xffffu;
-                    o += v >> 16;
-                }
-                blk_counts[s * prm.bps + tid] = g;
-                blk_counts[nb + s * prm.bps + tid] = o;
-            }
-            if (s == 0 && tid == 0)
-                blk_counts[2 * nb] = 0;  // sentinel: the exclusive scan leaves the grand total here
-            return;
-        }
-
-        // 16 words: n, sx, sy, sz, then (hi, lo) limbs of the six second moments
-        long long v[LPX_ACC_WORDS];
-        v[0] = a_n;
-        v[1] = a_x;
-        v[2] = a_y;
-        v[3] = a_z;
-        const long long sm[6] = {a_xx, a_xy, a_xz, a_yy, a_yz, a_zz};
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-        {
-            v[4 + 2 * i] = sm[i] >> 32;
-            v[5 + 2 * i] = sm[i] & 0xffffffffLL;
-        }
-#pragma unroll
-        for (int i = 0; i < LPX_ACC_WORDS; ++i)
-        {
-            v[i] = lpx_wave_sum_i64(v[i]);
-            if (lane == 0)
-                red[w][i] = v[i];
-        }
-        if (any_far)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the far points' atomics of every lane
-        __syncthreads();
-        if (tid < LPX_ACC_WORDS)
-        {
-            long long tot = 0;
-#pragma unroll
-            for (int i = 0; i < ONE_WAVES; ++i)
-                tot += red[i][tid];
-            red[0][tid] = tot;  // only thread tid touches column tid of row 0 in this phase
-        }
-        // fetch and clear the far accumulators (one lane each) while the columns above are summed
-        long long far_w = 0;
-        if (any_far && tid >= WAVE && tid < WAVE + LPX_FAR_WORDS)
-            far_w = (long long)atomicExch((unsigned long long *)&fa[tid - WAVE], 0ull);
-        __syncthreads();
-        if (any_far && tid >= WAVE && tid < WAVE + LPX_FAR_WORDS)
-            (&red[1][0])[tid - WAVE] = far_w;  // rows 1 and 2 are free once the column sums are done
-        if (any_far)
-            __syncthreads();
-        if (tid == 0)
-        {
-            long long m[LPX_ACC_WORDS];
-            for (int i = 0; i < LPX_ACC_WORDS; ++i)
-                m[i] = red[0][i];
-            float plane[4] = {pa, pb, pc, pd};
-            float nthr = thr;
-            uint32_t failed = dead ? (skip ? 2u : 1u) : 0u;
-            bool fitted = false;
-            if (!dead)
-            {
-                // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
-                if (!plane_from_moments(m, any_far ? &red[1][0] : nullptr, plane))
-                    failed = 1;
-                else
-                {
-                    nthr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
-                    fitted = true;
-                }
-            }
-            SegState *o = st + s;
-            if (fitted)
-            {
-                o->plane[0] = plane[0];
-                o->plane[1] = plane[1];
-                o->plane[2] = plane[2];
-                o->plane[3] = plane[3];
-                o->thr = nthr;
-                o->fitted = 1u;
-                s_plane[0] = plane[0];
-                s_plane[1] = plane[1];
-                s_plane[2] = plane[2];
-                s_plane[3] = plane[3];
-                s_plane[4] = nthr;
-            }
-            else
-            {
-                s_plane[0] = pa;
-                s_plane[1] = pb;
-                s_plane[2] = pc;
-                s_plane[3] = pd;
-                s_plane[4] = thr;
-            }
-            o->failed = failed;
-            s_plane[5] = __uint_as_float(failed);
-        }
-        __syncthreads();
-        pa = s_plane[0];
-        pb = s_plane[1];
-        pc = s_plane[2];
-        pd = s_plane[3];
-        thr = s_plane[4];
-        dead = __float_as_uint(s_plane[5]) != 0;
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // compaction: flags -> labels (original order), ground / obstacle index lists in output-cloud
 // order (:331-343, Q7) and the obstacle SoA handed to clustering.
 // ------------------------------------------------------------------------------------------------
@@ -1703,16 +1464,10 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     uint32_t *blk_counts = (uint32_t *)ctx->blk_counts.p;
     {
         StageTimer tm(ctx, ST_PLANE);
-        // One frame: all passes in one launch (1024-thread workgroups that keep the points in registers: shortest
-        // latency).  A batch shares the device with other chains, and a workgroup that needs a whole CU's registers
-        // waits for a CU to drain (measured 3.2 ms under load against 0.17 ms alone): batches take the launch-per-pass
-        // kernel, whose 256-thread workgroups schedule anywhere (0.5 ms under load).  LPX_PLANE_MODE=0 forces the
-        // single launch.
-        static const int plane_mode = getenv("LPX_PLANE_MODE") ? atoi(getenv("LPX_PLANE_MODE")) : 1;
-        if (prm.n_per <= ONE_MAX_POINTS && !(plane_mode == 1 && B > 1))
-            hipLaunchKernelGGL(plane_single_kernel, dim3(P, 1, B), dim3(ONE_THREADS), 0, st, XS, YS, ZS, prm, sst, facc,
-                               (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
-        else
+        // One launch per pass, 256-thread workgroups that schedule anywhere.  (Round 1-2 gave a single frame ONE launch
+        // for all passes -- a 1024-thread workgroup per segment with its points in registers: under load that workgroup
+        // waited for a whole CU to drain (3.2 ms against 0.5), and alone it has since been overtaken too: 0.145 ms
+        // against 0.095 ms for the six launches of a 123k-point frame.  Removed.)
         {
             const dim3 g2(prm.bps, P, B);
             for (uint32_t t = 0; t < I; ++t)
