@@ -766,6 +766,9 @@ def main(argv=None):
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback (--dry-run walks the launch only)")
     # one rank per GPU; on a box with fewer GPUs than ranks (the 1-GPU test boxes: `--gpus 2 --backend gloo` walks the
     # N > 1 path with both ranks on the one device -- RCCL itself refuses two ranks on one GPU) ranks share devices
+    shared_gpus = world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count()
+    if shared_gpus and backend == "nccl" and not args.backend:
+        backend = "gloo"  # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the line then says so
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -835,7 +838,9 @@ def main(argv=None):
                        "points_per_step": int(total_points_per_step), "frames_per_step": int(total_frames_per_step),
                        "frames_per_s": round(total_frames_per_step * args.steps / elapsed, 2),
                        "sharding": "frame i -> GPU i mod N, no data-path collective",
-                       "distributed_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
+                       "distributed_backend": (backend + (" (RCCL)" if backend == "nccl" else "")
+                                               + (" -- ranks share GPUs: fewer devices than ranks on this box"
+                                                  if shared_gpus else "")) if world > 1 else None,
                        "distributed_world_size": dist.get_world_size() if world > 1 else 1},
             "vs_target": {"north_star_mpts_s": 50.0, "ratio": round(value / 50.0, 2)},
             "roofline": roofline,
