@@ -506,8 +506,8 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
 }  // namespace
 
 // Frames frame_ids[0 .. n_frames) of the feeder through n_ctx batch contexts of equal slot count B (the chain
-// length): chain k -- frames [k B, (k+1) B) -- runs on context k % n_ctx, every context with its own copy streams
-// and buffer sets and its own host thread.  Results to host arrays pitched by out->frame_pitch elements per frame
+// length): chain k -- frames [k B, (k+1) B) -- runs on context k % n_ctx, every context with its own
+// buffer sets and host thread (the copy streams are shared).  Results to host arrays pitched by out->frame_pitch elements per frame
 // (planes: 4 P floats, counts: 4 words {n_ground, n_obstacle, n_clusters, status}).  Synchronous at return.
 extern "C" int lpx_feeder_run_multi(lpx_feeder *f, lpx_ctx *const *ctxs, uint32_t n_ctx, const uint32_t *frame_ids,
                                     uint32_t n_frames, const lpx_seg_cfg *seg_cfg, const lpx_clu_cfg *clu_cfg,
