@@ -452,8 +452,8 @@ class Feeder:
             raise LpxError(-1, f"frame id {int(ids.max())} out of range: the feeder holds {self.n_frames} frames")
         if out is None:
             pitch = max([self.info[i]["n_points"] for i in ids.tolist()] + [1])
-            # pinned arrays are written by the device itself (one launch per chain); ordinary memory (pinned=False)
-            # goes through the copy engine, one exact-size copy per frame and array
+            # pinned arrays let the copy engines write the results while the next chain computes; ordinary memory
+            # (pinned=False) works too, at the speed of a staged copy
             arr = PinnedArray if pinned else _PlainArray
             out = dict(pitch=pitch,
                        labels=arr((F, pitch), np.uint32), ground_idx=arr((F, pitch), np.uint32),

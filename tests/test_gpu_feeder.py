@@ -154,9 +154,9 @@ def test_feeder_over_several_contexts_gives_the_single_context_results(pcd_dir, 
 
 
 def test_feeder_results_in_ordinary_memory_equal_the_pinned_ones(pcd_dir):
-    """pinned result arrays are filled by the device (one push launch per chain, records pulled by one launch per chain);
-    ordinary host memory takes the copy-engine path, one exact-size copy per frame and array: same bytes, ragged
-    frame list, one and several contexts"""
+    """result arrays in ordinary (pageable) host memory -- what a caller that never heard of lpx_host_alloc passes --
+    receive the same bytes as pinned ones, and nothing is written past the exact sizes: ragged frame list, one and
+    several contexts"""
     cname = "p6i5_d025q05"
     skw, ckw = STREAM_CONFIGS[cname]
     scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
