@@ -255,3 +255,26 @@ def test_bench_under_a_launcher_does_not_spawn():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1
+
+
+def test_library_raises_hip_hardware_queues_only_when_unset():
+    """liblpx.so sets GPU_MAX_HW_QUEUES=32 when it is loaded (HIP's default of 4 makes the fifth busy stream of a process
+    wait for whole launch chains) -- and leaves a value the user chose alone.  Checked in child processes: the variable
+    is process state."""
+    # (os.environ is a snapshot of the start of the interpreter: ask the C library)
+    code = ("import ctypes; ctypes.CDLL(%r); g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; "
+            "print(g(b'GPU_MAX_HW_QUEUES').decode())" % os.path.join(ROOT, "lidar_processing_amd", "liblpx.so"))
+    base = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, "-c", code], env=base, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "32", (r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, "-c", code], env=dict(base, GPU_MAX_HW_QUEUES="8"), capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "8", (r.stdout, r.stderr[-500:])
+
+
+def test_tools_index_names_every_script():
+    """tools/README.md is the index of the development scripts: every script is named there"""
+    text = open(os.path.join(ROOT, "tools", "README.md")).read()
+    missing = [f for f in sorted(os.listdir(os.path.join(ROOT, "tools")))
+               if f.endswith((".py", ".sh")) and f not in text]
+    assert not missing, missing
