@@ -552,8 +552,9 @@ def inflight_curve(plan, lpx, seconds=0.6):
     import threading
     own = "lists" if plan.lists else "search"
     shapes = [(1, 1, "lists", False), (1, 1, "search", False), (4, 1, "lists", False), (4, 1, "search", False),
-              (1, 4, "search", False), (16, 1, "lists", False), (2, 8, "search", False), (1, 16, "search", False),
-              (8, 8, "search", False), (2, 32, "search", False), (4, 32, "search", False), (8, 32, "search", False),
+              (1, 4, "search", False), (1, 4, "lists", False), (16, 1, "lists", False), (2, 8, "search", False),
+              (2, 8, "lists", False), (1, 16, "search", False), (1, 16, "lists", False),
+              (8, 8, "search", False), (8, 8, "lists", False), (2, 32, "search", False), (2, 32, "lists", False), (4, 32, "search", False), (8, 32, "search", False),
               (20, 32, "search", False), (plan.C, plan.B, own, plan.overlap)]  # the last row: the headline's own shape
     rows = []
     F = plan.F
