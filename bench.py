@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md:36; a float4 copy measures 6.29 TB/s there)
+FRAME_BUDGET_MS = 100.0  # the reference's frame budget (10 Hz sensor, reference README.md:4): p99 completion must stay below
 PROFILE_ROUND = "r03"  # committed rocprofv3 summaries this line points at: profiles/<round>_<workload>_*
 
 WORKLOADS = {
@@ -234,6 +235,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-inflight", action="store_true", help="skip the frames-in-flight curve")
     ap.add_argument("--no-sub", action="store_true", help="skip the three-frames-cycled sub-measurement of the stream line")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the last step's outputs with tests/golden")
+    ap.add_argument("--side-legs", action="store_true",
+                    help="N > 1: also run rank 0's one-frame latency leg (by default skipped there: the other ranks would "
+                         "sit in a barrier holding their GPUs)")
     ap.add_argument("--feeder-only", action="store_true",
                     help="print only the PCIe-inclusive feeder rates of the stream (own process: side measurement of the default run)")
     ap.add_argument("--inflight-only", action="store_true",
@@ -349,22 +354,82 @@ class Plan:
         self.torch.cuda.synchronize()
 
     def timed(self, steps, warmup, barrier):
-        """W untimed steps, then exactly K steps between barrier + synchronize on both sides"""
-        for _ in range(warmup):
-            self.step()
-        self.sync()
-        barrier()
-        self.torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
-        self.sync()
-        barrier()
-        self.torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides.
+
+        A step is the F frames of this rank, and every context works through ITS chains of every step as a closed loop --
+        enqueue a chain of B frames, wait for it (with lpx_set_overlap: wait for the chain before it), next chain -- on a
+        host thread of its own: C x B frames are in flight (2 C B with overlap), never more, and the completion time of
+        every chain (enqueue -> all its results resident in HBM) is measured inside the same timed region that gives
+        `value`.  Contexts do not wait for one another between steps; the K steps are exact: K x F frames."""
+        import threading
+        C = self.C
+        mine = [[k for k in range(len(self.chains)) if k % C == i] for i in range(C)]
+        gate = threading.Barrier(C + 1)
+        lat = [[] for _ in range(C)]  # (completion seconds, frames) per chain
+        errors = []
+
+        def loop(i):
+            try:
+                self.torch.cuda.set_device(self.local_rank)
+                ctx = self.ctxs[i]
+                for phase, rounds in (("warm", warmup), ("timed", steps)):
+                    gate.wait()
+                    prev = None  # overlap: (enqueue time, frames) of the chain still in flight
+                    for _ in range(rounds):
+                        for k in mine[i]:
+                            lo, hi = self.chains[k]
+                            a = time.perf_counter()
+                            self.enqueue_frames(ctx, lo, hi)
+                            if self.overlap:
+                                ctx.wait_previous()  # chain k - 1 is complete; chain k stays in flight
+                            else:
+                                ctx.synchronize()
+                            done = (a, hi - lo)
+                            if self.overlap:
+                                done, prev = prev, done
+                            if done is not None and phase == "timed":
+                                lat[i].append((time.perf_counter() - done[0], done[1]))
+                    ctx.synchronize()
+                    if prev is not None and phase == "timed":
+                        lat[i].append((time.perf_counter() - prev[0], prev[1]))
+                    gate.wait()
+            except BaseException as e:  # a thread that dies must not leave the others at the gate
+                errors.append(e)
+                gate.abort()
+
+        th = [threading.Thread(target=loop, args=(i,)) for i in range(C)]
+        for x in th:
+            x.start()
+        try:
+            gate.wait()  # warm-up starts
+            gate.wait()  # ... and has completed on every context
+            self.sync()
+            barrier()
+            self.torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gate.wait()  # the K timed steps start
+            gate.wait()  # ... every context has synchronised after its last chain
+            self.sync()
+            barrier()
+            self.torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        except threading.BrokenBarrierError:
+            for x in th:
+                x.join()
+            raise SystemExit(f"an enqueue thread failed: {errors[:1]}")
+        for x in th:
+            x.join()
         counts = self.d_counts.cpu().numpy().view(np.uint32)
         if (counts[:, 3] != 0).any():
             raise SystemExit(f"device status != 0: {counts[:, 3].tolist()}")
+        ms = np.array([t for l in lat for (t, f) in l for _ in range(f)]) * 1e3  # one sample per frame
+        self.completion = {"frames_in_flight": C * self.B * (2 if self.overlap else 1),
+                           "p50_frame_completion_ms": round(float(np.median(ms)), 3) if ms.size else None,
+                           "p99_frame_completion_ms": round(float(np.percentile(ms, 99)), 3) if ms.size else None,
+                           "max_frame_completion_ms": round(float(ms.max()), 3) if ms.size else None,
+                           "what": "closed loop inside the timed region: every context enqueues a chain and waits for it "
+                                   "(overlap: for the chain before it); completion = enqueue of a frame's chain -> its "
+                                   "results resident in HBM"}
         return elapsed, counts
 
     def close(self):
@@ -373,6 +438,102 @@ class Plan:
         for c in self.ctxs:
             c.close()
         self.ctxs = []
+
+
+def golden_rows(name, my_ids):
+    """the committed golden row -- [n_ground, n_obstacle, n_clusters, crc32(labels as u8), crc32(obstacle_idx),
+    crc32(cluster_labels), crc32(planes)] -- of every frame of this rank's step (tests/golden: stream_golden.npz, made
+    from the reference's own kd-tree build for the cluster column; synth_golden.json for the synthetic clouds), or None
+    when the workload's configuration has no committed golden.  Data only: bench.py never calls the oracle here."""
+    from util import FRAMES, GOLDEN, STREAM_CONFIGS, stream_gold, stream_names
+    wl = WORKLOADS[name]
+    if name in ("stream", "kitti"):
+        skw, ckw = STREAM_CONFIGS["p6i5_d025q05"]
+        if skw != wl["seg"] or ckw != wl["clu"]:
+            return None
+        g = stream_gold()["p6i5_d025q05"]
+        names = stream_names()
+        index = list(range(len(names))) if name == "stream" else [names.index(f) for f in FRAMES]
+        return [[int(v) for v in g[index[fid]]] for fid in my_ids]
+    with open(os.path.join(GOLDEN, "synth_golden.json")) as f:
+        d = json.load(f).get(name)
+    if not d or d["seg"] != wl["seg"] or d["clu"] != wl["clu"]:
+        return None
+    return [[int(v) for v in d["row"]] for _ in my_ids]
+
+
+def verify_outputs(plan):
+    """Every frame of the timed region's LAST step (the outputs are still resident) against the committed goldens:
+    counts, and CRC-32 of labels / obstacle order / cluster labels / plane words.  One D2H per output array."""
+    import zlib
+    rows = golden_rows(plan.name, plan.my_ids)
+    if rows is None:
+        return {"frames": 0, "mismatches": None, "why": "no committed golden for this configuration"}
+
+    def crc(a):
+        return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+    counts = plan.d_counts.cpu().numpy().view(np.uint32)
+    got = [[int(counts[j, 0]), int(counts[j, 1]), int(counts[j, 2]), 0, 0, 0, 0] for j in range(plan.F)]
+    for col, tensor, upto, cast in ((3, plan.d_labels, lambda j: int(plan.n_points[j]), np.uint8),
+                                    (4, plan.d_oidx, lambda j: int(counts[j, 1]), None),
+                                    (5, plan.d_clabels, lambda j: int(counts[j, 1]), None),
+                                    (6, plan.d_planes, lambda j: 4 * plan.P, None)):
+        host = tensor.cpu().numpy()  # one array at a time (the step's labels alone are F x pitch x 4 bytes)
+        for j in range(plan.F):
+            a = host[j, :upto(j)]
+            got[j][col] = crc(a.view(np.uint32).astype(cast) if cast else a)
+        del host
+    bad = [j for j in range(plan.F) if counts[j, 3] != 0 or got[j] != rows[j]]
+    out = {"frames": plan.F, "mismatches": len(bad),
+           "what": "every frame of the last timed step: counts + CRC-32 of segmentation labels, obstacle order, cluster "
+                   "labels and plane words against tests/golden (cluster labels there come from the reference's own "
+                   "kd-tree build)"}
+    if bad:
+        j = bad[0]
+        out["first"] = {"frame": j, "frame_id": int(plan.my_ids[j]), "status": int(counts[j, 3]), "got": got[j], "want": rows[j]}
+    return out
+
+
+def environment_of(lpx):
+    """what in the process environment can shape the run: every LPX_* variable (read only by the development library),
+    the HIP queue count, and which library is loaded"""
+    from lidar_processing_amd import _lib
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("LPX_") or k == "GPU_MAX_HW_QUEUES"}
+    env["library"] = os.path.relpath(_lib.LIB_PATH, ROOT)
+    env["library_build"] = _lib.lib().lpx_build_info().decode()
+    return env
+
+
+def pin_to_gpu_numa_node(torch, local_rank):
+    """N > 1: the enqueue threads of a rank belong on the host cores next to its GPU (scaling risk).  Best
+    effort -- returns the node, or None when sysfs does not say."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, set(cpus) & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+        return node
+    except Exception:
+        return None
+
+
+def gather_per_rank(values, device, world):
+    """[values of rank 0, values of rank 1, ...]: what each rank measured by itself (all_gather of a few floats)"""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if world == 1:
+        return [t.tolist()]
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
 
 
 def stage_profile(plan, steps):
@@ -746,13 +907,17 @@ def main(argv=None):
         t0 = time.perf_counter()
         time.sleep(0.01 * args.steps)  # stands for the K steps
         barrier()
-        elapsed = time.perf_counter() - t0
-        elapsed, total_points, total_frames = aggregate(elapsed, points_per_step, torch.device("cpu"), world, F)
+        own_elapsed = time.perf_counter() - t0
+        elapsed, total_points, total_frames = aggregate(own_elapsed, points_per_step, torch.device("cpu"), world, F)
+        per_rank = [{"rank": r, "frames_per_s": round(v[0], 2), "ms_per_step": round(v[1], 4)}
+                    for r, v in enumerate(gather_per_rank([F * args.steps / own_elapsed, own_elapsed / args.steps * 1e3],
+                                                          torch.device("cpu"), world))]
         if rank == 0:
             print(json.dumps({"metric": "Mpts/s seg+cluster (120k-pt frame)", "value": 0.0, "unit": "Mpts/s",
                               "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
+                              "per_rank": per_rank,
                               "config": {"workload": wl["config"], "frames_per_step_per_gpu": F,
                                          "points_per_step": int(total_points), "frames_per_step": int(total_frames),
                                          "distributed_backend": backend if world > 1 else None,
@@ -793,26 +958,39 @@ def main(argv=None):
         print(json.dumps({"stream": feeder_rates(plan, host_frames, lpx)}))
         plan.close()
         return 0
+    numa_node = pin_to_gpu_numa_node(torch, local_rank) if world > 1 else None
     plan = Plan(args.workload, host_frames, args, rank, world, local_rank, torch, lpx)
-    elapsed, counts = plan.timed(args.steps, args.warmup, barrier)
-    elapsed, total_points_per_step, total_frames_per_step = aggregate(elapsed, plan.points_per_step, dev, world, plan.F)
+    own_elapsed, counts = plan.timed(args.steps, args.warmup, barrier)
+    elapsed, total_points_per_step, total_frames_per_step = aggregate(own_elapsed, plan.points_per_step, dev, world, plan.F)
+    # what every rank measured by itself (the line's value uses the MAX of the times, the SUM of the points)
+    verified = None if args.no_verify else verify_outputs(plan)
+    per_rank = [{"rank": r, "frames_per_s": round(v[0], 2), "ms_per_step": round(v[1], 4), "mpts_s": round(v[2], 3),
+                 "p99_frame_completion_ms": round(v[3], 3), "verified_mismatches": int(v[4]),
+                 "numa_node": None if v[5] < 0 else int(v[5])}
+                for r, v in enumerate(gather_per_rank(
+                    [plan.F * args.steps / own_elapsed, own_elapsed / args.steps * 1e3,
+                     plan.points_per_step * args.steps / own_elapsed / 1e6,
+                     plan.completion["p99_frame_completion_ms"] or 0.0,
+                     -1.0 if not verified or verified["mismatches"] is None else float(verified["mismatches"]),
+                     -1.0 if numa_node is None else float(numa_node)], dev, world))]
 
     roofline, latency, stream_info, inflight = None, None, None, None
     stage_ms = {}
+    side = world == 1 or args.side_legs  # N > 1: the other ranks wait in the final barrier while rank 0 measures
     if rank == 0:
         stage_ms, launches, per_launch = stage_profile(plan, args.steps)
         roofline = roofline_of(plan, counts, elapsed, args.steps, world, stage_ms, launches, per_launch)
-        if not args.no_latency:
+        if not args.no_latency and side:
             latency = latency_of(plan, host_frames, lpx)
         if feeder_child is not None:
             stream_info = dict(feeder_child)
-        elif args.workload == "stream" and not args.no_sub:
+        elif args.workload == "stream" and not args.no_sub and side:
             stream_info = feeder_rates(plan, host_frames, lpx)
         if stream_info is not None and "error" not in stream_info:
             stream_info = dict(device_resident_frames_per_s=round(plan.F * world * args.steps / elapsed, 1), **stream_info)
         if inflight_child is not None:
             inflight = inflight_child
-        elif not args.no_inflight and args.workload in ("stream", "kitti"):
+        elif not args.no_inflight and args.workload in ("stream", "kitti") and side:
             inflight = inflight_curve(plan, lpx)
     if rank == 0:
         value = total_points_per_step * args.steps / elapsed / 1e6
@@ -835,7 +1013,8 @@ def main(argv=None):
                        "frames_per_step_per_gpu": F, "frames_per_launch_chain": max(1, min(args.batch or wl["batch"], F)),
                        "contexts_per_gpu": max(1, min(args.contexts or wl["contexts"], -(-F // max(1, min(args.batch or wl["batch"], F))))),
                        "overlap": bool(args.overlap),
-                       "host_threads_per_gpu": args.threads, "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "host_threads_per_gpu": plan.C, "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "env": environment_of(lpx),
                        "points_per_step": int(total_points_per_step), "frames_per_step": int(total_frames_per_step),
                        "frames_per_s": round(total_frames_per_step * args.steps / elapsed, 2),
                        "sharding": "frame i -> GPU i mod N, no data-path collective",
@@ -844,6 +1023,10 @@ def main(argv=None):
                                                   if shared_gpus else "")) if world > 1 else None,
                        "distributed_world_size": dist.get_world_size() if world > 1 else 1},
             "vs_target": {"north_star_mpts_s": 50.0, "ratio": round(value / 50.0, 2)},
+            "verified": verified,
+            "completion": dict(plan.completion, budget_ms=FRAME_BUDGET_MS,
+                               within_budget=(plan.completion["p99_frame_completion_ms"] or 0.0) <= FRAME_BUDGET_MS),
+            "per_rank": per_rank,
             "roofline": roofline,
             "latency": latency,
             "throughput_vs_inflight": inflight,
@@ -863,6 +1046,10 @@ def main(argv=None):
         dist.destroy_process_group()
     if plan is not None:
         plan.close()
+    if verified and verified["mismatches"]:
+        sys.stderr.write(f"bench.py: {verified['mismatches']} of {verified['frames']} frames differ from tests/golden: "
+                         f"{verified.get('first')}\n")
+        return 1
     return 0
 
 

@@ -110,6 +110,13 @@ int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point);
 #define LPX_NEIGHBOURS_SEARCH 2
 int lpx_set_neighbour_mode(lpx_ctx *ctx, int mode);
 const char *lpx_last_error(const lpx_ctx *ctx);
+/* One line about the loaded library and the process it finds itself in: the build flavour -- the release library reads
+ * NO environment variable that could change what it computes or how (the LPX_* development knobs exist only in
+ * liblpx_dev.so, built with -DLPX_DEV_KNOBS) -- and GPU_MAX_HW_QUEUES as the process has it.  That HIP variable is the
+ * host program's to set, before its first HIP call: HIP multiplexes its streams onto that many hardware queues
+ * (default 4) and streams that share a queue serialise, so a process with more than four contexts, or with a feeder
+ * beside its contexts, wants 16-32.  The library never modifies the environment. */
+const char *lpx_build_info(void);
 /* blocks until everything enqueued on the context stream has finished */
 int lpx_synchronize(lpx_ctx *ctx);
 

@@ -5,7 +5,10 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LPX_LIB: development switch for A/B measurements of alternative builds of the same library (tools/build_variant.sh)
+# LPX_LIB: development switch -- another build of the same library: liblpx_dev.so (DEV_LIB_PATH: the same sources with
+# -DLPX_DEV_KNOBS, the only build that reads LPX_* environment knobs; tests that force a code path or poison the
+# workspace run their subprocesses on it) or an A/B variant of tools/build_variant.sh
+DEV_LIB_PATH = os.path.join(_HERE, "liblpx_dev.so")
 LIB_PATH = os.path.abspath(os.environ["LPX_LIB"]) if os.environ.get("LPX_LIB") else os.path.join(_HERE, "liblpx.so")
 
 
@@ -124,5 +127,7 @@ def lib():
     L.lpx_dbg_neighbours.argtypes = [vp, vp, u32, C.c_float, vp, vp, vp, C.c_uint64]
     L.lpx_dbg_components.argtypes = [vp, vp, u32, C.c_float, vp]
     L.lpx_dbg_plane.argtypes = [vp, vp, u32, vp]
+    L.lpx_build_info.argtypes = []
+    L.lpx_build_info.restype = C.c_char_p
     _lib = L
     return L

@@ -67,10 +67,10 @@ static inline size_t align256(size_t v)
 //     loss belongs to family 6, the component grid's per-point and per-cell kernels (insert with its atomics, clear,
 //     alloc, scatter, flatten) and the small label kernels, which save nothing: every OTHER family on (0xbf) gives
 //     115 MB per frame at the throughput of none (2055-2063 against 2032-2062 Mpts/s).
-// Hence family 6 only for large frames.  LPX_REMAP=<hex mask> overrides.
+// Hence family 6 only for large frames.  LPX_REMAP=<hex mask> overrides (development build only: LPX_KNOB).
 static uint32_t lpx_remap_mask(uint32_t points_per_slot)
 {
-    static const char *env = getenv("LPX_REMAP");
+    static const char *env = LPX_KNOB("LPX_REMAP");
     if (env)
         return (uint32_t)strtoul(env, nullptr, 16) & 0xffu;
     return points_per_slot >= 400000u ? 0xffu : 0xbfu;
@@ -150,6 +150,10 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             ctx->arena = nullptr;
             ctx->cap_n = 0;
         }
+        // whatever an earlier call left in the slots is gone with the old arena: every caller that grows the workspace
+        // (begin_call paths, lpx_reserve, lpx_reserve_single_pass, the switch to the search tables) passes through here
+        ctx->seg_valid = false;
+        ctx->last_n = 0;
         LPX_HIP(ctx, hipMalloc(&ctx->arena, total * ctx->batch));
         // zero once: frame states and scratch heads
         LPX_HIP(ctx, hipMemsetAsync(ctx->arena, 0, total * ctx->batch, ctx->stream));
@@ -238,10 +242,10 @@ static int ensure_for(lpx_ctx *ctx, uint32_t n)
         nb = 0xfffffff0ull;  // offsets are 32-bit
     const int rc = lpx_ensure_capacity(ctx, n, nb);
     lpx_note_enqueue(ctx);  // a new frame (or chain of frames) is being enqueued on this context
-    // LPX_POISON=<byte>: before every new frame the per-point workspace (everything a call must write before it
-    // reads) and the neighbour lists are filled with that byte -- a test that passes with 0, 0xff and 0xa5 does not
-    // depend on what an earlier frame left behind
-    static const char *poison = getenv("LPX_POISON");
+    // LPX_POISON=<byte> (development build only): before every new frame the per-point workspace (everything a call
+    // must write before it reads) and the neighbour lists are filled with that byte -- a test that passes with 0, 0xff
+    // and 0xa5 does not depend on what an earlier frame left behind
+    static const char *poison = LPX_KNOB("LPX_POISON");
     if (rc == LPX_OK && poison)
     {
         const int byte = (int)strtol(poison, nullptr, 0) & 0xff;
@@ -458,11 +462,23 @@ static int create_common(int device, hipStream_t stream, bool own, uint32_t batc
 // HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue run
 // their kernels one after the other: the fifth context of a process -- or a feeder's copy stream that lands on a
 // context's queue -- waits for whole chains (measured: the feeder moved 5.6 k frames/s on four lanes with the default
-// and 10.7 k with 32 queues).  The library therefore raises the default when it is loaded, unless the variable is set;
-// this takes effect only if the HIP runtime has not been initialised yet (it reads the variable on its first call).
-__attribute__((constructor)) static void lpx_default_hw_queues()
+// and 10.7 k with 32 queues).  That variable belongs to the PROCESS (HIP reads it once, on its first call): the host
+// program's launcher sets it (bench.py, tests/conftest.py and the tools do; INTEGRATION.md for a ROS 2 launch file).
+// The library never touches the environment; lpx_build_info() reports what it found.
+extern "C" const char *lpx_build_info(void)
 {
-    setenv("GPU_MAX_HW_QUEUES", "32", 0);
+    static char info[192];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+#ifdef LPX_DEV_KNOBS
+        const char *flavour = "development build: LPX_* environment knobs are read";
+#else
+        const char *flavour = "release build: no LPX_* environment knobs";
+#endif
+        snprintf(info, sizeof info, "liblpx gfx950, %s; GPU_MAX_HW_QUEUES=%s", flavour, q ? q : "unset (HIP default 4)");
+    });
+    return info;
 }
 
 extern "C" int lpx_create(int device, lpx_ctx **out)
@@ -529,7 +545,16 @@ extern "C" int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_
     LPX_HIP(ctx, hipSetDevice(ctx->device));
     if (neighbours_per_point)
         ctx->nb_per_point = neighbours_per_point;
-    return ensure_for(ctx, n_points);
+    int rc = ensure_for(ctx, n_points);
+    if (rc == LPX_OK && ctx->twin)  // the second slot set of an overlapped context is sized with the first
+    {
+        ctx->twin->use_lists = ctx->use_lists;
+        ctx->twin->nb_per_point = ctx->nb_per_point;
+        ctx->twin->rs_per_point = ctx->rs_per_point;
+        if ((rc = ensure_for(ctx->twin, n_points)))
+            lpx_fail(ctx, rc, "%s", ctx->twin->err);
+    }
+    return rc;
 }
 
 extern "C" int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point)
@@ -538,7 +563,14 @@ extern "C" int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point)
         return LPX_ERR_ARG;
     LPX_HIP(ctx, hipSetDevice(ctx->device));
     ctx->rs_per_point = words_per_point;
-    return lpx_ensure_capacity(ctx, ctx->cap_n, ctx->cap_nb);
+    int rc = lpx_ensure_capacity(ctx, ctx->cap_n, ctx->cap_nb);
+    if (rc == LPX_OK && ctx->twin)
+    {
+        ctx->twin->rs_per_point = words_per_point;
+        if ((rc = lpx_ensure_capacity(ctx->twin, ctx->twin->cap_n, ctx->twin->cap_nb)))
+            lpx_fail(ctx, rc, "%s", ctx->twin->err);
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,7 +580,8 @@ extern "C" int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point)
 // stream sits in it the context contributes nothing to the wide work.  With the tail on a second stream and a second
 // set of frame slots, the context's stream goes straight on to the front end of its next chain: the delay leaves the
 // cycle.  The tail streams are a small pool per device shared by all contexts (a tail stream is idle most of the
-// time; 22 contexts + 8 tail streams stay within the 32 hardware queues the bench asks for).
+// time; the pool holds 12: 10 overlapped contexts + their 10 tail streams are 20 hardware queues, inside the ~24 the
+// device serves at full speed -- a process with more contexts than that should not overlap).
 // ------------------------------------------------------------------------------------------------
 constexpr int TAIL_POOL_MAX = 64;
 static hipStream_t g_tail_pool[16][TAIL_POOL_MAX];
@@ -559,7 +592,7 @@ static std::mutex g_tail_mutex;
 static hipStream_t tail_stream_for(int device)
 {
     static const int pool = [] {
-        const char *e = getenv("LPX_TAIL_STREAMS");
+        const char *e = LPX_KNOB("LPX_TAIL_STREAMS");
         const int v = e ? atoi(e) : 12;
         return v < 1 ? 1 : (v > TAIL_POOL_MAX ? TAIL_POOL_MAX : v);
     }();
@@ -625,6 +658,17 @@ extern "C" int lpx_set_overlap(lpx_ctx *ctx, int on)
             lpx_destroy(t);
             return lpx_fail(ctx, LPX_ERR_HIP, "the overlapped tail could not get its events");
         }
+        // the second slot set starts with the capacity and settings of the first: its first call must not allocate
+        // (hipMalloc / hipFree synchronise the whole device and would stall every other context's chains)
+        t->use_lists = ctx->use_lists;
+        t->nb_per_point = ctx->nb_per_point;
+        t->rs_per_point = ctx->rs_per_point;
+        if ((rc = ensure_for(t, ctx->cap_n)))
+        {
+            lpx_fail(ctx, rc, "%s", t->err);
+            lpx_destroy(t);
+            return rc;
+        }
         ctx->twin = t;
     }
     ctx->overlap = on != 0;
@@ -632,15 +676,13 @@ extern "C" int lpx_set_overlap(lpx_ctx *ctx, int on)
     return LPX_OK;
 }
 
-// the slot set that serves the next overlapped batch call, with the primary's settings
+// the slot set that would serve the next overlapped batch call, with the primary's settings; the alternation only
+// advances (overlap_commit) once that call has passed its argument checks and begun to enqueue
 static lpx_ctx *overlap_pick(lpx_ctx *ctx)
 {
     if (!ctx->overlap || !ctx->twin)
-    {
-        ctx->last = ctx;
         return ctx;
-    }
-    lpx_ctx *t = (ctx->flip++ & 1u) ? ctx->twin : ctx;
+    lpx_ctx *t = (ctx->flip & 1u) ? ctx->twin : ctx;
     if (t != ctx)
     {
         t->use_lists = ctx->use_lists;
@@ -649,8 +691,35 @@ static lpx_ctx *overlap_pick(lpx_ctx *ctx)
         t->profiling = ctx->profiling;
         t->dbg_buf = ctx->dbg_buf;
     }
-    ctx->last = t;
     return t;
+}
+
+static void overlap_commit(lpx_ctx *primary, lpx_ctx *used)
+{
+    if (primary->overlap && primary->twin)
+        primary->flip++;
+    primary->last = used;  // statistics and coloured clouds of "the last batch call" read this slot set
+}
+
+// one batch call through the slot set whose turn it is (the primary itself without lpx_set_overlap)
+static int batch_call(lpx_ctx *ctx, uint32_t n_frames, const void *d_pts, size_t stride, const uint32_t *offs,
+                      uint32_t frame_pitch, const uint32_t *n_points, const lpx_seg_cfg *seg_cfg,
+                      const lpx_clu_cfg *clu_cfg, uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes,
+                      int32_t *d_clabels, uint32_t *d_counts)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    lpx_ctx *t = overlap_pick(ctx);
+    t->split_tail = t->tail_stream != nullptr && ctx->overlap;
+    t->enqueued = false;
+    const int rc = lpx_batch_impl(t, n_frames, d_pts, stride, offs, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels,
+                                  d_gidx, d_oidx, d_planes, d_clabels, d_counts);
+    t->split_tail = false;
+    if (t->enqueued)  // (a call that failed its checks has touched no slot set: the alternation stays where it was)
+        overlap_commit(ctx, t);
+    if (rc && t != ctx)
+        lpx_fail(ctx, rc, "%s", t->err);
+    return rc;
 }
 
 extern "C" int lpx_synchronize(lpx_ctx *ctx)
@@ -819,6 +888,8 @@ int lpx_batch_impl(lpx_ctx *ctx, uint32_t n_frames, const void *d_pts, size_t st
     LPX_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = ensure_for(ctx, n)))
         return rc;
+    ctx->enqueued = true;  // from here on the slot set holds this call's frames
+    ctx->last = ctx;       // (a primary used directly -- the feeder's lanes -- is its own "last" slot set)
     if ((rc = lpx_run_segment(ctx, d_pts, stride, n_points, seg_cfg, d_labels, d_gidx, d_oidx, d_planes)))
         return rc;
     return lpx_run_cluster(ctx, n, clu_cfg, d_clabels, d_counts, false);
@@ -830,16 +901,8 @@ extern "C" int lpx_segment_cluster_batch_device(lpx_ctx *ctx, uint32_t n_frames,
                                                 uint32_t *d_labels, uint32_t *d_gidx, uint32_t *d_oidx, float *d_planes,
                                                 int32_t *d_clabels, uint32_t *d_counts)
 {
-    if (!ctx)
-        return LPX_ERR_ARG;
-    lpx_ctx *t = overlap_pick(ctx);
-    t->split_tail = t->tail_stream != nullptr && ctx->overlap;
-    const int rc = lpx_batch_impl(t, n_frames, d_pts, stride, nullptr, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels,
-                                  d_gidx, d_oidx, d_planes, d_clabels, d_counts);
-    t->split_tail = false;
-    if (rc && t != ctx)
-        lpx_fail(ctx, rc, "%s", t->err);
-    return rc;
+    return batch_call(ctx, n_frames, d_pts, stride, nullptr, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels, d_gidx,
+                      d_oidx, d_planes, d_clabels, d_counts);
 }
 
 // the same for n_frames PointCloud2-style buffers (records of point_step bytes, x / y / z at the given offsets)
@@ -851,8 +914,8 @@ extern "C" int lpx_segment_cluster_batch_fields_device(lpx_ctx *ctx, uint32_t n_
                                                        float *d_planes, int32_t *d_clabels, uint32_t *d_counts)
 {
     const uint32_t offs[3] = {off_x, off_y, off_z};
-    return lpx_batch_impl(ctx, n_frames, d_data, point_step, offs, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels,
-                          d_gidx, d_oidx, d_planes, d_clabels, d_counts);
+    return batch_call(ctx, n_frames, d_data, point_step, offs, frame_pitch, n_points, seg_cfg, clu_cfg, d_labels, d_gidx,
+                      d_oidx, d_planes, d_clabels, d_counts);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1146,7 +1146,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     if (m_max == 0)
         return d_counts ? lpx_write_counts(ctx, d_counts) : LPX_OK;
     // diagnostics only (results are wrong when a stage is skipped): LPX_SKIP=kd,index,grid,sort,replay
-    static const char *skip_env = getenv("LPX_SKIP");
+    static const char *skip_env = LPX_KNOB("LPX_SKIP");
     const bool skip_kd = skip_env && strstr(skip_env, "kd"), skip_index = skip_env && strstr(skip_env, "index");
     const bool skip_grid = skip_env && strstr(skip_env, "grid"), skip_sort = skip_env && strstr(skip_env, "sort");
     const bool skip_replay = skip_env && strstr(skip_env, "replay");
@@ -1249,7 +1249,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // 8 per frame 1338, 16 per frame 1317; stream, 5 x 32: 8 per frame; synth1m, 4 x 4: 32-64 per frame).
         // The frame slots of the contexts of this device that enqueued a frame in the last 100 ms stand for "frames in
         // flight".  LPX_RS_GRID overrides the per-frame count.
-        static const uint32_t rg_env = getenv("LPX_RS_GRID") ? (uint32_t)atoi(getenv("LPX_RS_GRID")) : 0u;
+        static const uint32_t rg_env = LPX_KNOB("LPX_RS_GRID") ? (uint32_t)atoi(LPX_KNOB("LPX_RS_GRID")) : 0u;
         uint32_t slots = lpx_active_frame_slots(ctx->device);
         slots = slots < ctx->cur_b ? ctx->cur_b : slots;
         uint32_t rg_cap = rg_env ? rg_env : 1024u / slots;
@@ -1268,7 +1268,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // footprint is set by rgrid, not by this), capped at what LDS holds (~440k points).  When the bound exceeds
         // the cap a second launch with one byte per point in HBM serves the frames that really are that large; each
         // launch checks the frame's obstacle count on the device (a 1M-point cloud usually has < 440k obstacles).
-        static const int rs_state = getenv("LPX_RS_STATE") ? atoi(getenv("LPX_RS_STATE")) : 0;  // 1: states in HBM
+        static const int rs_state = LPX_KNOB("LPX_RS_STATE") ? atoi(LPX_KNOB("LPX_RS_STATE")) : 0;  // 1: states in HBM
         // (LPX_RS_STATE: 1 states in HBM, 2 in LDS up to its capacity.)  Default: the LDS bitmap while it is at most 64 KiB
         // (262 144 points): a larger one leaves room for one replay workgroup per CU and costs more than it saves --
         // 1M-point frames (100 KiB bitmaps): 1060 Mpts/s with the states in LDS, 1125 with one byte per point in HBM;
@@ -1281,7 +1281,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // bitmaps hold of every CU's LDS is what the LDS-staged kernels of the other chains (kd subtrees, chunk tables,
         // seed selection) cannot get.  So the bitmap is sized by the largest obstacle count the context's previous call
         // saw (+25 %); a frame that exceeds it is served by the second launch.
-        static const int rs_fit = getenv("LPX_RS_FIT") ? atoi(getenv("LPX_RS_FIT")) : 0;  // (measured: no gain, and a second launch per chain)
+        static const int rs_fit = LPX_KNOB("LPX_RS_FIT") ? atoi(LPX_KNOB("LPX_RS_FIT")) : 0;  // (measured: no gain, and a second launch per chain)
         if (rs_fit && ctx->cur_b > 1 && ctx->h_search && m_lds)
         {
             const uint32_t seen = (uint32_t)(ctx->h_search[5] & 0xffffffffull);
@@ -1305,8 +1305,8 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     {
         StageTimer tm(ctx, ST_REPLAY);
         const size_t lds = sizeof(uint32_t) * (((((size_t)m_max + 15) / 16 + 3) & ~(size_t)3) + RP_RING);
-        static const int rp_grid = getenv("LPX_RP_GRID") ? atoi(getenv("LPX_RP_GRID")) : 2048;
-        static const int rp_state = getenv("LPX_RP_STATE") ? atoi(getenv("LPX_RP_STATE")) : 0;  // 1: states in HBM (tests)
+        static const int rp_grid = LPX_KNOB("LPX_RP_GRID") ? atoi(LPX_KNOB("LPX_RP_GRID")) : 2048;
+        static const int rp_state = LPX_KNOB("LPX_RP_STATE") ? atoi(LPX_KNOB("LPX_RP_STATE")) : 0;  // 1: states in HBM (tests)
 #define RP_ARGS                                                                                                       \
     frame, cc_lo, cc_hi, members, (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,                   \
         (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->OX.p, (const float *)ctx->OY.p,                          \

@@ -426,6 +426,8 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
 
     // exact-size D2H of the results of the lane's j-th chain once it has computed (the host waits for it while the
     // lane's next chain runs)
+    int flagged_rc = LPX_OK;  // first frame of this lane that came back with a device status
+    char flagged_msg[96] = {0};
     auto drain = [&](uint32_t j) -> int {
         const int s = (int)(j & 1u);
         const uint32_t k = first + j * stride;
@@ -455,14 +457,15 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
                                    hipMemcpyDeviceToHost, l->d2h));
         FHIP(l, hipEventRecord(l->ev_d2h[s], l->d2h));
         // a frame the device flagged (non-finite coordinates; neighbour lists that did not fit a LISTS-mode context)
-        // has no valid labels: the run reports the first such frame instead of LPX_OK (counts[] keeps every status)
-        for (uint32_t b = 0; b < nb; ++b)
+        // has no valid labels: the run reports the FIRST such frame of the lane instead of LPX_OK -- after every chain
+        // of the lane has been processed and drained, so that counts[] really holds every frame's status and no copy
+        // is left in flight
+        for (uint32_t b = 0; b < nb && flagged_rc == LPX_OK; ++b)
             if (hc[4 * b + 3] != 0u)
             {
-                char msg[96];
-                snprintf(msg, sizeof msg, "frame %u of the run (file %u): device status %d", lo + b, a.frame_ids[lo + b],
-                         -(int)hc[4 * b + 3]);
-                return ffail(l, -(int)hc[4 * b + 3], "%s", msg);
+                flagged_rc = -(int)hc[4 * b + 3];
+                snprintf(flagged_msg, sizeof flagged_msg, "frame %u of the run (file %u): device status %d", lo + b,
+                         a.frame_ids[lo + b], flagged_rc);
             }
         return LPX_OK;
     };
@@ -501,7 +504,7 @@ int lane_run(FeederLane *l, lpx_ctx *ctx, const RunArgs &a, uint32_t first, uint
         return rc;
     for (int s = 0; s < 2 && (uint32_t)s < j; ++s)  // the lane's own last copies (the stream is shared)
         FHIP(l, hipEventSynchronize(l->ev_d2h[s]));
-    return LPX_OK;
+    return flagged_rc ? ffail(l, flagged_rc, "%s", flagged_msg) : LPX_OK;
 }
 }  // namespace
 
@@ -566,7 +569,7 @@ extern "C" int lpx_feeder_run_multi(lpx_feeder *f, lpx_ctx *const *ctxs, uint32_
     const uint32_t lanes = n_ctx < a.n_chains ? n_ctx : a.n_chains;
     while (f->lanes.size() < lanes)
         f->lanes.push_back(new FeederLane());
-    static const int pool_env = getenv("LPX_FEEDER_COPY_STREAMS") ? atoi(getenv("LPX_FEEDER_COPY_STREAMS")) : 2;
+    static const int pool_env = LPX_KNOB("LPX_FEEDER_COPY_STREAMS") ? atoi(LPX_KNOB("LPX_FEEDER_COPY_STREAMS")) : 2;
     const size_t pool = (size_t)(pool_env < 1 ? 1 : (pool_env > 16 ? 16 : pool_env));
     while (f->h2d_pool.size() < pool)
     {

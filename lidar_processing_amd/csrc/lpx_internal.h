@@ -145,6 +145,7 @@ struct lpx_ctx
     hipStream_t tail_stream = nullptr;  // where this slot set's tail runs (from the device's pool)
     hipEvent_t ev_front = nullptr, ev_tail = nullptr;
     bool split_tail = false;       // the call being enqueued hands its tail to tail_stream
+    bool enqueued = false;         // the batch call in progress got past its checks and uses this slot set
     bool tail_pending = false;     // a tail was enqueued since the stream last waited for ev_tail
     char err[512] = {0};
 
@@ -247,6 +248,15 @@ static inline FV lpx_fv(const lpx_ctx *ctx)
 int lpx_fail(lpx_ctx *ctx, int code, const char *fmt, ...);
 int lpx_ensure(lpx_ctx *ctx, Buf &b, size_t bytes);
 int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb);
+
+// Environment knobs (LPX_SKIP, LPX_POISON, LPX_REMAP, LPX_RS_*, LPX_KD_*, ...) exist only in the DEVELOPMENT build
+// (make dev -> liblpx_dev.so, -DLPX_DEV_KNOBS: what tools/ and a few tests select with LPX_LIB).  The release library
+// reads no LPX_* variable at all: nothing in a host's environment can change what it computes or how.
+#ifdef LPX_DEV_KNOBS
+#define LPX_KNOB(name) getenv(name)
+#else
+#define LPX_KNOB(name) ((const char *)nullptr)
+#endif
 
 #define LPX_HIP(ctx, call)                                                                                          \
     do                                                                                                              \

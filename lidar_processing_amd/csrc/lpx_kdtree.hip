@@ -2796,7 +2796,7 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
         const bool stage = ctx->cur_b == 1 || size <= 4u * (uint32_t)blk_cap;
         const KdTopState *top = nullptr;
         // LPX_KD_TOP_MIN overrides the size from which a level takes the multi-workgroup rounds (tests)
-        static const uint32_t top_min = getenv("LPX_KD_TOP_MIN") ? (uint32_t)atoi(getenv("LPX_KD_TOP_MIN")) : TOP_MIN;
+        static const uint32_t top_min = LPX_KNOB("LPX_KD_TOP_MIN") ? (uint32_t)atoi(LPX_KNOB("LPX_KD_TOP_MIN")) : TOP_MIN;
         if (size > top_min && size > (uint32_t)TOP_HAND && (sizeof(KdTopState) << level) <= ctx->kd_state.bytes)
         {
             // large ranges: the first rounds of every nth_element of this level on many workgroups
@@ -2808,8 +2808,8 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
             {
                 // the active range shrinks by ~0.6 per round; kd_block_kernel finishes whatever is left (from any state:
                 // LPX_KD_HAND / LPX_KD_EXTRA only move work between the four-launch rounds and its single workgroup)
-                static const int hand_env = getenv("LPX_KD_HAND") ? atoi(getenv("LPX_KD_HAND")) : TOP_HAND;
-                static const int extra_env = getenv("LPX_KD_EXTRA") ? atoi(getenv("LPX_KD_EXTRA")) : TOP_EXTRA;
+                static const int hand_env = LPX_KNOB("LPX_KD_HAND") ? atoi(LPX_KNOB("LPX_KD_HAND")) : TOP_HAND;
+                static const int extra_env = LPX_KNOB("LPX_KD_EXTRA") ? atoi(LPX_KNOB("LPX_KD_EXTRA")) : TOP_EXTRA;
                 const int hand = hand_env;
                 int rounds = extra_env;
                 for (uint32_t sz = size; sz > (uint32_t)hand; sz = sz * 3 / 5)
@@ -2837,15 +2837,15 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
         // range whatever its size, each a chain of dependent global round trips (~6 us); once the active range is down
         // to BLK_TAIL nodes the remaining ~10 rounds run from 24 KiB of LDS.  (Staging the full blk_cap there makes
         // these workgroups wait for a CU with 48 KiB free while other chains fill the device.)
-        static const int tail_env = getenv("LPX_KD_TAIL") ? atoi(getenv("LPX_KD_TAIL")) : BLK_TAIL;
+        static const int tail_env = LPX_KNOB("LPX_KD_TAIL") ? atoi(LPX_KNOB("LPX_KD_TAIL")) : BLK_TAIL;
         const int stage_cap = stage ? blk_cap : (tail_env < blk_cap ? tail_env : blk_cap);
         const size_t stage_lds = sizeof(Node) * stage_cap + 2 * sizeof(uint32_t) * stage_cap + 64 * sizeof(uint32_t);
         // Workgroup size by range length.  An introselect round is a chain of dependent steps whatever the range holds
         // (~100 us per level from 47k nodes down to 3k), so below BLK_WIDE nodes sixteen wavefronts only wait for one
         // another: with many chains in flight what a kernel costs the device is its resident wavefronts x their
         // lifetime, and four wavefronts per range instead of sixteen give the other chains three quarters of it back.
-        static const uint32_t wide_env = getenv("LPX_KD_WIDE") ? (uint32_t)atoi(getenv("LPX_KD_WIDE")) : BLK_WIDE;
-        static const uint32_t mid_env = getenv("LPX_KD_MID") ? (uint32_t)atoi(getenv("LPX_KD_MID")) : BLK_MID;
+        static const uint32_t wide_env = LPX_KNOB("LPX_KD_WIDE") ? (uint32_t)atoi(LPX_KNOB("LPX_KD_WIDE")) : BLK_WIDE;
+        static const uint32_t mid_env = LPX_KNOB("LPX_KD_MID") ? (uint32_t)atoi(LPX_KNOB("LPX_KD_MID")) : BLK_MID;
         // (a single frame keeps sixteen wavefronts on every level: four per range cost it 0.58 -> 0.66 ms)
         if (size > wide_env || ctx->cur_b == 1)
             hipLaunchKernelGGL(kd_block_kernel<1024>, dim3(1u << level, 1, ctx->cur_b), dim3(1024), stage_lds + key_lds,
@@ -2925,7 +2925,7 @@ int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
     // hit (dense surfaces: BASELINE's synthetic box clouds test 200 candidates per neighbour with 64-node groups and
     // run 36 % faster with 32; KITTI frames test 12 and lose 4 %).  Hysteresis between 20 and 40 candidates per hit.
     // The choice changes the work, never a result.  LPX_IX_BUCKET fixes it.
-    static const uint32_t env_bucket = getenv("LPX_IX_BUCKET") ? (uint32_t)atoi(getenv("LPX_IX_BUCKET")) : 0u;
+    static const uint32_t env_bucket = LPX_KNOB("LPX_IX_BUCKET") ? (uint32_t)atoi(LPX_KNOB("LPX_IX_BUCKET")) : 0u;
     uint32_t bucket = ctx->ix_bucket;
     if (env_bucket >= 32 && env_bucket <= 64)
         bucket = env_bucket;
@@ -2948,7 +2948,7 @@ int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
     const uint32_t groups = (2u << dmax) - 1;
     if (sizeof(ChunkRec) * LPX_GROUP_CHUNKS * (size_t)groups > ctx->chunks.bytes)
         return lpx_fail(ctx, LPX_ERR_INTERNAL, "chunk table of %u groups does not fit the workspace", groups);
-    static const uint32_t ix_spine = getenv("LPX_IX_SPINE") ? (uint32_t)atoi(getenv("LPX_IX_SPINE")) : 2u;
+    static const uint32_t ix_spine = LPX_KNOB("LPX_IX_SPINE") ? (uint32_t)atoi(LPX_KNOB("LPX_IX_SPINE")) : 2u;
     hipLaunchKernelGGL(nb_index_kernel, dim3((groups + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b), dim3(NB_THREADS), 0,
                        ctx->stream, (const Node *)ctx->nodes_pre.p, (const FrameState *)ctx->frame.p, rr,
                        (ChunkRec *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, ix_spine, bucket, lpx_fv(ctx));
@@ -2988,20 +2988,20 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     // far pass) 1589 Mpts/s, 128 / 512 1686, 32 / 128 1723, 16 / 64 1723, while the kernels alone take 336 + 313,
     // 295 + 234 (64 / 256) and 484 + 255 us (16 / 64).  A single frame keeps the wide launch.
     {
-        static const uint32_t g0_env = getenv("LPX_GP_G0") ? (uint32_t)atoi(getenv("LPX_GP_G0")) : 32u;
-        static const uint32_t g1_env = getenv("LPX_GP_G1") ? (uint32_t)atoi(getenv("LPX_GP_G1")) : 128u;
+        static const uint32_t g0_env = LPX_KNOB("LPX_GP_G0") ? (uint32_t)atoi(LPX_KNOB("LPX_GP_G0")) : 32u;
+        static const uint32_t g1_env = LPX_KNOB("LPX_GP_G1") ? (uint32_t)atoi(LPX_KNOB("LPX_GP_G1")) : 128u;
         // (per 128k points of the largest frame: a 1M-point frame gets eight times the workgroups of a KITTI frame)
-        static const uint32_t gs_env = getenv("LPX_GP_SCALE") ? (uint32_t)atoi(getenv("LPX_GP_SCALE")) : 1u;
+        static const uint32_t gs_env = LPX_KNOB("LPX_GP_SCALE") ? (uint32_t)atoi(LPX_KNOB("LPX_GP_SCALE")) : 1u;
         const uint32_t scale = gs_env ? (m_max + 131071u) / 131072u : 1u;
-        const uint32_t w0 = ctx->cur_b > 1 || getenv("LPX_GP_G0") ? g0_env * scale : 512u;
-        const uint32_t w1 = ctx->cur_b > 1 || getenv("LPX_GP_G1") ? g1_env * scale : 2048u;
+        const uint32_t w0 = ctx->cur_b > 1 || LPX_KNOB("LPX_GP_G0") ? g0_env * scale : 512u;
+        const uint32_t w1 = ctx->cur_b > 1 || LPX_KNOB("LPX_GP_G1") ? g1_env * scale : 2048u;
         const uint32_t pg0 = (m_max * 13u + 255u) / 256u < w0 ? (m_max * 13u + 255u) / 256u : w0;
         const uint32_t pg1 = (m_max * 13u + 255u) / 256u < w1 ? (m_max * 13u + 255u) / 256u : w1;
 #define GP_ARGS                                                                                                        \
     (const FrameState *)frame, (const unsigned long long *)tkey, tparent, (const uint32_t *)thead,                    \
         (const uint32_t *)tstart, (const uint32_t *)cells, (const float4 *)cpts, (const float4 *)ctx->cell_xyz.p, r2,  \
         ctx->cell_cap, gp_dbg, ctx->fs_tag
-        static const int gp_dbg = getenv("LPX_GP_DBG") ? atoi(getenv("LPX_GP_DBG")) : 0;  // timing experiments only
+        static const int gp_dbg = LPX_KNOB("LPX_GP_DBG") ? atoi(LPX_KNOB("LPX_GP_DBG")) : 0;  // timing experiments only
         hipLaunchKernelGGL(grid_pairs_kernel<false>, dim3(pg0, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
         hipLaunchKernelGGL(grid_compress_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, (const uint32_t *)cells,
                            tparent, ctx->fs_tag);

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the launcher's job, not the library's (liblpx never touches the environment): HIP multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable on its first call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -15,6 +15,8 @@ from test_gpu_pipeline import check_against_oracle  # noqa: E402
 from util import FRAMES, load_frame, synthetic_scene  # noqa: E402
 
 assert os.environ.get("LPX_RP_STATE") == "1" and os.environ.get("LPX_RS_STATE") == "1"
+from lidar_processing_amd import _lib as _l  # noqa: E402
+assert b"development build" in _l.lib().lpx_build_info(), "the knobs are read by liblpx_dev.so only (LPX_LIB)"
 skw = dict(number_of_planar_partitions=6, number_of_iterations=5)
 checked = 0
 for mode in ("lists", "search"):

@@ -220,14 +220,15 @@ def test_device_entry_point_matches_host_entry_point(ctx):
 
 @pytest.mark.parametrize("byte", ["0xa5", "0xff"])
 def test_results_do_not_depend_on_what_an_earlier_frame_left_in_the_workspace(byte):
-    """LPX_POISON fills the per-point workspace and the neighbour lists before every new frame (read once per
+    """LPX_POISON (development build, liblpx_dev.so) fills the per-point workspace and the neighbour lists before every new frame (read once per
     process, hence the subprocess): the batch tests above and the capacity-retry tests must pass unchanged, and
     a frame whose lists overflow must not chase the poison (it used to fault before the retry could run)"""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, LPX_POISON=byte)
+    from lidar_processing_amd import _lib
+    env = dict(os.environ, LPX_POISON=byte, LPX_LIB=_lib.DEV_LIB_PATH)  # the knob exists in the development build only
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(here, "test_gpu_batch.py"), os.path.join(here, "test_gpu_pipeline.py"),
                         "-k", "not earlier_frame and (test_batch or workspace_grows or workspace_retry or real_frames "
@@ -386,7 +387,8 @@ def test_xcd_affine_launch_geometry_is_a_bijection(mask):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, LPX_REMAP=mask, PYTHONPATH=os.pathsep.join([os.path.dirname(here), here,
+    from lidar_processing_amd import _lib
+    env = dict(os.environ, LPX_REMAP=mask, LPX_LIB=_lib.DEV_LIB_PATH, PYTHONPATH=os.pathsep.join([os.path.dirname(here), here,
                                                                        os.environ.get("PYTHONPATH", "")]))
     r = subprocess.run([sys.executable, os.path.join(here, "remap_check.py")], env=env, capture_output=True, text=True,
                        timeout=900)

@@ -183,3 +183,46 @@ def test_feeder_results_in_ordinary_memory_equal_the_pinned_ones(pcd_dir):
         for c in ctxs:
             c.close()
         feeder.close()
+
+
+@pytest.mark.parametrize("n_ctx", [1, 2])
+def test_feeder_reports_a_flagged_frame_after_finishing_every_other_frame(pcd_dir, tmp_path, n_ctx):
+    """one file with a NaN coordinate in the middle of a run: the run returns LPX_ERR_RANGE naming that frame, but only
+    after every chain of every lane has been processed and drained -- counts[] holds every frame's status (the header's
+    promise) and every other frame's results equal an undisturbed run's"""
+    cname = "p6i5_d025q05"
+    skw, ckw = STREAM_CONFIGS[cname]
+    scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
+    names = stream_names()[:12]
+    bad = load_stream_frame(names[5]).copy()
+    bad[1000, 1] = np.nan
+    bad_path = tmp_path / "bad.pcd"
+    write_pcd(bad_path, bad)
+    paths = [pcd_dir / f"{n}.pcd" for n in names]
+    good = Feeder(paths)
+    poisoned = Feeder(paths[:5] + [bad_path] + paths[6:])
+    ctxs = [Context(0, batch=2) for _ in range(n_ctx)]
+    try:
+        ids = np.arange(12)  # six chains of two; the flagged frame sits in the third
+        who = ctxs[0] if n_ctx == 1 else ctxs
+        want = good.run(who, ids, scfg, ccfg)
+        out = good.run(who, ids, scfg, ccfg)  # (arrays of the right shape, refilled below)
+        for k in ("labels", "ground_idx", "obstacle_idx", "cluster_labels", "planes", "counts"):
+            out[k].array[...] = 0
+        with pytest.raises(LpxError) as e:
+            poisoned.run(who, ids, scfg, ccfg, out)
+        assert e.value.code == -2 and "frame 5 " in str(e.value), str(e.value)  # LPX_ERR_RANGE
+        status = out["counts"].array[:, 3]
+        assert status[5] == 2 and not status[np.arange(12) != 5].any(), status.tolist()
+        for j in range(12):
+            if j == 5:
+                continue
+            assert np.array_equal(out["counts"].array[j], want["counts"].array[j]), j
+            n, no = good.info[j]["n_points"], int(want["counts"].array[j, 1])
+            assert np.array_equal(out["labels"].array[j, :n], want["labels"].array[j, :n]), j
+            assert np.array_equal(out["cluster_labels"].array[j, :no], want["cluster_labels"].array[j, :no]), j
+    finally:
+        for c in ctxs:
+            c.close()
+        good.close()
+        poisoned.close()

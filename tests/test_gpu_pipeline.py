@@ -577,7 +577,8 @@ def test_point_states_in_hbm_give_the_same_labels():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, LPX_RP_STATE="1", LPX_RS_STATE="1",
+    from lidar_processing_amd import _lib
+    env = dict(os.environ, LPX_RP_STATE="1", LPX_RS_STATE="1", LPX_LIB=_lib.DEV_LIB_PATH,  # knobs: development build only
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get("PYTHONPATH", "")]))
     r = subprocess.run([sys.executable, os.path.join(here, "state_check.py")], env=env, capture_output=True, text=True,
                        timeout=900)

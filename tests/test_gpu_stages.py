@@ -99,7 +99,8 @@ def test_kd_layout_multi_workgroup_rounds_forced_on_small_levels():
         "    assert np.array_equal(c.dbg_kd_layout(xyz), oracle.kd_layout(xyz)), (kind, m)\n"
         "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                             os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LPX_KD_TOP_MIN="5000")
+    from lidar_processing_amd import _lib
+    env = dict(os.environ, LPX_KD_TOP_MIN="5000", LPX_LIB=_lib.DEV_LIB_PATH)  # the knob exists in the development build only
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 

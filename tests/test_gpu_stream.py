@@ -101,8 +101,9 @@ def test_stream_154_frames_match_reference_goldens(stream, cname):
     assert not bad, bad[:3]
 
 
-@pytest.mark.parametrize("shape", [(256, 32, 8, 2, False), (640, 64, 10, 4, False), (512, 64, 4, 2, True)],
-                         ids=["8x32", "10x64", "4x64-overlap"])
+@pytest.mark.parametrize("shape", [(256, 32, 8, 2, False), (640, 64, 10, 4, False), (512, 64, 4, 2, True),
+                                   (1280, 64, 20, 4, False)],
+                         ids=["8x32", "10x64", "4x64-overlap", "20x64"])
 def test_bench_shape_contexts_slots_threads(stream, shape):
     """the configurations bench.py times -- round 2's 32-frame chains on 8 contexts, round 3's 64-frame chains on many
     contexts, and lpx_set_overlap (two slot sets per context, the tail of a chain beside the next chain) -- several host
@@ -159,3 +160,24 @@ def test_bench_shape_contexts_slots_threads(stream, shape):
             assert res["n_clusters"] == want["n_clusters"]
     finally:
         one.close()
+
+
+def test_bench_line_verifies_its_own_timed_region():
+    """bench.py compares every frame of its timed region's last step (the headline shape: closed loops on every context)
+    with the committed goldens and says so in the line; a mismatch makes it exit 1.  Also: the line echoes the
+    environment it ran in and the library it loaded (the release build: no LPX_* knobs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LPX_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-latency", "--no-inflight", "--no-sub"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    v = line["verified"]
+    assert v["frames"] == line["config"]["frames_per_step_per_gpu"] and v["mismatches"] == 0, v
+    assert line["completion"]["p99_frame_completion_ms"] > 0 and line["completion"]["frames_in_flight"] > 0
+    assert "release build" in line["config"]["env"]["library_build"], line["config"]["env"]
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["verified_mismatches"] == 0

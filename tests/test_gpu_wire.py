@@ -101,6 +101,29 @@ def test_coloured_clouds_edge_cases(ctx):
     assert np.array_equal(o, oracle.coloured_records(flat, oi, False))
 
 
+def test_coloured_clouds_refuse_a_workspace_that_was_reallocated():
+    """lpx_reserve (like every growth of the workspace) frees the arena the segmented cloud lived in: the records of the
+    earlier lpx_segment are gone, and lpx_coloured_clouds must say so instead of colouring the zeroed new arena"""
+    from lidar_processing_amd import LpxError
+    pts = load_frame(FRAMES[0])[:20_000]
+    c = Context(0)
+    try:
+        c.reserve(20_000)
+        _, gi, oi, _ = c.segment(pts, SegmentationConfiguration(**SEG))
+        g, o = c.coloured_clouds(len(gi), len(oi))  # fine: the cloud is resident
+        assert np.array_equal(g, oracle.coloured_records(pts, gi, True))
+        c.reserve(60_000)  # reallocates
+        with pytest.raises(LpxError) as e:
+            c.coloured_clouds(len(gi), len(oi))
+        assert e.value.code == -1  # LPX_ERR_ARG
+        _, gi, oi, _ = c.segment(pts, SegmentationConfiguration(**SEG))
+        c.reserve(30_000)  # no growth: nothing moves, the cloud stays valid
+        g, o = c.coloured_clouds(len(gi), len(oi))
+        assert np.array_equal(o, oracle.coloured_records(pts, oi, False))
+    finally:
+        c.close()
+
+
 def test_coloured_clouds_batch_device(ctx):
     import torch
     dev = torch.device("cuda:0")

@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/build_variant.sh NAME [extra hipcc flags...] -- builds lidar_processing_amd/ab/liblpx_NAME.so with extra
 # compile flags (objects under /tmp), for A/B runs on the GPU box: LPX_LIB=lidar_processing_amd/ab/liblpx_NAME.so.
-# Development only: the product library is lidar_processing_amd/liblpx.so.
+# Development only (built with -DLPX_DEV_KNOBS like liblpx_dev.so: the LPX_* environment knobs are read): the product
+# library is lidar_processing_amd/liblpx.so.
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -11,7 +12,7 @@ cd "$root/lidar_processing_amd/csrc"
 pids=()
 for f in lpx_primitives lpx_segment lpx_kdtree lpx_cluster lpx_api lpx_feeder; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I../../include -I. \
-    -Wno-unused-value -Wno-unused-result "$@" -c $f.hip -o "$obj/$f.o" &
+    -Wno-unused-value -Wno-unused-result -DLPX_DEV_KNOBS "$@" -c $f.hip -o "$obj/$f.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
