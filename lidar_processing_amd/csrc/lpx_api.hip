@@ -102,7 +102,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         size_t hist_bytes = 64 + 256 * sizeof(uint32_t) * sort_blocks + 64;
         if (hist_bytes < (1u << 16))
             hist_bytes = 1u << 16;
-        const size_t blk_bytes = sizeof(uint32_t) * (2 * ((size_t)n / 4096 + LPX_MAX_PARTITIONS + 2) + 2);
+        const size_t blk_bytes = sizeof(uint32_t) * (2 * LPX_SEG_MAX_BLOCKS(n) + 2);
         // expansion-driven search: at most n / 16 + 2 kd groups (2^(D+1) with n >> D <= 64), a cell table of the
         // next power of two >= 2 n slots
         const size_t chunk_bytes = sizeof(ChunkRec) * LPX_GROUP_CHUNKS * ((size_t)n / 8 + 64);  // groups of >= 32 nodes: fewer than n / 8
@@ -116,9 +116,9 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         };
         const Item items[] = {
             {&ctx->frame, sizeof(FrameState)},
-            {&ctx->seg_state, sizeof(SegState) * LPX_MAX_PARTITIONS},
-            {&ctx->seg_acc, (sizeof(long long) * LPX_ACC_WORDS + 2 * sizeof(uint32_t)) * LPX_MAX_PARTITIONS},
-            {&ctx->seg_far, sizeof(long long) * LPX_FAR_WORDS * LPX_MAX_PARTITIONS},
+            {&ctx->seg_state, 2 * sizeof(SegState) * LPX_MAX_PARTITIONS},
+            {&ctx->seg_part, 2 * sizeof(long long) * LPX_ACC_WORDS * LPX_SEG_MAX_BLOCKS(n)},
+            {&ctx->seg_far, 3 * sizeof(long long) * LPX_FAR_WORDS * LPX_MAX_PARTITIONS},
             {&ctx->d_planes, sizeof(float) * 4 * LPX_MAX_PARTITIONS},
             {&ctx->d_counts, 64},
             {&ctx->hist, hist_bytes},

@@ -79,6 +79,9 @@ static inline uint64_t lpx_entries_written(const FrameState &f)
 }
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
+// blocks of a plane pass (and rows of seg_part / blk_counts) a cloud of n points can need at most: a segment's blocks
+// start on a multiple of four points (16-byte loads), which can add one block per segment
+#define LPX_SEG_MAX_BLOCKS(n) ((size_t)(n) / 4096 + 2 * LPX_MAX_PARTITIONS + 2)
 #define LPX_FAR_WORDS 24  // moments of the points beyond +-2048 m: n, sx, sy, sz, 6 x (hh, hl, ll) limbs, 2 spare
 
 struct SegState  // per segment
@@ -177,9 +180,9 @@ struct lpx_ctx
     Buf XS, YS, ZS;            // x-sorted SoA
     Buf flags;                 // u8 per sorted position
     Buf hist;                  // radix histograms / scan scratch
-    Buf seg_state;             // SegState[LPX_MAX_PARTITIONS]
-    Buf seg_acc;               // int64 [LPX_MAX_PARTITIONS][LPX_ACC_WORDS] + tickets
-    Buf seg_far;               // int64 [LPX_MAX_PARTITIONS][LPX_FAR_WORDS], zero between passes
+    Buf seg_state;             // SegState[2][LPX_MAX_PARTITIONS]: the state pass t works with lives in set t & 1
+    Buf seg_part;              // int64 [2][blocks of a pass][LPX_ACC_WORDS]: the moment partials pass t leaves for pass t + 1
+    Buf seg_far;               // int64 [3][LPX_MAX_PARTITIONS][LPX_FAR_WORDS]: far-point moments of pass t in set t % 3
     Buf blk_counts;            // per block ground / obstacle counts
     Buf d_labels, d_gidx, d_oidx, d_planes, d_counts;  // outputs for host API
     // ---- clustering buffers ----

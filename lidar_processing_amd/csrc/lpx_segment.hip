@@ -40,6 +40,7 @@ struct SegParams
     float seed_thr;    // initial_seed_threshold
     float odt;         // orthogonal_distance_threshold
     uint32_t n_lpr;
+    uint32_t part_stride;  // int64 words between the two sets of moment partials (seg_part)
 };
 
 // per-frame sizes: the launch geometry (bps) comes from the largest frame of the call, the ranges
@@ -194,9 +195,17 @@ __global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float4 *_
 // ------------------------------------------------------------------------------------------------
 constexpr int SEED_LDS = 4096;
 
+// The three sets of far-point accumulators of segment s start a frame at zero (pass t adds into set t % 3, the head
+// of pass t + 1 reads it and clears set (t + 2) % 3: plane_pass_kernel).  Called by the first 3 * LPX_FAR_WORDS threads
+// of the seed kernels, the launch before pass 0.
+__device__ __forceinline__ void seg_far_reset(long long *facc, uint32_t s, uint32_t tid)
+{
+    if (tid < 3u * LPX_FAR_WORDS)
+        facc[((size_t)(tid / LPX_FAR_WORDS) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + tid % LPX_FAR_WORDS] = 0;
+}
+
 __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__restrict__ zsorted, SegParams prm,
-                                                            SegState *__restrict__ st, long long *__restrict__ acc,
-                                                            uint32_t *__restrict__ ticket,
+                                                            SegState *__restrict__ st, long long *__restrict__ facc,
                                                             const FrameState *__restrict__ frame, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<2>(fs);
@@ -205,18 +214,14 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
     __shared__ uint32_t s_cut;
     zsorted = lpx_slot(zsorted, fs);
     st = lpx_slot(st, fs);
-    acc = lpx_slot(acc, fs);
-    ticket = lpx_slot(ticket, fs);
+    facc = lpx_slot(facc, fs);
     seg_bind(prm, lpx_slot(frame, fs));
     const uint32_t s = lpx_blk.x;
     const uint32_t ns = prm.n_per;
     const uint64_t *zs = zsorted + (size_t)s * ns;
     const uint32_t tid = threadIdx.x;
 
-    if (tid < LPX_ACC_WORDS)
-        acc[s * LPX_ACC_WORDS + tid] = 0;
-    if (tid == 0)
-        ticket[s] = 0;
+    seg_far_reset(facc, s, tid);
 
     // first index with z > z_floor (sorted ascending): upper bound
     if (tid == 0)
@@ -338,8 +343,7 @@ __device__ __forceinline__ uint32_t sel_block_sum(uint32_t v, uint32_t *red, uin
 
 __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *__restrict__ ZS, SegParams prm,
                                                                    SegState *__restrict__ st,
-                                                                   long long *__restrict__ acc,
-                                                                   uint32_t *__restrict__ ticket,
+                                                                   long long *__restrict__ facc,
                                                                    const FrameState *__restrict__ frame, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<2>(fs);
@@ -352,16 +356,12 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
     __shared__ float s_zmax;
     ZS = lpx_slot(ZS, fs);
     st = lpx_slot(st, fs);
-    acc = lpx_slot(acc, fs);
-    ticket = lpx_slot(ticket, fs);
+    facc = lpx_slot(facc, fs);
     seg_bind(prm, lpx_slot(frame, fs));
     const uint32_t s = lpx_blk.x, tid = threadIdx.x;
     const uint32_t ns = prm.n_per;
     const uint32_t base = s * ns;
-    if (tid < LPX_ACC_WORDS)
-        acc[s * LPX_ACC_WORDS + tid] = 0;
-    if (tid == 0)
-        ticket[s] = 0;
+    seg_far_reset(facc, s, tid);
 
     uint32_t key[SEL_PTS];
     uint32_t vmask = 0;  // bit u: slot u holds a point of the segment
@@ -855,30 +855,51 @@ __device__ bool plane_from_moments(const long long *m, const long long *far, flo
 // K2+K3 fused pass.  Pass t tests every point of the segment against predicate t
 //   t == 0 : seed predicate (z window)                         (:243, :199-216)
 //   t >= 1 : signed distance to plane t-1 < thr * |normal|     (:287-307, Q1)
-// and, unless FINAL, accumulates the moments of the members for plane t (:261-273).  The last
-// block of a segment to finish solves the 3x3 problem and publishes plane t for the next launch.
-// FINAL writes the per-point flag and per-block ground/obstacle counts for the compaction.
+// and, unless FINAL, accumulates the moments of the members for plane t (:261-273).
+//
+// No cross-block traffic inside a launch: every block leaves the exact integer moments of ITS members in a 128-byte
+// row of its own (seg_part, set t & 1) and pass t + 1 starts by reducing the rows of its segment and solving the 3x3
+// problem -- every block for itself, identically (integer sums are order-independent, the solve is deterministic),
+// while the sixteen points per thread it requested first are on their way from HBM.  (Rounds 1-3 had sixteen
+// same-address 64-bit atomics per block, a ticket, and the solve on ONE lane at the very end of the kernel, after
+// which the next launch could start: the non-final pass took 44 us against 18 us for the final one on the same loads.)
+// Block 0 of a segment publishes the state for the host-visible planes (set t & 1 of seg_state; a pass reads set
+// (t - 1) & 1, so nobody reads what it writes).  FINAL writes the per-point flag and per-block ground/obstacle counts
+// for the compaction.  Points are loaded four at a time (16-byte loads): a block covers chunk consecutive points
+// starting at a multiple of four, clipped to its segment (seg_block_range).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void seg_block_range(const SegParams &prm, uint32_t s, uint32_t b, uint32_t &base,
+                                                uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t seg_lo = s * prm.n_per, seg_hi = seg_lo + prm.n_per;
+    base = (seg_lo & ~3u) + b * prm.chunk;  // first point of the block's 16-byte-aligned window
+    lo = max(base, seg_lo);
+    hi = min(base + prm.chunk, seg_hi);
+    if (hi < lo)
+        hi = lo;
+}
+
+constexpr int PASS_QUADS = 4;  // quads (of four consecutive points) per thread and trip: SEG_CHUNK = 4 * 4 * SEG_THREADS
+
 template <bool FINAL>
 __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__restrict__ XS,
                                                                   const float *__restrict__ YS,
                                                                   const float *__restrict__ ZS, SegParams prm,
-                                                                  uint32_t t, SegState *st, long long *acc,
-                                                                  long long *facc, uint32_t *ticket,
-                                                                  uint8_t *__restrict__ flags,
+                                                                  uint32_t t, SegState *st, long long *part,
+                                                                  long long *facc, uint8_t *__restrict__ flags,
                                                                   uint32_t *__restrict__ blk_counts,
                                                                   const FrameState *__restrict__ frame, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<2>(fs);
     __shared__ long long red[SEG_WAVES][LPX_ACC_WORDS];
-    __shared__ uint32_t s_last;
+    __shared__ long long s_far[LPX_FAR_WORDS];
+    __shared__ SegState s_st;
     XS = lpx_slot(XS, fs);
     YS = lpx_slot(YS, fs);
     ZS = lpx_slot(ZS, fs);
     st = lpx_slot(st, fs);
-    acc = lpx_slot(acc, fs);
+    part = lpx_slot(part, fs);
     facc = lpx_slot(facc, fs);
-    ticket = lpx_slot(ticket, fs);
     flags = lpx_slot(flags, fs);
     blk_counts = lpx_slot(blk_counts, fs);
     frame = lpx_slot(frame, fs);
@@ -886,78 +907,172 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     const bool any_far = frame->has_far != 0;
     const uint32_t s = lpx_blk.y, b = lpx_blk.x;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
-    const uint32_t seg_lo = s * prm.n_per;
-    const uint32_t lo = seg_lo + b * prm.chunk;
-    const uint32_t hi = min(lo + prm.chunk, seg_lo + prm.n_per);
-    long long *fa = facc + (size_t)s * LPX_FAR_WORDS;
+    const uint32_t nb = prm.P * prm.bps;
+    uint32_t base, lo, hi;
+    seg_block_range(prm, s, b, base, lo, hi);
+    const uint32_t trips = prm.chunk / (4u * SEG_THREADS * PASS_QUADS);  // 1 unless the segment exceeds 2^20 points
 
-    const SegState sst = st[s];
+    // ---- the first sixteen points of every thread are requested before anything else ----
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f x4[PASS_QUADS], y4[PASS_QUADS], z4[PASS_QUADS];
+    auto load_trip = [&](uint32_t trip) {
+#pragma unroll
+        for (int u = 0; u < PASS_QUADS; ++u)
+        {
+            const uint32_t p = base + 4u * (tid + SEG_THREADS * (u + PASS_QUADS * trip));
+            if (p < hi)  // (a quad that starts before `hi` may reach past it: the arrays carry 16 spare elements)
+            {
+                x4[u] = *(const v4f *)(XS + p);
+                y4[u] = *(const v4f *)(YS + p);
+                z4[u] = *(const v4f *)(ZS + p);
+            }
+        }
+    };
+    load_trip(0);
+
+    // ---- head: the state this pass tests against ----
+    const SegState *st_in = st + (size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS;  // set (t - 1) & 1; pass 0: the seed state, set 0
+    SegState sst;
+    if (t == 0)
+        sst = st[s];
+    else
+    {
+        // plane t - 1 from the partials of pass t - 1: wave 0 reduces the segment's rows (4 rows x 16 words per load
+        // instruction, eight independent loads in flight), one pass of the solve per block
+        const long long *pin = part + (size_t)((t + 1u) & 1u) * prm.part_stride + (size_t)s * prm.bps * LPX_ACC_WORDS;
+        if (w == 0)
+        {
+            const uint32_t row = lane >> 4, word = lane & 15u;
+            long long v = 0;
+            for (uint32_t r0 = 0; r0 < prm.bps; r0 += 32)
+            {
+                long long q[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                {
+                    const uint32_t r = r0 + row + 4u * k;
+                    q[k] = r < prm.bps ? pin[(size_t)r * LPX_ACC_WORDS + word] : 0ll;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    v += q[k];
+            }
+            v += __shfl_xor(v, 16, WAVE);
+            v += __shfl_xor(v, 32, WAVE);
+            if (lane < LPX_ACC_WORDS)
+                red[0][lane] = v;
+            if (any_far && lane < LPX_FAR_WORDS)
+                s_far[lane] = facc[((size_t)((t - 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane];
+            if (any_far && b == 0 && lane < LPX_FAR_WORDS)  // the set pass t + 1 accumulates into: read by pass t - 1, free
+                facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
+        }
+        __syncthreads();
+        if (w == 0)
+        {
+            // every lane of the wave computes the same scalars (no divergence, one pass through the solve)
+            long long m[LPX_ACC_WORDS];
+#pragma unroll
+            for (int i = 0; i < LPX_ACC_WORDS; ++i)
+                m[i] = red[0][i];
+            SegState o = st_in[s];
+            if (o.failed == 0)
+            {
+                float plane[4];
+                // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
+                if (!plane_from_moments(m, any_far ? s_far : nullptr, plane))
+                    o.failed = 1;
+                else
+                {
+                    o.plane[0] = plane[0];
+                    o.plane[1] = plane[1];
+                    o.plane[2] = plane[2];
+                    o.plane[3] = plane[3];
+                    o.thr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
+                    o.fitted = 1;
+                }
+            }
+            if (lane == 0)
+            {
+                s_st = o;
+                if (b == 0)
+                    st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s] = o;  // what the compaction hands out as planes
+            }
+        }
+        __syncthreads();
+        sst = s_st;
+    }
     const bool skip = sst.failed == 2;       // < 3 points: nothing labelled
     const bool dead = sst.failed != 0;       // all obstacle
     const float pa = sst.plane[0], pb = sst.plane[1], pc = sst.plane[2], pd = sst.plane[3];
     const float thr = sst.thr;
     const bool use_seed = (t == 0);
     const bool seeds_ok = sst.has_seeds != 0;
+    long long *fa = facc + ((size_t)(t % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS;
 
     long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
     uint32_t cnt_g = 0, cnt_o = 0;
 
-    // four points per thread and trip: the twelve loads are issued before any of them is used
-    for (uint32_t p0 = lo + tid; p0 < hi; p0 += 4 * SEG_THREADS)
+    for (uint32_t trip = 0; trip < trips; ++trip)
     {
-        float xs[4], ys[4], zs[4];
-        bool in[4];
+        if (trip)
+            load_trip(trip);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < PASS_QUADS; ++u)
         {
-            const uint32_t p = p0 + u * SEG_THREADS;
-            in[u] = p < hi;
-            xs[u] = in[u] ? XS[p] : 0.0f;
-            ys[u] = in[u] ? YS[p] : 0.0f;
-            zs[u] = in[u] ? ZS[p] : 0.0f;
-        }
+            const uint32_t p0 = base + 4u * (tid + SEG_THREADS * (u + PASS_QUADS * trip));
+            if (p0 >= hi)
+                continue;
+            uint32_t fword = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-        {
-            const uint32_t p = p0 + u * SEG_THREADS;
-            const float x = xs[u], y = ys[u], z = zs[u];
-            bool member;
-            if (use_seed)
-                member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
-            else
+            for (int e = 0; e < 4; ++e)
             {
-                const float dist = ((x * pa + y * pb) + z * pc) - pd;
-                member = dist < thr;
-            }
-            member = member && !dead && in[u];
-            if (FINAL)
-            {
-                if (in[u])
+                const uint32_t p = p0 + e;
+                const bool in = p >= lo && p < hi;
+                const float x = x4[u][e], y = y4[u][e], z = z4[u][e];
+                bool member;
+                if (use_seed)
+                    member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
+                else
+                {
+                    const float dist = ((x * pa + y * pb) + z * pc) - pd;
+                    member = dist < thr;
+                }
+                member = member && !dead && in;
+                if (FINAL)
                 {
                     // number_of_iterations == 0: seeds are ground, the rest stays UNKNOWN (:243-247)
-                    const uint8_t f = skip ? 0 : (member ? 1 : ((prm.I == 0 && !dead) ? 0 : 2));
-                    flags[p] = f;
-                    cnt_g += (f == 1);
-                    cnt_o += (f == 2);
+                    const uint32_t f = (!in || skip) ? 0u : (member ? 1u : ((prm.I == 0 && !dead) ? 0u : 2u));
+                    fword |= f << (8 * e);
+                    cnt_g += (f == 1u);
+                    cnt_o += (f == 2u);
+                }
+                else if (member && any_far && !is_near(x, y, z))
+                    far_accumulate(fa, x, y, z);
+                else if (member)
+                {
+                    const int qx = __float2int_rn(x * FIX_SCALE);
+                    const int qy = __float2int_rn(y * FIX_SCALE);
+                    const int qz = __float2int_rn(z * FIX_SCALE);
+                    a_n += 1;
+                    a_x += qx;
+                    a_y += qy;
+                    a_z += qz;
+                    a_xx += (long long)qx * qx;
+                    a_xy += (long long)qx * qy;
+                    a_xz += (long long)qx * qz;
+                    a_yy += (long long)qy * qy;
+                    a_yz += (long long)qy * qz;
+                    a_zz += (long long)qz * qz;
                 }
             }
-            else if (member && any_far && !is_near(x, y, z))
-                far_accumulate(fa, x, y, z);
-            else if (member)
+            if (FINAL)
             {
-                const int qx = __float2int_rn(x * FIX_SCALE);
-                const int qy = __float2int_rn(y * FIX_SCALE);
-                const int qz = __float2int_rn(z * FIX_SCALE);
-                a_n += 1;
-                a_x += qx;
-                a_y += qy;
-                a_z += qz;
-                a_xx += (long long)qx * qx;
-                a_xy += (long long)qx * qy;
-                a_xz += (long long)qx * qz;
-                a_yy += (long long)qy * qy;
-                a_yz += (long long)qy * qz;
-                a_zz += (long long)qz * qz;
+                if (p0 >= lo && p0 + 4u <= hi)
+                    *(uint32_t *)(flags + p0) = fword;  // p0 is a multiple of four
+                else
+                    for (int e = 0; e < 4; ++e)
+                        if (p0 + e >= lo && p0 + e < hi)
+                            flags[p0 + e] = (uint8_t)(fword >> (8 * e));
             }
         }
     }
@@ -980,7 +1095,6 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
                 g += (uint32_t)red[i][0];
                 o += (uint32_t)red[i][1];
             }
-            const uint32_t nb = prm.P * prm.bps;
             blk_counts[s * prm.bps + b] = g;
             blk_counts[nb + s * prm.bps + b] = o;
             if (s == 0 && b == 0)
@@ -1016,60 +1130,9 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
 #pragma unroll
         for (int i = 0; i < SEG_WAVES; ++i)
             tot += red[i][tid];
-        if (tot != 0)
-            atomicAdd((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], (unsigned long long)tot);
-        // All cross-block traffic of this kernel is device-scope atomics (performed at the coherence
-        // point, nothing cached dirty), so ordering is all that is needed: wait until this lane's adds
-        // have been performed before the barrier that precedes the ticket.  No L2 write-back fence.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (any_far)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the far points' atomics of every lane
-    __syncthreads();
-    if (tid == 0)
-    {
-        const uint32_t old = atomicAdd(&ticket[s], 1u);
-        s_last = (old == prm.bps - 1);
-    }
-    __syncthreads();
-    if (!s_last)
-        return;
-    // last block of the segment: solve and publish plane t, reset the accumulators.  The 16 words are
-    // fetched and cleared by 16 lanes at once (a single lane would chain 32 dependent atomics).
-    if (tid < LPX_ACC_WORDS)
-    {
-        red[0][tid] = (long long)atomicExch((unsigned long long *)&acc[s * LPX_ACC_WORDS + tid], 0ull);
-        if (tid == 0)
-            atomicExch(&ticket[s], 0u);
-    }
-    long long *fred = &red[1][0];  // rows 1 and 2 hold the LPX_FAR_WORDS
-    static_assert(LPX_FAR_WORDS <= 2 * LPX_ACC_WORDS && SEG_WAVES >= 3, "far words fit two rows");
-    if (any_far && tid >= WAVE && tid < WAVE + LPX_FAR_WORDS)
-        fred[tid - WAVE] = (long long)atomicExch((unsigned long long *)&fa[tid - WAVE], 0ull);
-    __syncthreads();
-    if (tid == 0)
-    {
-        long long m[LPX_ACC_WORDS];
-        for (int i = 0; i < LPX_ACC_WORDS; ++i)
-            m[i] = red[0][i];
-        SegState o = sst;
-        if (!dead)
-        {
-            float plane[4];
-            // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
-            if (!plane_from_moments(m, any_far ? fred : nullptr, plane))
-                o.failed = 1;
-            else
-            {
-                o.plane[0] = plane[0];
-                o.plane[1] = plane[1];
-                o.plane[2] = plane[2];
-                o.plane[3] = plane[3];
-                o.thr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
-                o.fitted = 1;
-            }
-            st[s] = o;
-        }
+        // this block's row of set t & 1: one 128-byte line, written whole, read by every block of the segment in the
+        // head of the next launch
+        part[(size_t)(t & 1u) * prm.part_stride + ((size_t)s * prm.bps + b) * LPX_ACC_WORDS + tid] = tot;
     }
 }
 
@@ -1112,9 +1175,8 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     const uint32_t s = lpx_blk.y, b = lpx_blk.x;
     const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
     const uint32_t nb = prm.P * prm.bps;
-    const uint32_t seg_lo = s * prm.n_per;
-    const uint32_t lo = seg_lo + b * prm.chunk;
-    const uint32_t hi = min(lo + prm.chunk, seg_lo + prm.n_per);
+    uint32_t base_unused, lo, hi;  // the block's points: the same ranges as the plane passes that counted them
+    seg_block_range(prm, s, b, base_unused, lo, hi);
     const uint32_t total_g = blk_offs[nb];  // exclusive scan over [G blocks | O blocks]
     const uint32_t gbase = blk_offs[s * prm.bps + b];
     const uint32_t obase = blk_offs[nb + s * prm.bps + b] - total_g;
@@ -1220,13 +1282,11 @@ __global__ void colour_kernel(const float4 *__restrict__ P4,
     dst[1] = make_float4(__uint_as_float(rgba), __uint_as_float(g ? 0u : 1u), 0.0f, 0.0f);
 }
 
-__global__ void dbg_all_seed_kernel(SegState *st, long long *acc, uint32_t *ticket)
+__global__ void dbg_all_seed_kernel(SegState *st, long long *facc)
 {
-    if (threadIdx.x < LPX_ACC_WORDS)
-        acc[threadIdx.x] = 0;
+    seg_far_reset(facc, 0, threadIdx.x);
     if (threadIdx.x == 0)
     {
-        ticket[0] = 0;
         SegState o;
         o.lo_excl = -INFINITY;
         o.hi_incl = INFINITY;
@@ -1242,6 +1302,7 @@ __global__ void dbg_all_seed_kernel(SegState *st, long long *acc, uint32_t *tick
 
 __global__ void dbg_plane_out_kernel(const SegState *st, float *out)
 {
+    st += LPX_MAX_PARTITIONS;  // the state the head of pass 1 published (set 1)
     if (threadIdx.x < 4)
         out[threadIdx.x] = st[0].plane[threadIdx.x];
     if (threadIdx.x == 4)
@@ -1313,6 +1374,25 @@ int lpx_write_counts(lpx_ctx *ctx, uint32_t *d_counts)
 }
 
 // plane of ALL n points (stride-12 device input) through the moment + Jacobi path; out[0..3] plane, out[4] failed
+// Launch geometry of the plane passes and the compaction from prm.n_per (the largest segment of the call): blocks of
+// SEG_CHUNK points, larger ones once a segment would need more than 256 of them (every block of pass t + 1 reads the
+// rows of ALL blocks of its segment), at most 256 points per thread (the bound of the int64 moment lanes); one block
+// more where a segment's 16-byte-aligned window starts before the segment.
+static void seg_geometry(SegParams &prm, uint32_t cap_n)
+{
+    uint32_t chunk = SEG_CHUNK;
+    const uint32_t quantum = 4u * SEG_THREADS * PASS_QUADS;  // a whole number of trips per block
+    if (prm.n_per / 256u > chunk)
+    {
+        chunk = ((prm.n_per / 256u + quantum - 1) / quantum) * quantum;
+        if (chunk > 256u * SEG_THREADS)
+            chunk = 256u * SEG_THREADS;
+    }
+    prm.chunk = chunk;
+    prm.bps = prm.n_per ? (prm.n_per + 3u + chunk - 1) / chunk : 1;
+    prm.part_stride = (uint32_t)(LPX_SEG_MAX_BLOCKS(cap_n) * LPX_ACC_WORDS);
+}
+
 int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
 {
     FrameState *frame = (FrameState *)ctx->frame.p;
@@ -1321,25 +1401,27 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
     prm.n_per = n;
     prm.P = 1;
     prm.I = 1;
-    prm.chunk = SEG_CHUNK;
-    prm.bps = n ? (n + SEG_CHUNK - 1) / SEG_CHUNK : 1;
+    seg_geometry(prm, ctx->cap_n);
     prm.z_floor = 0.0f;
     prm.seed_thr = 0.0f;
     prm.odt = 0.0f;
     prm.n_lpr = 0;
     float *XS = (float *)ctx->XS.p, *YS = (float *)ctx->YS.p, *ZS = (float *)ctx->ZS.p;
     SegState *sst = (SegState *)ctx->seg_state.p;
-    long long *acc = (long long *)ctx->seg_acc.p;
-    uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
+    long long *part = (long long *)ctx->seg_part.p;
     const FV fv = lpx_fv(ctx);
     int rc = lpx_frame_init(ctx, &n, false);
     if (rc)
         return rc;
     if (n)
         launch_ingest(ctx, dim3((n + 255) / 256), d_pts, 12, XS, YS, ZS, nullptr, nullptr, nullptr, frame, nullptr);
-    hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, acc, ticket);
+    // pass 0 leaves the moments of every point, the head of pass 1 (run as the final pass) solves and publishes the plane
+    hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(128), 0, ctx->stream, sst, (long long *)ctx->seg_far.p);
     hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
-                       0u, sst, acc, (long long *)ctx->seg_far.p, ticket, (uint8_t *)ctx->flags.p, (uint32_t *)nullptr,
+                       0u, sst, part, (long long *)ctx->seg_far.p, (uint8_t *)ctx->flags.p, (uint32_t *)ctx->blk_counts.p,
+                       (const FrameState *)frame, fv.fs);
+    hipLaunchKernelGGL((plane_pass_kernel<true>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
+                       1u, sst, part, (long long *)ctx->seg_far.p, (uint8_t *)ctx->flags.p, (uint32_t *)ctx->blk_counts.p,
                        (const FrameState *)frame, fv.fs);
     hipLaunchKernelGGL(dbg_plane_out_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, d_out);
     LPX_HIP(ctx, hipGetLastError());
@@ -1394,8 +1476,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     prm.n_per = n / P;
     prm.P = P;
     prm.I = I;
-    prm.chunk = SEG_CHUNK;
-    prm.bps = prm.n_per ? (prm.n_per + SEG_CHUNK - 1) / SEG_CHUNK : 1;
+    seg_geometry(prm, ctx->cap_n);
     prm.z_floor = -1.5f * cfg->sensor_height_m;
     prm.seed_thr = cfg->initial_seed_threshold;
     prm.odt = cfg->orthogonal_distance_threshold;
@@ -1435,13 +1516,12 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
                            (const FrameState *)frame, fv.fs);
     }
     SegState *sst = (SegState *)ctx->seg_state.p;
-    long long *acc = (long long *)ctx->seg_acc.p;
-    uint32_t *ticket = (uint32_t *)(acc + LPX_MAX_PARTITIONS * LPX_ACC_WORDS);
+    long long *part = (long long *)ctx->seg_part.p;
     long long *facc = (long long *)ctx->seg_far.p;
     if (select_seeds)
     {
         StageTimer tm(ctx, ST_SEEDS);
-        hipLaunchKernelGGL(seed_select_kernel, dim3(P, 1, B), dim3(SEL_THREADS), 0, st, ZS, prm, sst, acc, ticket,
+        hipLaunchKernelGGL(seed_select_kernel, dim3(P, 1, B), dim3(SEL_THREADS), 0, st, ZS, prm, sst, facc,
                            (const FrameState *)frame, fv.fs);
     }
     else
@@ -1455,12 +1535,13 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
                 return rc;
         }
         StageTimer tm(ctx, ST_SEEDS);
-        hipLaunchKernelGGL(seed_kernel, dim3(P, 1, B), dim3(SEG_THREADS), 0, st, zsorted, prm, sst, acc, ticket,
+        hipLaunchKernelGGL(seed_kernel, dim3(P, 1, B), dim3(SEG_THREADS), 0, st, zsorted, prm, sst, facc,
                            (const FrameState *)frame, fv.fs);
     }
     const uint32_t nb = P * prm.bps;
-    if (sizeof(uint32_t) * (2 * (size_t)nb + 2) > ctx->blk_counts.bytes)
-        return lpx_fail(ctx, LPX_ERR_INTERNAL, "block count table of %u blocks does not fit the workspace", nb);
+    if (sizeof(uint32_t) * (2 * (size_t)nb + 2) > ctx->blk_counts.bytes ||
+        sizeof(long long) * LPX_ACC_WORDS * (size_t)nb > ctx->seg_part.bytes / 2)
+        return lpx_fail(ctx, LPX_ERR_INTERNAL, "block tables of %u blocks do not fit the workspace", nb);
     uint32_t *blk_counts = (uint32_t *)ctx->blk_counts.p;
     {
         StageTimer tm(ctx, ST_PLANE);
@@ -1471,10 +1552,10 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         {
             const dim3 g2(prm.bps, P, B);
             for (uint32_t t = 0; t < I; ++t)
-                hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, t, sst, acc,
-                                   facc, ticket, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
-            hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, I, sst, acc,
-                               facc, ticket, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
+                hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, t, sst, part,
+                                   facc, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
+            hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, I, sst, part,
+                               facc, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
         }
     }
     {
@@ -1485,7 +1566,9 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
             return rc;
         hipLaunchKernelGGL(compact_kernel, dim3(prm.bps, P, B), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p,
                            sidx, XS, YS, ZS, prm, blk_counts, d_labels, d_gidx, d_oidx, (float *)ctx->OX.p,
-                           (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p, sst, d_planes, frame, fv);
+                           (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p,
+                           sst + (size_t)(I & 1u) * LPX_MAX_PARTITIONS,  // the state the head of the final pass published
+                           d_planes, frame, fv);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
