@@ -221,6 +221,33 @@ def cpu_baselines(host_frames, wl, budget_s):
                                          "what": f"one frame per core, {len(jobs)} frames in {t3:.1f} s"}}
 
 
+def dropin_cxx_latency(frame, wl):
+    """The unchanged node's two calls through the drop-in C++ headers themselves (tests/cxx/dropin_latency.cpp, compiled
+    here with g++ against the test-only PCL stand-in): Segmenter::segment + Clusterer::cluster on default-constructed
+    objects (one shared context), and with a context each.  Runs as a child process BEFORE this process touches the GPU."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        exe, fin = os.path.join(tmp, "dropin_latency"), os.path.join(tmp, "in.f32")
+        cmd = ["g++", "-std=c++17", "-O2", f"-I{ROOT}/include", f"-I{ROOT}/include/lidar_processing", f"-I{ROOT}/tests/cxx",
+               f"{ROOT}/tests/cxx/dropin_latency.cpp", "-o", exe, f"-L{ROOT}/lidar_processing_amd", "-llpx",
+               f"-Wl,-rpath,{ROOT}/lidar_processing_amd", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": "g++: " + r.stderr[-300:]}
+        np.ascontiguousarray(frame, np.float32).tofile(fin)
+        r = subprocess.run([exe, fin, "15", str(wl["seg"]["number_of_planar_partitions"]),
+                            str(wl["seg"]["number_of_iterations"]), str(wl["clu"]["distance_squared"])],
+                           capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-300:]}
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    d["what"] = ("lidar_processing::Segmenter::segment + Clusterer::cluster (include/lidar_processing/*.hpp, C++, pageable "
+                 "PCL clouds) as reference src/processor.cpp:150 and :178 call them; default-constructed objects share "
+                 "one context, so cluster() finds the obstacle cloud on the device")
+    return d
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="ranks (one process per GPU); > 1 without WORLD_SIZE: spawned here")
@@ -250,6 +277,8 @@ def parse_args(argv=None):
                     help="batch contexts with lpx_set_overlap: replay + labels of a chain on a second stream beside the "
                          "context's next chain (half the frames in flight for the same rate; use about 10 contexts: the "
                          "device serves about 24 hardware queues at full speed)")
+    ap.add_argument("--fork", action="store_true",
+                    help="lpx_set_fork: the component grid of a chain on a side stream beside its kd build and chunk tables")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default=None,
                     help="torch.distributed backend of the barrier / MAX / SUM (default nccl = RCCL; gloo with --dry-run)")
     ap.add_argument("--dry-run", action="store_true",
@@ -287,6 +316,7 @@ class Plan:
         self.name, self.wl, self.torch = name, wl, torch
         self.lists = not args.search and (args.lists or wl.get("lists", False))
         self.overlap = args.overlap
+        self.fork = getattr(args, "fork", False)
         self.scfg = lpx.SegmentationConfiguration(**wl["seg"])
         self.ccfg = lpx.ClusteringConfiguration(**wl["clu"])
         self.P, self.I = wl["seg"]["number_of_planar_partitions"], wl["seg"]["number_of_iterations"]
@@ -323,6 +353,8 @@ class Plan:
         c.reserve(self.pitch)
         if batch > 1 and (self.overlap if overlap is None else overlap):
             c.set_overlap(True)  # replay + labels of a chain beside the front end of the context's next chain
+        if self.fork:
+            c.set_fork(True)     # the component grid of a chain beside its kd build and chunk tables
         return c
 
     def enqueue_frames(self, ctx, lo, hi):
@@ -501,7 +533,8 @@ def environment_of(lpx):
     from lidar_processing_amd import _lib
     env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("LPX_") or k == "GPU_MAX_HW_QUEUES"}
     env["library"] = os.path.relpath(_lib.LIB_PATH, ROOT)
-    env["library_build"] = _lib.lib().lpx_build_info().decode()
+    env["library_build"] = (_lib.lib().lpx_build_info().decode() if hasattr(_lib.lib(), "lpx_build_info")
+                            else "older A/B variant without lpx_build_info")
     return env
 
 
@@ -844,7 +877,13 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baselines(host_frames, wl, args.cpu_seconds)  # before the GPU is initialised (fork)
 
-    sub, overlap_sub, inflight_child, feeder_child = None, None, None, None
+    sub, overlap_sub, inflight_child, feeder_child, cxx_latency = None, None, None, None, None
+    if rank == 0 and world == 1 and not args.no_latency and not args.dry_run and not args.inflight_only \
+            and not args.feeder_only:
+        try:
+            cxx_latency = dropin_cxx_latency(host_frames[0], wl)
+        except Exception as e:  # a side measurement must never cost the line
+            cxx_latency = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and args.workload == "stream" and not args.no_sub and not args.dry_run \
             and not args.inflight_only and not args.feeder_only:
         # Two side measurements, each by a CHILD process that runs to completion before this process touches the GPU
@@ -982,6 +1021,8 @@ def main(argv=None):
         roofline = roofline_of(plan, counts, elapsed, args.steps, world, stage_ms, launches, per_launch)
         if not args.no_latency and side:
             latency = latency_of(plan, host_frames, lpx)
+            if cxx_latency is not None:
+                latency["dropin_cxx"] = cxx_latency
         if feeder_child is not None:
             stream_info = dict(feeder_child)
         elif args.workload == "stream" and not args.no_sub and side:
@@ -1012,7 +1053,7 @@ def main(argv=None):
             "config": {"workload": wl["config"], "neighbour_mode": "lists" if (not args.search and (args.lists or wl.get("lists"))) else "search",
                        "frames_per_step_per_gpu": F, "frames_per_launch_chain": max(1, min(args.batch or wl["batch"], F)),
                        "contexts_per_gpu": max(1, min(args.contexts or wl["contexts"], -(-F // max(1, min(args.batch or wl["batch"], F))))),
-                       "overlap": bool(args.overlap),
+                       "overlap": bool(args.overlap), "fork": bool(args.fork),
                        "host_threads_per_gpu": plan.C, "hip_hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "env": environment_of(lpx),
                        "points_per_step": int(total_points_per_step), "frames_per_step": int(total_frames_per_step),

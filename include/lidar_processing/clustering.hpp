@@ -36,7 +36,9 @@ class Clusterer final
     static constexpr ClusteringLabel UNDEFINED{std::numeric_limits<std::int32_t>::lowest()};
     static constexpr ClusteringLabel INVALID{-1};
 
-    Clusterer() : context_{std::make_shared<detail::LpxContext>()}, configuration_{}
+    // the process-wide context, shared with a default-constructed Segmenter (lpx_context.hpp: default_context): the
+    // obstacle cloud segment() left on the device is clustered where it lies
+    Clusterer() : context_{detail::default_context()}, configuration_{}
     {
         reserve_memory();
     }
@@ -53,6 +55,7 @@ class Clusterer final
 
     void reserve_memory(std::uint32_t number_of_points = 200'000U)
     {
+        std::lock_guard<std::mutex> lock(context_->mutex());
         lpx_reserve(context_->get(), number_of_points, 0U);
     }
 
@@ -64,6 +67,7 @@ class Clusterer final
         {
             return;
         }
+        std::lock_guard<std::mutex> lock(context_->mutex());
 
         lpx_clu_cfg cfg{};
         cfg.distance_squared = configuration_.distance_squared;
@@ -101,6 +105,7 @@ class Clusterer final
         group_offsets_.resize(last_clusters_ + 1U);
         group_indices_.resize(last_size_);
         std::uint32_t number_of_valid = 0U;
+        std::lock_guard<std::mutex> lock(context_->mutex());
         const int rc = lpx_cluster_groups(context_->get(), last_size_, last_clusters_, group_offsets_.data(),
                                           group_indices_.data(), &number_of_valid);
         if (rc != LPX_OK)
@@ -137,6 +142,7 @@ class Clusterer final
         hull_indices_.resize(last_size_);
         hull_xy_.resize(2U * static_cast<std::size_t>(last_size_));
         std::uint32_t number_of_hull_points = 0U;
+        std::lock_guard<std::mutex> lock(context_->mutex());
         const int rc = lpx_cluster_hulls(context_->get(), last_size_, last_clusters_, max_points, hull_offsets_.data(),
                                          hull_indices_.data(), hull_xy_.data(), &number_of_hull_points);
         if (rc != LPX_OK)

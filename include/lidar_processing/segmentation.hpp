@@ -38,7 +38,8 @@ struct SegmentationConfiguration final
 class Segmenter final
 {
   public:
-    Segmenter() : context_{std::make_shared<detail::LpxContext>()}, configuration_{}
+    // the process-wide context, shared with a default-constructed Clusterer (lpx_context.hpp: default_context)
+    Segmenter() : context_{detail::default_context()}, configuration_{}
     {
         reserve_memory();
     }
@@ -56,6 +57,7 @@ class Segmenter final
 
     void reserve_memory(std::uint32_t number_of_points = 200'000U)
     {
+        std::lock_guard<std::mutex> lock(context_->mutex());
         lpx_reserve(context_->get(), number_of_points, 0U);
         ground_indices_.reserve(number_of_points);
         obstacle_indices_.reserve(number_of_points);
@@ -79,6 +81,8 @@ class Segmenter final
                  pcl::PointCloud<PointT> &ground_cloud, pcl::PointCloud<PointT> &obstacle_cloud)
     {
         static_assert(sizeof(SegmentationLabel) == sizeof(std::uint32_t), "label layout");
+        std::lock_guard<std::mutex> lock(context_->mutex());
+        context_->segment_owner = this;
         labels.resize(cloud_in.size(), SegmentationLabel::UNKNOWN);
         ground_cloud.clear();
         obstacle_cloud.clear();
@@ -146,6 +150,11 @@ class Segmenter final
     void coloured_clouds(pcl::PointCloud<PointOutT> &ground_cloud, pcl::PointCloud<PointOutT> &obstacle_cloud)
     {
         static_assert(sizeof(PointOutT) == 32U, "pcl::PointXYZRGBL records are 32 bytes");
+        std::lock_guard<std::mutex> lock(context_->mutex());
+        if (context_->segment_owner != this)
+        {
+            throw std::runtime_error("coloured clouds failed: another Segmenter has used the shared context since segment()");
+        }
         ground_cloud.points.resize(last_ground_);
         obstacle_cloud.points.resize(last_obstacle_);
         std::uint32_t number_of_ground = 0U;

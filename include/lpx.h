@@ -70,7 +70,9 @@ typedef struct
 #define LPX_ERR_NO_DEVICE (-5)
 #define LPX_ERR_INTERNAL (-6)
 
+#ifndef LPX_MAX_BATCH
 #define LPX_MAX_BATCH 64u
+#endif
 #define LPX_MAX_PARTITIONS 256u
 #define LPX_MAX_ITERATIONS 64u
 
@@ -128,6 +130,12 @@ int lpx_synchronize(lpx_ctx *ctx);
  * it on a caller's stream whose later work reads the results without a host synchronisation.  Throughput only: a
  * single call is not faster. */
 int lpx_set_overlap(lpx_ctx *ctx, int on);
+/* Forked front end: with `on`, the component search of Clusterer::cluster (the clique-cell grid: eight short,
+ * latency-bound launches) runs on a side stream of the device beside the kd-tree build and the chunk tables of the
+ * same call -- both need only the obstacle cloud -- and the context's stream joins it before the ordered replay.
+ * Results are the same; a call completes sooner (one frame in LPX_NEIGHBOURS_SEARCH mode, a chain of frames), at the
+ * price of a second hardware queue while the fork is open.  Call it after lpx_set_overlap if both are wanted. */
+int lpx_set_fork(lpx_ctx *ctx, int on);
 /* host wait until every batch call of an overlapped context but the LAST one is complete (a pipelined caller enqueues
  * call k, then collects call k - 1); without overlap the same as lpx_synchronize */
 int lpx_wait_previous(lpx_ctx *ctx);

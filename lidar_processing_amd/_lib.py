@@ -72,6 +72,8 @@ def lib():
     L.lpx_last_error.restype = C.c_char_p
     L.lpx_synchronize.argtypes = [vp]
     L.lpx_set_overlap.argtypes = [vp, C.c_int]
+    if hasattr(L, "lpx_set_fork"):  # (absent from A/B variants built from an older tree)
+        L.lpx_set_fork.argtypes = [vp, C.c_int]
     L.lpx_wait_previous.argtypes = [vp]
     L.lpx_segment.argtypes = [vp, vp, sz, u32, C.POINTER(SegCfg), vp, vp, pu32, vp, pu32, vp]
     L.lpx_cluster.argtypes = [vp, vp, sz, u32, C.POINTER(CluCfg), vp, pu32]
@@ -127,7 +129,8 @@ def lib():
     L.lpx_dbg_neighbours.argtypes = [vp, vp, u32, C.c_float, vp, vp, vp, C.c_uint64]
     L.lpx_dbg_components.argtypes = [vp, vp, u32, C.c_float, vp]
     L.lpx_dbg_plane.argtypes = [vp, vp, u32, vp]
-    L.lpx_build_info.argtypes = []
-    L.lpx_build_info.restype = C.c_char_p
+    if hasattr(L, "lpx_build_info"):  # (an A/B variant built from an older tree, LPX_LIB, may lack it)
+        L.lpx_build_info.argtypes = []
+        L.lpx_build_info.restype = C.c_char_p
     _lib = L
     return L

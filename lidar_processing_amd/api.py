@@ -128,6 +128,10 @@ class Context:
         call on a second stream (throughput; results are final after synchronize())"""
         self.check(self._L.lpx_set_overlap(self._h, 1 if on else 0))
 
+    def set_fork(self, on=True):
+        """lpx_set_fork: the component search of a call runs on a side stream beside its kd build and chunk tables"""
+        self.check(self._L.lpx_set_fork(self._h, 1 if on else 0))
+
     def wait_previous(self):
         """lpx_wait_previous: every batch call but the last one is complete (overlapped contexts)"""
         self.check(self._L.lpx_wait_previous(self._h))

@@ -544,7 +544,7 @@ template <bool STATE_LDS>
 __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
     const FrameState *__restrict__ frame, const uint32_t *__restrict__ cc_lo, const uint32_t *__restrict__ cc_hi,
     const uint32_t *__restrict__ members, const KdNode *__restrict__ PR, const ChunkRec *__restrict__ chunks,
-    const uint32_t *__restrict__ grp_of, const float *__restrict__ OX, const float *__restrict__ OY,
+    const float4 *__restrict__ grp_of, const float *__restrict__ OX, const float *__restrict__ OY,
     const float *__restrict__ OZ, uint8_t *gstate, int32_t *seed_of, uint32_t *queue, uint32_t *valid,
     ReplayParams prm, FrameState *fstate, const uint32_t *__restrict__ roots, uint32_t m_lo, uint32_t m_hi,
     unsigned long long *prof, FV fv)
@@ -726,8 +726,11 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 }
                 const bool alive = inw && !(ST_GET(wcand) & 2u);
                 const uint32_t ci = alive ? wcand : 0u;
-                const float wx = OX[ci], wy = OY[ci], wz = OZ[ci];
-                const uint32_t wg = grp_of[ci];  // gathered with the coordinates: no extra round trip per search
+                // one 16-byte record per point {x, y, z, kd group}: a window of 64 scattered points is 64 memory requests
+                // instead of 256 (four arrays), and no extra round trip per search
+                const float4 wrec = grp_of[ci];
+                const float wx = wrec.x, wy = wrec.y, wz = wrec.z;
+                const uint32_t wg = __float_as_uint(wrec.w);
                 unsigned long long am = __ballot(alive), em = 0;
                 // The first alive candidate of a window is always expanded (nothing before it can absorb it): its chunk
                 // table is requested BEFORE the selection loop below, which only needs the coordinates and then runs
@@ -1150,7 +1153,26 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     const bool skip_kd = skip_env && strstr(skip_env, "kd"), skip_index = skip_env && strstr(skip_env, "index");
     const bool skip_grid = skip_env && strstr(skip_env, "grid"), skip_sort = skip_env && strstr(skip_env, "sort");
     const bool skip_replay = skip_env && strstr(skip_env, "replay");
-    int rc = (kd_ready || skip_kd) ? LPX_OK : lpx_kd_build(ctx, m_max);
+    const dim3 blk(256), grd((m_max + 255) / 256, 1, ctx->cur_b);
+    uint32_t *root = (uint32_t *)ctx->key_a.p, *iota = (uint32_t *)ctx->val_a.p;
+    // Forked front end (lpx_set_fork): the component grid goes to a side stream BEFORE the kd build is enqueued here --
+    // both start from the obstacle cloud alone and touch disjoint buffers; the join sits where the first consumer of
+    // the components (the sort by root) is enqueued.
+    const bool grid_cc = !ctx->use_lists && !skip_grid && !lpx_cc_from_chunks(m_max);
+    const bool forked = grid_cc && ctx->fork && ctx->fork_stream && ctx->ev_fork && ctx->ev_join;
+    int rc = LPX_OK;
+    if (forked)
+    {
+        LPX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+        LPX_HIP(ctx, hipStreamWaitEvent(ctx->fork_stream, ctx->ev_fork, 0));
+        ctx->stream = ctx->fork_stream;
+        rc = lpx_grid_components(ctx, m_max, cfg->distance_squared, root, iota, false);
+        ctx->stream = st;
+        if (rc)
+            return rc;
+        LPX_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->fork_stream));
+    }
+    rc = (kd_ready || skip_kd) ? LPX_OK : lpx_kd_build(ctx, m_max);
     if (rc)
         return rc;
     ReplayParams prm;
@@ -1162,8 +1184,6 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     prm.r2 = cfg->distance_squared;
     prm.min_size = cfg->min_cluster_size;
     prm.max_size = cfg->max_cluster_size;
-    const dim3 blk(256), grd((m_max + 255) / 256, 1, ctx->cur_b);
-    uint32_t *root = (uint32_t *)ctx->key_a.p, *iota = (uint32_t *)ctx->val_a.p;
     uint32_t *sroot = nullptr, *members = nullptr;
     uint32_t *cc_lo = (uint32_t *)ctx->cc_lo.p, *cc_hi = (uint32_t *)ctx->cc_hi.p;
     uint32_t *valid = (uint32_t *)ctx->valid.p;
@@ -1176,14 +1196,19 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     }
     else
     {
-        // expansion-driven path: candidate chunks per kd group, components from the uniform grid
-        if ((!skip_index && (rc = lpx_group_index(ctx, m_max, cfg->distance_squared))) ||
-            (!skip_grid && (rc = lpx_grid_components(ctx, m_max, cfg->distance_squared, root, iota))))
+        // expansion-driven path: candidate chunks per kd group; the components come out of the same kernel
+        // (kd_link_queries) -- or, development build with LPX_CC=grid, from the clique-cell grid
+        const bool clear_in_index = grid_cc && !forked && !skip_index;
+        if ((!skip_index && (rc = lpx_group_index(ctx, m_max, cfg->distance_squared, clear_in_index))) ||
+            (grid_cc && !forked &&
+             (rc = lpx_grid_components(ctx, m_max, cfg->distance_squared, root, iota, clear_in_index))))
             return rc;
+        if (forked)
+            LPX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
     {
         StageTimer tm(ctx, ST_CC);
-        if (ctx->use_lists)
+        if (ctx->use_lists || lpx_cc_from_chunks(m_max))
             hipLaunchKernelGGL(flatten_kernel, grd, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
                                (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, fv.fs);
         if (skip_sort)
@@ -1257,7 +1282,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         const uint32_t rgrid = (m_max + RS_WAVES - 1) / RS_WAVES < rg_cap ? (m_max + RS_WAVES - 1) / RS_WAVES : rg_cap;
 #define RS_ARGS(lo_, hi_)                                                                                             \
     (const FrameState *)frame, (const uint32_t *)cc_lo, (const uint32_t *)cc_hi, (const uint32_t *)members,            \
-        (const KdNode *)ctx->nodes_pre.p, (const ChunkRec *)ctx->chunks.p, (const uint32_t *)ctx->grp_of.p,            \
+        (const KdNode *)ctx->nodes_pre.p, (const ChunkRec *)ctx->chunks.p, (const float4 *)ctx->grp_of.p,              \
         (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p, (uint8_t *)ctx->state.p,          \
         (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, frame, (const uint32_t *)ctx->rpos.p,         \
         (uint32_t)(lo_), (uint32_t)(hi_),                                                                             \

@@ -64,11 +64,26 @@ struct alignas(128) FrameState
     uint32_t n_single;        // single-point sets, settled by cc_ranges_kernel (not in the work list of n_roots)
     uint32_t max_obstacle;    // slot 0 only: largest n_obstacle of the frames of the call (sizes the next call's LDS bitmaps)
     uint32_t pad_stats;
+    // position-bound checksum of the obstacle cloud the compaction wrote (single-frame calls): what lets lpx_cluster
+    // recognise the cloud lpx_segment left on the device and skip the upload (lpx_obstacle_mix)
+    alignas(128) uint64_t obs_hash;
     // The single-pass region of the list workspace is handed out from LPX_RS_STRIPES sub-regions with a cursor each
     // (group g bumps cursor g % LPX_RS_STRIPES): thousands of bumps of ONE word per frame serialise at L2.
     FrameStripe rs_stripe[LPX_RS_STRIPES];
     FrameStripe ent_stripe[LPX_RS_STRIPES];  // neighbour entries written, likewise striped
 };
+
+// One point's share of the obstacle-cloud checksum: its three coordinate words bound to its position in the cloud.
+// The checksum is the wrapping sum of the shares (order of accumulation irrelevant: the device adds per wavefront).
+__host__ __device__ static inline uint64_t lpx_obstacle_mix(uint32_t i, uint32_t xb, uint32_t yb, uint32_t zb)
+{
+    uint64_t h = (((uint64_t)xb << 32) | yb) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h += ((uint64_t)zb << 32) | i;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return h;
+}
 
 static inline uint64_t lpx_entries_written(const FrameState &f)
 {
@@ -81,7 +96,7 @@ static inline uint64_t lpx_entries_written(const FrameState &f)
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
 // blocks of a plane pass (and rows of seg_part / blk_counts) a cloud of n points can need at most: a segment's blocks
 // start on a multiple of four points (16-byte loads), which can add one block per segment
-#define LPX_SEG_MAX_BLOCKS(n) ((size_t)(n) / 4096 + 2 * LPX_MAX_PARTITIONS + 2)
+#define LPX_SEG_MAX_BLOCKS(n) ((size_t)(n) / 2048 + 2 * LPX_MAX_PARTITIONS + 2)
 #define LPX_FAR_WORDS 24  // moments of the points beyond +-2048 m: n, sx, sy, sz, 6 x (hh, hl, ll) limbs, 2 spare
 
 struct SegState  // per segment
@@ -147,6 +162,12 @@ struct lpx_ctx
     uint32_t flip = 0;
     hipStream_t tail_stream = nullptr;  // where this slot set's tail runs (from the device's pool)
     hipEvent_t ev_front = nullptr, ev_tail = nullptr;
+    // ---- forked front end (lpx_set_fork): the component grid of a chain runs on a side stream beside the kd build and
+    // the chunk tables of the same chain -- both need nothing but the obstacle cloud, and both are chains of
+    // latency-bound launches
+    bool fork = false;
+    hipStream_t fork_stream = nullptr;  // from the device's pool of side streams
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool split_tail = false;       // the call being enqueued hands its tail to tail_stream
     bool enqueued = false;         // the batch call in progress got past its checks and uses this slot set
     bool tail_pending = false;     // a tail was enqueued since the stream last waited for ev_tail
@@ -173,6 +194,10 @@ struct lpx_ctx
     // other call that re-initialises the frame state or may move the arena (cluster, device and batch entry points).
     bool seg_valid = false;
     uint32_t seg_ground = 0, seg_obstacle = 0;
+    // the obstacle cloud of that call is still resident exactly as the compaction left it (SoA + kd input): lpx_cluster
+    // of a cloud with this count and checksum runs on it without an upload; cleared once a clustering has consumed it
+    bool seg_fresh = false;
+    uint64_t seg_hash = 0;
     Buf pts4;                  // the cloud in original order, float4 {x, y, z, 0} per point
     Buf key_a, key_b;          // u32 keys ping-pong
     Buf val_a, val_b;          // u32 values ping-pong
@@ -206,13 +231,16 @@ struct lpx_ctx
     Buf valid;                 // u32 per seed
     Buf d_clabels;
     // ---- expansion-driven search (default path): no neighbour lists at all ----
-    Buf grp_of;                // u32 per point: kd group (bucket or upper node) the point is a query of
+    Buf grp_of;                // float4 per point {x, y, z, kd group (bucket or upper node) the point is a query of}: what a
+                               // queue window of the replay gathers per point, in ONE 16-byte record
     Buf chunks;                // ChunkRec [groups][LPX_GROUP_CHUNKS]: candidate chunks (pre-order rank, count, box) of a group
     Buf cell_key;              // u64 [cell_cap]: occupied cells of the component grid (open addressing)
     Buf cell_rep, cell_parent; // u32 [cell_cap]: points of the cell / union-find over cells
     Buf cell_start;            // u32 [cell_cap]: where the cell's points begin in the cell-ordered copy
     Buf cell_of;               // u32 per point: its cell slot
     Buf cell_xyz;              // float4 [cell_cap]: the point that claimed the cell
+    Buf cell_pts;              // float4 per point: the cell-ordered copy of the cloud ({x, y, z, index} runs per cell)
+    Buf cell_list;             // u32 per point: the occupied cells' table slots
     uint32_t cell_cap = 0;     // slots per frame slot (power of two >= 2 * cap_n)
     bool arena_has_search = false;  // the arena holds the search tables above (contexts that have been in search mode)
     bool use_lists = false;    // lpx_dbg_use_lists: materialise every radius list (the round-1 path, kept for tests)
@@ -332,8 +360,10 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
 // expansion-driven path: candidate chunks per kd group + the point -> group map; components from a uniform grid
 uint32_t lpx_active_frame_slots(int device);  // frame slots of the contexts of the device that enqueued work lately
 void lpx_note_enqueue(lpx_ctx *ctx);
-int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2);
-int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota);
+// clear_grid: also empty the cell table of the component grid (lpx_grid_components(..., cleared = true) follows)
+int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2, bool clear_grid);
+bool lpx_cc_from_chunks(uint32_t m_max);  // components of the search path: chunk tables (large frames) or clique-cell grid
+int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota, bool cleared);
 // the neighbour-list workspace is only allocated for the list path
 int lpx_ensure_lists(lpx_ctx *ctx);
 

@@ -1083,12 +1083,14 @@ constexpr int LG = LPX_KD_LG;  // threads of kd_lds_kernel: one wavefront per SI
 template <typename PosT>  // stop-list entries: uint16_t (batches: 20 B of LDS per node) or uint32_t (a single frame)
 __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restrict__ PR,
                                                     const FrameState *__restrict__ frame,
-                                                    uint32_t *__restrict__ dbg, int BLK_CAP, size_t fs)
+                                                    uint32_t *__restrict__ dbg, int BLK_CAP,
+                                                    uint32_t *__restrict__ parent, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<3>(fs);
     nodes = lpx_slot(nodes, fs);
     PR = lpx_slot(PR, fs);
     frame = lpx_slot(frame, fs);
+    parent = lpx_slot(parent, fs);  // (search path: every point its own set before nb_index_kernel links them)
     const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t n_rounds = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1119,7 +1121,10 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
             if (tb < te)
             {
                 const uint32_t mid = (uint32_t)(tb + (te - tb) / 2);
-                PR[kd_rank_of(mid, (uint32_t)M)] = nodes[mid];
+                const Node nm = nodes[mid];
+                PR[kd_rank_of(mid, (uint32_t)M)] = nm;
+                if (parent)
+                    parent[__float_as_uint(nm.w)] = __float_as_uint(nm.w);
             }
         }
     if (n < 1)
@@ -1127,7 +1132,12 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
     if (n == 1)
     {
         if (tid == 0)
-            PR[kd_rank_of((uint32_t)b, (uint32_t)M)] = nodes[b];
+        {
+            const Node n1 = nodes[b];
+            PR[kd_rank_of((uint32_t)b, (uint32_t)M)] = n1;
+            if (parent)
+                parent[__float_as_uint(n1.w)] = __float_as_uint(n1.w);
+        }
         return;
     }
     for (int i = tid; i < n; i += LG)
@@ -1301,6 +1311,8 @@ __global__ __launch_bounds__(LG) void kd_lds_kernel(Node *nodes, Node *__restric
         const Node nd = l_nodes[i];
         nodes[b + i] = nd;
         PR[kd_rank_of((uint32_t)(b + i), (uint32_t)M)] = nd;  // pre-order rank layout for the neighbour search
+        if (parent)
+            parent[__float_as_uint(nd.w)] = __float_as_uint(nd.w);
     }
 }
 
@@ -2022,6 +2034,96 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
 // chunks than lanes the last one is long (covers the rest of the rank range, gaps included: nodes the traversal
 // pruned fail the distance test anyway) and is never culled.  grp_of[point] = gid.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Exact connected components of the d-graph from the chunk tables (replaces the clique-cell grid: eight launches of
+// hash inserts, probes and pointer chases that held 37 % of a chain's resident wavefront time while waiting for memory).
+// The wavefront that has just built the chunk table of a kd group holds the group's <= 64 queries in registers and
+// knows every chunk that can contain a neighbour of any of them; it tests its queries against those candidates --
+// all pairs, 64 queries at once, one candidate per step broadcast from the lane that loaded it -- with the
+// reference's float expression (src/kdtree.hpp:145-157, inclusive).  Every unordered pair is tested once, by the group
+// of its HIGHER pre-order rank (a query only looks at candidates of lower rank).
+// A query does not unite with every neighbour: with a neighbour c only if c is farther than d from the neighbour it
+// linked LAST.  (Induction on the higher rank of a pair: if c is within d of an earlier linked neighbour c', the pair
+// (c', c) -- both of lower rank than the query -- is connected by the time every group has run, and the query is
+// linked to c'.)  That leaves one to three unions per point instead of ~90; they are kept in four registers and done
+// after the scan, all lanes at once (uf_unite: hooks by CAS, stale reads only cost a retry).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void kd_link_queries(const Node *__restrict__ PR, uint32_t *parent, const ChunkRec &rec,
+                                                unsigned long long cmask, float qx, float qy, float qz, uint32_t qidx,
+                                                uint32_t qrank, bool act, uint32_t rank_end, const float *blo,
+                                                const float *bhi, float r2, uint32_t lane)
+{
+    float lx = 0.0f, ly = 0.0f, lz = 0.0f;
+    bool have_last = false;
+    uint32_t l0 = 0xffffffffu, l1 = 0xffffffffu, l2 = 0xffffffffu, l3 = 0xffffffffu;  // pending unions, newest first
+    while (cmask)
+    {
+        const int c = __ffsll((long long)cmask) - 1;
+        cmask &= cmask - 1;
+        const uint32_t crank = (uint32_t)__builtin_amdgcn_readlane((int)rec.rank, c);
+        const uint32_t ccnt = (uint32_t)__builtin_amdgcn_readlane((int)rec.count, c);
+        for (uint32_t o = 0; o < ccnt; o += WAVE)
+        {
+            const uint32_t r0 = crank + o;
+            if (r0 >= rank_end)
+                break;  // ranks ascend inside a chunk: nothing below the group's last rank is left
+            const uint32_t cnt = min((uint32_t)WAVE, min(ccnt - o, rank_end - r0));
+            const Node nd = PR[lane < cnt ? r0 + lane : 0u];
+            // candidates outside the group's box (widened by the radius) cannot be a neighbour of any query
+            const bool near = lane < cnt && nd.x >= blo[0] && nd.x <= bhi[0] && nd.y >= blo[1] && nd.y <= bhi[1] &&
+                              nd.z >= blo[2] && nd.z <= bhi[2];
+            unsigned long long km = __ballot(near);
+            while (km)
+            {
+                const int k = __ffsll((long long)km) - 1;
+                km &= km - 1;
+                const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd.x), k));
+                const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd.y), k));
+                const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd.z), k));
+                const float a0 = qx - cx, a1 = qy - cy, a2 = qz - cz;
+                const float da = a0 * a0 + (a1 * a1 + a2 * a2);
+                const bool hit = act && (r0 + (uint32_t)k) < qrank && da <= r2;
+                if (__ballot(hit) == 0ull)
+                    continue;
+                const float b0 = lx - cx, b1 = ly - cy, b2 = lz - cz;
+                const float db = b0 * b0 + (b1 * b1 + b2 * b2);
+                if (hit && !(have_last && db <= r2))
+                {
+                    if (l3 != 0xffffffffu)
+                        uf_unite(parent, qidx, l3);  // (more than four mutually distant neighbours: rare)
+                    l3 = l2;
+                    l2 = l1;
+                    l1 = l0;
+                    l0 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(nd.w), k);
+                    lx = cx;
+                    ly = cy;
+                    lz = cz;
+                    have_last = true;
+                }
+            }
+        }
+    }
+    if (l0 != 0xffffffffu)
+        uf_unite(parent, qidx, l0);
+    if (l1 != 0xffffffffu)
+        uf_unite(parent, qidx, l1);
+    if (l2 != 0xffffffffu)
+        uf_unite(parent, qidx, l2);
+    if (l3 != 0xffffffffu)
+        uf_unite(parent, qidx, l3);
+}
+
+// (cell table of the component grid, further down; nb_index_kernel empties it)
+constexpr unsigned long long CELL_EMPTY = ~0ull;
+constexpr uint32_t CELL_NONE = 0xffffffffu;
+__device__ __forceinline__ uint32_t cell_cap_for(uint32_t M, uint32_t cap_max)
+{
+    uint32_t cap = 64;
+    while (cap < 2 * M && cap < cap_max)
+        cap <<= 1;
+    return cap;
+}
+
 constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B + prefix = 4.6 KiB)
 #ifndef LPX_IX_BOX_UNROLL
 #define LPX_IX_BOX_UNROLL 4
@@ -2030,10 +2132,35 @@ constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B +
 __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__restrict__ PR,
                                                                const FrameState *__restrict__ frame, float rr,
                                                                ChunkRec *__restrict__ chunks,
-                                                               uint32_t *__restrict__ grp_of, uint32_t spine_max,
-                                                               uint32_t bucket, FV fv)
+                                                               float4 *__restrict__ grp_of, uint32_t spine_max,
+                                                               uint32_t bucket, uint32_t *parent, float r2,
+                                                               unsigned long long *__restrict__ tkey,
+                                                               uint32_t *__restrict__ tparent, uint32_t *__restrict__ thead,
+                                                               uint32_t cap_max, FrameState *__restrict__ wframe, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
+    parent = lpx_slot(parent, fv.fs);
+    if (tkey)
+    {
+        // The cell table of the component grid, which runs right behind this kernel, is emptied here (what
+        // grid_clear_kernel did in a launch of its own: one launch less per chain).  Nothing in this kernel reads it.
+        tkey = lpx_slot(tkey, fv.fs);
+        tparent = lpx_slot(tparent, fv.fs);
+        thead = lpx_slot(thead, fv.fs);
+        wframe = lpx_slot(wframe, fv.fs);
+        const uint32_t cap = cell_cap_for(wframe->n_obstacle, cap_max);
+        for (uint32_t sl = lpx_blk.x * NB_THREADS + threadIdx.x; sl < cap; sl += gridDim.x * NB_THREADS)
+        {
+            tkey[sl] = CELL_EMPTY;
+            tparent[sl] = sl;
+            thead[sl] = 0;
+        }
+        if (lpx_blk.x == 0 && threadIdx.x == 0)
+        {
+            wframe->n_cells = 0;
+            wframe->cell_cursor = 0;
+        }
+    }
     __shared__ Item s_seq[NB_WAVES][2 * IX_CAPS];
     __shared__ uint32_t s_pre[NB_WAVES][IX_CAPS + 8];
     __shared__ uint32_t s_mrank[NB_WAVES][IX_CAPS + 8], s_mpre[NB_WAVES][IX_CAPS + 8];
@@ -2102,7 +2229,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
     const bool active = lane < nq;
     const Node q = PR[g0 + (active ? lane : 0u)];
     if (active)
-        grp_of[__float_as_uint(q.w)] = gid;
+        grp_of[__float_as_uint(q.w)] = make_float4(q.x, q.y, q.z, __uint_as_float(gid));
     float blo[3] = {q.x, q.y, q.z}, bhi[3] = {q.x, q.y, q.z};
     if (nq > (uint32_t)WAVE)
     {
@@ -2110,7 +2237,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
         const Node q2 = PR[g0 + (more ? lane + WAVE : 0u)];
         if (more)
         {
-            grp_of[__float_as_uint(q2.w)] = gid;
+            grp_of[__float_as_uint(q2.w)] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(gid));
             blo[0] = fminf(blo[0], q2.x), blo[1] = fminf(blo[1], q2.y), blo[2] = fminf(blo[2], q2.z);
             bhi[0] = fmaxf(bhi[0], q2.x), bhi[1] = fmaxf(bhi[1], q2.y), bhi[2] = fmaxf(bhi[2], q2.z);
         }
@@ -2289,6 +2416,27 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
     rec.hi[1] = hi1;
     rec.hi[2] = hi2;
     chunks[(size_t)gid * LPX_GROUP_CHUNKS + lane] = rec;
+    if (!parent)
+        return;
+    // ---- the group's share of the connected components (kd_link_queries) ----
+    {
+        const uint32_t rank_end = g0 + nq;
+        // chunks that begin below the group's last rank and whose exact box meets the group's widened box
+        const bool wanted = lane < stored && rec.count != 0u && rec.rank < rank_end && rec.lo[0] <= bhi[0] &&
+                            rec.hi[0] >= blo[0] && rec.lo[1] <= bhi[1] && rec.hi[1] >= blo[1] && rec.lo[2] <= bhi[2] &&
+                            rec.hi[2] >= blo[2];
+        const unsigned long long cmask = __ballot(wanted);
+        kd_link_queries(PR, parent, rec, cmask, q.x, q.y, q.z, __float_as_uint(q.w), g0 + lane, active, rank_end, blo, bhi,
+                        r2, lane);
+        if (nq > (uint32_t)WAVE)
+        {
+            // the one or two queries beyond the 64th (a full bucket with its spine nodes): a second scan for them
+            const bool more = lane + WAVE < nq;
+            const Node q2 = PR[g0 + (more ? lane + WAVE : 0u)];
+            kd_link_queries(PR, parent, rec, cmask, q2.x, q2.y, q2.z, __float_as_uint(q2.w), g0 + WAVE + lane, more,
+                            rank_end, blo, bhi, r2, lane);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2310,8 +2458,6 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
 // the packed index triple; the points of a cell hang on a linked list (head per slot, next per point); union-find
 // over table slots.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned long long CELL_EMPTY = ~0ull;
-constexpr uint32_t CELL_NONE = 0xffffffffu;
 
 // Home slot of a cell: the 2 x 2 x 2 block of cells it belongs to is hashed, the cell's position inside the block
 // picks one of the 8 slots of that 64-byte line -- the 124 partners a cell probes then lie in ~27 lines instead of
@@ -2329,13 +2475,6 @@ __device__ __forceinline__ uint32_t cell_hash(unsigned long long key)
     return ((uint32_t)k << 3) | sub;
 }
 
-__device__ __forceinline__ uint32_t cell_cap_for(uint32_t M, uint32_t cap_max)
-{
-    uint32_t cap = 64;
-    while (cap < 2 * M && cap < cap_max)
-        cap <<= 1;
-    return cap;
-}
 
 __device__ __forceinline__ uint32_t cell_coord(float v, double inv_c)
 {
@@ -2859,12 +2998,15 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
     }
+    // search path: the kernel that writes every node to its final place also makes every point its own set (the
+    // union-find forest nb_index_kernel links); the list path builds its forest from the lists
+    uint32_t *forest = (!ctx->use_lists && lpx_cc_from_chunks(m_max)) ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr;
     if (ctx->cur_b > 1)
         hipLaunchKernelGGL(kd_lds_kernel<uint16_t>, dim3(1u << level, 1, ctx->cur_b), dim3(LG), lds_lds, ctx->stream, nodes,
-                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fs_tag);
+                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, forest, ctx->fs_tag);
     else
         hipLaunchKernelGGL(kd_lds_kernel<uint32_t>, dim3(1u << level, 1, ctx->cur_b), dim3(LG), blk_lds, ctx->stream, nodes,
-                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, ctx->fs_tag);
+                           (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, forest, ctx->fs_tag);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
@@ -2915,7 +3057,22 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
     return LPX_OK;
 }
 
-int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
+// Components of the search path: from the chunk tables (kd_link_queries, inside nb_index_kernel) or from the
+// clique-cell grid (lpx_grid_components).  Both are exact; which is cheaper depends on the cloud.  Measured on MI355X
+// (alone on the device, per launch chain): 64 KITTI frames (53k obstacle points each, ~20k occupied cells) grid 1.77 ms,
+// chunk tables 2.45 ms -- a group's table covers its whole box widened by the radius, ~3000 candidates for 52 queries,
+// and all of them are tested -- and 1990 against 1615 Mpts/s with twenty chains in flight; 32 frames of BASELINE's
+// 1M-point box cloud (318k obstacle points on dense surfaces: many cells, many cell pairs) grid 8.3 ms, chunk tables
+// 5.4 ms, 1134 against 1379 Mpts/s.  Hence by frame size.  LPX_CC=grid / chunks forces one (development build).
+bool lpx_cc_from_chunks(uint32_t m_max)
+{
+    static const char *e = LPX_KNOB("LPX_CC");
+    if (e)
+        return strcmp(e, "grid") != 0;
+    return m_max >= 400000u;
+}
+
+int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2, bool clear_grid)
 {
     if (m_max == 0)
         return LPX_OK;
@@ -2951,12 +3108,16 @@ int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2)
     static const uint32_t ix_spine = LPX_KNOB("LPX_IX_SPINE") ? (uint32_t)atoi(LPX_KNOB("LPX_IX_SPINE")) : 2u;
     hipLaunchKernelGGL(nb_index_kernel, dim3((groups + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b), dim3(NB_THREADS), 0,
                        ctx->stream, (const Node *)ctx->nodes_pre.p, (const FrameState *)ctx->frame.p, rr,
-                       (ChunkRec *)ctx->chunks.p, (uint32_t *)ctx->grp_of.p, ix_spine, bucket, lpx_fv(ctx));
+                       (ChunkRec *)ctx->chunks.p, (float4 *)ctx->grp_of.p, ix_spine, bucket,
+                       lpx_cc_from_chunks(m_max) ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, r2,
+                       clear_grid ? (unsigned long long *)ctx->cell_key.p : (unsigned long long *)nullptr,
+                       (uint32_t *)ctx->cell_parent.p, (uint32_t *)ctx->cell_rep.p, ctx->cell_cap,
+                       (FrameState *)ctx->frame.p, lpx_fv(ctx));
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
 
-int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota)
+int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota, bool cleared)
 {
     if (m_max == 0)
         return LPX_OK;
@@ -2968,15 +3129,17 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     const dim3 blk(256), gc((cap + 255) / 256, 1, ctx->cur_b), gm((m_max + 255) / 256, 1, ctx->cur_b);
     unsigned long long *tkey = (unsigned long long *)ctx->cell_key.p;
     uint32_t *tparent = (uint32_t *)ctx->cell_parent.p, *thead = (uint32_t *)ctx->cell_rep.p;
-    uint32_t *next = (uint32_t *)ctx->parent.p, *cells = (uint32_t *)ctx->lpos.p;  // free in this path
-    hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, thead, ctx->cell_cap,
-                       ctx->fs_tag);
+    // (nothing here touches a buffer of the kd build or of the chunk tables: a forked front end runs them side by side)
+    uint32_t *next = (uint32_t *)ctx->parent.p, *cells = (uint32_t *)ctx->cell_list.p;
+    if (!cleared)  // (nb_index_kernel has emptied the table when it ran right in front of this: one launch less)
+        hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, thead, ctx->cell_cap,
+                           ctx->fs_tag);
     const dim3 gi((m_max + 256 * LPX_GRID_INSERT_ITEMS - 1) / (256 * LPX_GRID_INSERT_ITEMS), 1, ctx->cur_b);
     hipLaunchKernelGGL(grid_insert_kernel, gi, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells,
                        (uint32_t *)ctx->cell_of.p, (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fs_tag);
     uint32_t *tstart = (uint32_t *)ctx->cell_start.p;
-    float4 *cpts = (float4 *)ctx->nodes.p;  // the array-layout kd nodes are consumed by the build: free here
+    float4 *cpts = (float4 *)ctx->cell_pts.p;
     hipLaunchKernelGGL(grid_alloc_kernel, gm, blk, 0, ctx->stream, frame, (const uint32_t *)cells, (const uint32_t *)thead,
                        tstart, ctx->fs_tag);
     hipLaunchKernelGGL(grid_scatter_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, (const float *)ctx->OX.p,

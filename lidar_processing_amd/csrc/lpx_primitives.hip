@@ -181,10 +181,15 @@ constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_GROUPS = 4;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 
-// in == out is allowed (no __restrict__): every thread reads its inputs before it writes them
-__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint32_t *in, uint32_t *out, uint32_t n_max,
-                                                             const uint32_t *d_n, uint64_t *d_total, size_t fs)
+// in == out is allowed (no __restrict__): every thread reads its inputs before it writes them.
+// THREADS: 1024 for a frame alone on the device; 256 inside launch chains -- under load a 1024-thread workgroup waits
+// until ONE compute unit has sixteen free wave slots (scan_kernel: 5 us alone, 0.86 ms with twenty chains in flight,
+// twice what the other small kernels of a chain wait), a 256-thread workgroup fits anywhere.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_kernel(const uint32_t *in, uint32_t *out, uint32_t n_max,
+                                                        const uint32_t *d_n, uint64_t *d_total, size_t fs)
 {
+    constexpr int SCAN_THREADS = THREADS, SCAN_WAVES = THREADS / WAVE;
     const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t wsum[2][SCAN_GROUPS][SCAN_WAVES];
     in = lpx_slot(in, fs);
@@ -386,24 +391,32 @@ static int ensure_hist(lpx_ctx *ctx, uint32_t nblocks)
 int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n,
                        uint64_t *d_total)
 {
-    // long arrays: tile sums (scratch: the radix table, free outside a sort) -> their scan -> tiles with bases
+    // long arrays: tile sums (scratch: the radix table, free outside a sort) -> their scan -> tiles with bases.
+    // Launch chains of many frames take ONE launch up to half a million elements per frame instead (one 256-thread
+    // workgroup per frame walks its array in steps of 4096): three launches are three waits for a turn on a loaded
+    // device (~0.4 ms each), the walk of a 53k-element array is ~30 us.
     const uint32_t tiles = (n + XS_TILE - 1) / XS_TILE;
-    if (n > 16u * XS_TILE && ctx->hist.p && 64 + sizeof(uint32_t) * (size_t)tiles <= ctx->hist.bytes &&
+    const bool chain = ctx->cur_b > 1;
+    if (n > (chain ? 128u : 16u) * XS_TILE && ctx->hist.p && 64 + sizeof(uint32_t) * (size_t)tiles <= ctx->hist.bytes &&
         (const void *)in != (const void *)((char *)ctx->hist.p + 64))
     {
         uint32_t *sums = (uint32_t *)((char *)ctx->hist.p + 64);
         const dim3 grid(tiles, 1, ctx->cur_b);
         hipLaunchKernelGGL(scan_tiles_kernel<false>, grid, dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, sums,
                            ctx->fs_tag);
-        hipLaunchKernelGGL(scan_kernel, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL(scan_kernel<SCAN_THREADS>, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream,
                            (const uint32_t *)sums, sums, tiles, (const uint32_t *)nullptr, d_total, ctx->fs_tag);
         hipLaunchKernelGGL(scan_tiles_kernel<true>, grid, dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, sums,
                            ctx->fs_tag);
         LPX_HIP(ctx, hipGetLastError());
         return LPX_OK;
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, d_total,
-                       ctx->fs_tag);
+    if (chain)
+        hipLaunchKernelGGL(scan_kernel<256>, dim3(1, 1, ctx->cur_b), dim3(256), 0, ctx->stream, in, out, n, d_n, d_total,
+                           ctx->fs_tag);
+    else
+        hipLaunchKernelGGL(scan_kernel<SCAN_THREADS>, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n,
+                           d_n, d_total, ctx->fs_tag);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

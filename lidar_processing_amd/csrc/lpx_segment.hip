@@ -23,7 +23,14 @@ namespace
 {
 constexpr int SEG_THREADS = 256;
 constexpr int SEG_WAVES = SEG_THREADS / WAVE;
-constexpr uint32_t SEG_CHUNK = 4096;  // points per block (16 per thread; bound for int64 lanes is 256)
+#ifndef LPX_PASS_CHUNK
+#define LPX_PASS_CHUNK 4096
+#endif
+#ifndef LPX_PASS_MINWAVES
+#define LPX_PASS_MINWAVES 1
+#endif
+constexpr uint32_t SEG_CHUNK = LPX_PASS_CHUNK;  // points per block of the plane passes / the compaction (64 per lane of a one-wavefront
+                                      // pass block; the int64 moment lanes hold 256 points: |q| < 2^27, products < 2^54)
 constexpr float FIX_SCALE = 65536.0f;
 constexpr float FIX_LIMIT = 2048.0f;       // below: |q| < 2^27, the int32 / int64 fast path
 constexpr float FIX_CLAMP = 16777216.0f;   // 2^24 m: |q| <= 2^40, the wide path of the rare far points
@@ -879,21 +886,71 @@ __device__ __forceinline__ void seg_block_range(const SegParams &prm, uint32_t s
         hi = lo;
 }
 
-constexpr int PASS_QUADS = 4;  // quads (of four consecutive points) per thread and trip: SEG_CHUNK = 4 * 4 * SEG_THREADS
+// One WAVEFRONT per block.  Every block of a pass pays for the head -- a dependent chain of ~10k cycles on a single
+// instruction stream (the 3x3 Jacobi with its correctly rounded divisions and square roots) -- and with 256-thread
+// blocks three of four wavefronts sat at a barrier meanwhile, holding registers and wave slots (measured: 47 us per
+// pass against 44 us for the atomics-and-ticket form it replaced).  A one-wavefront block has nobody waiting for it:
+// the ~1900 blocks of a 64-frame launch are all resident at once (two per SIMD), their heads overlap one another and
+// the loads of the other blocks, and the block reduction is a DPP reduction without LDS or barriers.
+constexpr int PASS_THREADS = WAVE;
+constexpr int PASS_QUADS = 4;                                           // quads (four consecutive points) per lane and trip
+constexpr uint32_t PASS_TRIP = 4u * PASS_THREADS * PASS_QUADS;          // points of a trip: 1024
+static_assert(SEG_CHUNK % (2u * PASS_TRIP) == 0, "a block is an even number of trips (two register sets alternate)");
+
+typedef float pass_v4f __attribute__((ext_vector_type(4)));
+
+// The plane of pass t - 1 from the 16 moment words (lane l holds word l & 15, every lane the reduced total): the nine
+// quantities that need a 128-bit product, a conversion and a double-precision division -- three centroid coordinates,
+// six covariances -- are computed by nine lanes AT ONCE (one instruction stream either way: nine times fewer
+// instructions than nine evaluations in a row), the same operations in the same order as plane_from_moments, so the
+// results are bit-identical to it and to the oracle.  Then the 3x3 solve, identically on every lane.
+__device__ __forceinline__ bool plane_from_moment_lanes(long long v, uint32_t lane, float *plane)
+{
+    const uint64_t cnt = (uint64_t)__shfl(v, 0, WAVE);
+    if (cnt < 3)
+        return false;
+    // lane 0..2: sums sx, sy, sz (word 1 + lane); lane 3 + k: second moment k = xx, xy, xz, yy, yz, zz (words 4 + 2 k, 5 + 2 k)
+    const int k = (int)lane - 3;
+    const int ka = k < 3 ? 0 : (k < 5 ? 1 : 2);               // first factor of moment k: x, x, x, y, y, z
+    const int kb = k < 3 ? k : (k < 5 ? k - 2 : 2);           // second factor:            x, y, z, y, z, z
+    const bool first = lane < 3, used = lane < 9;
+    const long long lo = __shfl(v, first ? 1 + (int)lane : (used ? 5 + 2 * k : 0), WAVE);
+    const long long hi = __shfl(v, (used && !first) ? 4 + 2 * k : 0, WAVE);
+    const long long ya = __shfl(v, (used && !first) ? 1 + ka : 0, WAVE);
+    const long long zb = __shfl(v, (used && !first) ? 1 + kb : 0, WAVE);
+    const i128 X = first ? (i128)lo : (((i128)hi << 32) + (i128)lo);
+    const i128 N = (i128)cnt;
+    const i128 num = first ? X : (N * X - (i128)ya * (i128)zb);
+    const double n = (double)cnt;
+    const double den = n * (double)(cnt - 1);
+    const double inv16 = 1.0 / 65536.0, inv32 = inv16 * inv16;
+    const float r = (float)((i128_to_double(num) / (first ? n : den)) * (first ? inv16 : inv32));
+#define LPX_RL(l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), (l)))
+    const float cx = LPX_RL(0), cy = LPX_RL(1), cz = LPX_RL(2);
+    const float cxx = LPX_RL(3), cxy = LPX_RL(4), cxz = LPX_RL(5), cyy = LPX_RL(6), cyz = LPX_RL(7), czz = LPX_RL(8);
+#undef LPX_RL
+    const float cov[9] = {cxx, cxy, cxz, cxy, cyy, cyz, cxz, cyz, czz};
+    float vv[9];
+    if (!jacobi_svd3(cov, vv))
+        return false;
+    const float a = vv[2], b = vv[5], c = vv[8];
+    plane[0] = a;
+    plane[1] = b;
+    plane[2] = c;
+    plane[3] = (a * cx + b * cy) + c * cz;
+    return true;
+}
 
 template <bool FINAL>
-__global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__restrict__ XS,
-                                                                  const float *__restrict__ YS,
-                                                                  const float *__restrict__ ZS, SegParams prm,
-                                                                  uint32_t t, SegState *st, long long *part,
-                                                                  long long *facc, uint8_t *__restrict__ flags,
-                                                                  uint32_t *__restrict__ blk_counts,
-                                                                  const FrameState *__restrict__ frame, size_t fs)
+__global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_kernel(const float *__restrict__ XS,
+                                                                   const float *__restrict__ YS,
+                                                                   const float *__restrict__ ZS, SegParams prm,
+                                                                   uint32_t t, SegState *st, long long *part,
+                                                                   long long *facc, uint8_t *__restrict__ flags,
+                                                                   uint32_t *__restrict__ blk_counts,
+                                                                   const FrameState *__restrict__ frame, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<2>(fs);
-    __shared__ long long red[SEG_WAVES][LPX_ACC_WORDS];
-    __shared__ long long s_far[LPX_FAR_WORDS];
-    __shared__ SegState s_st;
     XS = lpx_slot(XS, fs);
     YS = lpx_slot(YS, fs);
     ZS = lpx_slot(ZS, fs);
@@ -906,100 +963,96 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     seg_bind(prm, frame);
     const bool any_far = frame->has_far != 0;
     const uint32_t s = lpx_blk.y, b = lpx_blk.x;
-    const uint32_t tid = threadIdx.x, lane = tid % WAVE, w = tid / WAVE;
+    const uint32_t lane = threadIdx.x;
     const uint32_t nb = prm.P * prm.bps;
     uint32_t base, lo, hi;
     seg_block_range(prm, s, b, base, lo, hi);
-    const uint32_t trips = prm.chunk / (4u * SEG_THREADS * PASS_QUADS);  // 1 unless the segment exceeds 2^20 points
+    const uint32_t trips = prm.chunk / PASS_TRIP;  // even (seg_geometry)
 
-    // ---- the first sixteen points of every thread are requested before anything else ----
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f x4[PASS_QUADS], y4[PASS_QUADS], z4[PASS_QUADS];
-    auto load_trip = [&](uint32_t trip) {
-#pragma unroll
-        for (int u = 0; u < PASS_QUADS; ++u)
-        {
-            const uint32_t p = base + 4u * (tid + SEG_THREADS * (u + PASS_QUADS * trip));
-            if (p < hi)  // (a quad that starts before `hi` may reach past it: the arrays carry 16 spare elements)
-            {
-                x4[u] = *(const v4f *)(XS + p);
-                y4[u] = *(const v4f *)(YS + p);
-                z4[u] = *(const v4f *)(ZS + p);
-            }
-        }
-    };
-    load_trip(0);
+    // two register sets of four quads per lane: the loads of trip k + 1 are in flight while trip k is processed
+    pass_v4f xa[PASS_QUADS], ya[PASS_QUADS], za[PASS_QUADS], xb[PASS_QUADS], yb[PASS_QUADS], zb[PASS_QUADS];
+#define LPX_PASS_LOAD(X4, Y4, Z4, TRIP)                                                                               \
+    _Pragma("unroll") for (int u = 0; u < PASS_QUADS; ++u)                                                            \
+    {                                                                                                                 \
+        const uint32_t p_ = base + 4u * (lane + PASS_THREADS * (u + PASS_QUADS * (TRIP)));                            \
+        if (p_ < hi) /* (a quad that starts before `hi` may reach past it: the arrays carry 16 spare elements) */     \
+        {                                                                                                             \
+            X4[u] = *(const pass_v4f *)(XS + p_);                                                                     \
+            Y4[u] = *(const pass_v4f *)(YS + p_);                                                                     \
+            Z4[u] = *(const pass_v4f *)(ZS + p_);                                                                     \
+        }                                                                                                             \
+    }
+    // The first trip is requested before anything else and is on its way from HBM while the head runs.  (Measured, per
+    // 64-frame pass chain / per 5M-point frame: one trip ahead 0.198 / 0.115 ms; two trips ahead with 4096-point blocks
+    // 0.302 / 0.120; 2048-point blocks, both trips ahead, 0.262 / 0.150, and 0.367 / 0.166 when held to 128 registers:
+    // every register spent on data in flight costs a resident wavefront -- 168 registers keep three per SIMD, which is
+    // all blocks of a 64-frame launch -- and resident wavefronts are what hides the heads of the others.)
+    LPX_PASS_LOAD(xa, ya, za, 0u)
 
     // ---- head: the state this pass tests against ----
-    const SegState *st_in = st + (size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS;  // set (t - 1) & 1; pass 0: the seed state, set 0
     SegState sst;
     if (t == 0)
-        sst = st[s];
+        sst = st[s];  // the seed state, set 0
     else
     {
-        // plane t - 1 from the partials of pass t - 1: wave 0 reduces the segment's rows (4 rows x 16 words per load
-        // instruction, eight independent loads in flight), one pass of the solve per block
+        // plane t - 1 from the rows pass t - 1 left (set (t - 1) & 1): 4 rows x 16 words per load instruction, eight
+        // independent loads in flight per lane
         const long long *pin = part + (size_t)((t + 1u) & 1u) * prm.part_stride + (size_t)s * prm.bps * LPX_ACC_WORDS;
-        if (w == 0)
+        const uint32_t row = lane >> 4, word = lane & 15u;
+        long long v = 0;
+        for (uint32_t r0 = 0; r0 < prm.bps; r0 += 32)
         {
-            const uint32_t row = lane >> 4, word = lane & 15u;
-            long long v = 0;
-            for (uint32_t r0 = 0; r0 < prm.bps; r0 += 32)
+            long long q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
             {
-                long long q[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                {
-                    const uint32_t r = r0 + row + 4u * k;
-                    q[k] = r < prm.bps ? pin[(size_t)r * LPX_ACC_WORDS + word] : 0ll;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    v += q[k];
+                const uint32_t r = r0 + row + 4u * k;
+                q[k] = r < prm.bps ? pin[(size_t)r * LPX_ACC_WORDS + word] : 0ll;
             }
-            v += __shfl_xor(v, 16, WAVE);
-            v += __shfl_xor(v, 32, WAVE);
-            if (lane < LPX_ACC_WORDS)
-                red[0][lane] = v;
-            if (any_far && lane < LPX_FAR_WORDS)
-                s_far[lane] = facc[((size_t)((t - 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane];
-            if (any_far && b == 0 && lane < LPX_FAR_WORDS)  // the set pass t + 1 accumulates into: read by pass t - 1, free
-                facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v += q[k];
         }
-        __syncthreads();
-        if (w == 0)
+        v += __shfl_xor(v, 16, WAVE);
+        v += __shfl_xor(v, 32, WAVE);  // every lane: the segment's total of word lane & 15
+        SegState o = st[(size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS + s];
+        if (o.failed == 0)
         {
-            // every lane of the wave computes the same scalars (no divergence, one pass through the solve)
-            long long m[LPX_ACC_WORDS];
+            float plane[4];
+            bool ok;
+            if (any_far)
+            {
+                // rare (a coordinate beyond +-2048 m): the far-point limbs join the sums; the plain evaluation
+                long long m[LPX_ACC_WORDS], fm[LPX_FAR_WORDS];
 #pragma unroll
-            for (int i = 0; i < LPX_ACC_WORDS; ++i)
-                m[i] = red[0][i];
-            SegState o = st_in[s];
-            if (o.failed == 0)
-            {
-                float plane[4];
-                // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
-                if (!plane_from_moments(m, any_far ? s_far : nullptr, plane))
-                    o.failed = 1;
-                else
-                {
-                    o.plane[0] = plane[0];
-                    o.plane[1] = plane[1];
-                    o.plane[2] = plane[2];
-                    o.plane[3] = plane[3];
-                    o.thr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
-                    o.fitted = 1;
-                }
+                for (int i = 0; i < LPX_ACC_WORDS; ++i)
+                    m[i] = __shfl(v, i, WAVE);
+                const long long *fin = facc + ((size_t)((t - 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS;
+                for (int i = 0; i < LPX_FAR_WORDS; ++i)
+                    fm[i] = fin[i];
+                ok = plane_from_moments(m, fm, plane);
             }
-            if (lane == 0)
+            else
+                ok = plane_from_moment_lanes(v, lane, plane);
+            // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
+            if (!ok)
+                o.failed = 1;
+            else
             {
-                s_st = o;
-                if (b == 0)
-                    st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s] = o;  // what the compaction hands out as planes
+                o.plane[0] = plane[0];
+                o.plane[1] = plane[1];
+                o.plane[2] = plane[2];
+                o.plane[3] = plane[3];
+                o.thr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
+                o.fitted = 1;
             }
         }
-        __syncthreads();
-        sst = s_st;
+        if (b == 0 && lane == 0)
+            st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s] = o;  // what the compaction hands out as planes
+        // the far set pass t + 1 accumulates into was read by pass t - 1 and is free
+        if (any_far && b == 0 && lane < LPX_FAR_WORDS)
+            facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
+        sst = o;
     }
     const bool skip = sst.failed == 2;       // < 3 points: nothing labelled
     const bool dead = sst.failed != 0;       // all obstacle
@@ -1012,14 +1065,11 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
     uint32_t cnt_g = 0, cnt_o = 0;
 
-    for (uint32_t trip = 0; trip < trips; ++trip)
-    {
-        if (trip)
-            load_trip(trip);
+    auto process = [&](const pass_v4f *x4, const pass_v4f *y4, const pass_v4f *z4, uint32_t trip) {
 #pragma unroll
         for (int u = 0; u < PASS_QUADS; ++u)
         {
-            const uint32_t p0 = base + 4u * (tid + SEG_THREADS * (u + PASS_QUADS * trip));
+            const uint32_t p0 = base + 4u * (lane + PASS_THREADS * (u + PASS_QUADS * trip));
             if (p0 >= hi)
                 continue;
             uint32_t fword = 0;
@@ -1075,7 +1125,18 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
                             flags[p0 + e] = (uint8_t)(fword >> (8 * e));
             }
         }
+    };
+    for (uint32_t trip = 0; trip < trips; trip += 2)
+    {
+        LPX_PASS_LOAD(xb, yb, zb, trip + 1u)
+        process(xa, ya, za, trip);
+        if (trip + 2 < trips)
+        {
+            LPX_PASS_LOAD(xa, ya, za, trip + 2u)
+        }
+        process(xb, yb, zb, trip + 1u);
     }
+#undef LPX_PASS_LOAD
 
     if (FINAL)
     {
@@ -1083,27 +1144,16 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
         cnt_o = lpx_wave_sum_u32(cnt_o);
         if (lane == 0)
         {
-            red[w][0] = cnt_g;
-            red[w][1] = cnt_o;
-        }
-        __syncthreads();
-        if (tid == 0)
-        {
-            uint32_t g = 0, o = 0;
-            for (int i = 0; i < SEG_WAVES; ++i)
-            {
-                g += (uint32_t)red[i][0];
-                o += (uint32_t)red[i][1];
-            }
-            blk_counts[s * prm.bps + b] = g;
-            blk_counts[nb + s * prm.bps + b] = o;
+            blk_counts[s * prm.bps + b] = cnt_g;
+            blk_counts[nb + s * prm.bps + b] = cnt_o;
             if (s == 0 && b == 0)
                 blk_counts[2 * nb] = 0;  // sentinel: the exclusive scan leaves the grand total here
         }
         return;
     }
 
-    // 16 words: n, sx, sy, sz, then (hi, lo) limbs of the six second moments
+    // 16 words: n, sx, sy, sz, then (hi, lo) limbs of the six second moments; this block's row of set t & 1 -- one
+    // 128-byte line, written whole, read by every block of the segment in the head of the next launch
     long long v[LPX_ACC_WORDS];
     v[0] = a_n;
     v[1] = a_x;
@@ -1118,21 +1168,13 @@ __global__ __launch_bounds__(SEG_THREADS) void plane_pass_kernel(const float *__
     }
 #pragma unroll
     for (int i = 0; i < LPX_ACC_WORDS; ++i)
+        v[i] = lpx_wave_sum_i64(v[i]);  // valid in lane 0
+    if (lane == 0)
     {
-        v[i] = lpx_wave_sum_i64(v[i]);
-        if (lane == 0)
-            red[w][i] = v[i];
-    }
-    __syncthreads();
-    if (tid < LPX_ACC_WORDS)
-    {
-        long long tot = 0;
+        long long *row = part + (size_t)(t & 1u) * prm.part_stride + ((size_t)s * prm.bps + b) * LPX_ACC_WORDS;
 #pragma unroll
-        for (int i = 0; i < SEG_WAVES; ++i)
-            tot += red[i][tid];
-        // this block's row of set t & 1: one 128-byte line, written whole, read by every block of the segment in the
-        // head of the next launch
-        part[(size_t)(t & 1u) * prm.part_stride + ((size_t)s * prm.bps + b) * LPX_ACC_WORDS + tid] = tot;
+        for (int i = 0; i < LPX_ACC_WORDS; ++i)
+            row[i] = v[i];
     }
 }
 
@@ -1155,6 +1197,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
 {
     const LpxBlock lpx_blk = lpx_block<0>(fv.fs);
     __shared__ uint32_t wg[SEG_WAVES], wo[SEG_WAVES];
+    __shared__ uint32_t s_base[3][SEG_WAVES];
     flags = lpx_slot(flags, fv.fs);
     sidx = lpx_slot(sidx, fv.fs);
     XS = lpx_slot(XS, fv.fs);
@@ -1177,9 +1220,42 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     const uint32_t nb = prm.P * prm.bps;
     uint32_t base_unused, lo, hi;  // the block's points: the same ranges as the plane passes that counted them
     seg_block_range(prm, s, b, base_unused, lo, hi);
-    const uint32_t total_g = blk_offs[nb];  // exclusive scan over [G blocks | O blocks]
-    const uint32_t gbase = blk_offs[s * prm.bps + b];
-    const uint32_t obase = blk_offs[nb + s * prm.bps + b] - total_g;
+    // The block's offsets into the two output lists from the RAW per-block counts the final plane pass left
+    // ([ground counts | obstacle counts], nb each): every block sums what lies before it by itself -- a few hundred words
+    // at most for a 120k-point frame, L2-resident -- instead of a scan kernel between the two launches (under load every
+    // launch of a chain, however small, waits ~0.4 ms for its turn).
+    const uint32_t me = s * prm.bps + b;
+    uint32_t sg_all = 0, sg_before = 0, so_before = 0, so_all = 0;
+    for (uint32_t i = tid; i < nb; i += SEG_THREADS)
+    {
+        const uint32_t g = blk_offs[i], o = blk_offs[nb + i];
+        sg_all += g;
+        so_all += o;
+        sg_before += i < me ? g : 0u;
+        so_before += i < me ? o : 0u;
+    }
+    sg_all = lpx_wave_sum_u32(sg_all);
+    sg_before = lpx_wave_sum_u32(sg_before);
+    so_before = lpx_wave_sum_u32(so_before);
+    so_all = lpx_wave_sum_u32(so_all);
+    if (lane == 0)
+    {
+        s_base[0][w] = sg_all;
+        s_base[1][w] = sg_before;
+        s_base[2][w] = so_before;
+        wg[w] = so_all;  // (wg / wo are filled with the wave counts further down, after the barrier below)
+    }
+    __syncthreads();
+    uint32_t total_g = 0, gbase = 0, obase = 0, total_o = 0;
+#pragma unroll
+    for (int i = 0; i < SEG_WAVES; ++i)
+    {
+        total_g += s_base[0][i];
+        gbase += s_base[1][i];
+        obase += s_base[2][i];
+        total_o += wg[i];
+    }
+    __syncthreads();
     const unsigned long long lt = lpx_lanemask_lt();
 
     // each wave owns a contiguous quarter of the chunk
@@ -1206,6 +1282,8 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
         gpos += wg[i];
         opos += wo[i];
     }
+    const bool want_hash = gridDim.z == 1;  // single-frame calls: the host may be handed this cloud back (lpx_cluster)
+    uint64_t hsum = 0;
     for (uint32_t p0 = wlo; p0 < whi; p0 += WAVE)
     {
         const uint32_t p = p0 + lane;
@@ -1227,10 +1305,18 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
                 OY[d] = oy;
                 OZ[d] = oz;
                 nodes[d] = make_float4(ox, oy, oz, __uint_as_float(d));  // kd-tree input, KDTree::rebuild :185-189
+                if (want_hash)
+                    hsum += lpx_obstacle_mix(d, __float_as_uint(ox), __float_as_uint(oy), __float_as_uint(oz));
             }
         }
         gpos += __popcll(mg);
         opos += __popcll(mo);
+    }
+    if (want_hash)
+    {
+        hsum = (uint64_t)lpx_wave_sum_i64((long long)hsum);  // wrapping sum, valid in lane 0
+        if (lane == 0 && hsum)
+            atomicAdd((unsigned long long *)&frame->obs_hash, (unsigned long long)hsum);
     }
     if (s == 0 && b == 0)
     {
@@ -1239,9 +1325,8 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
             labels[sidx[p]] = LPX_LABEL_UNKNOWN;
         if (tid == 0)
         {
-            const uint32_t total = blk_offs[2 * nb];
             frame->n_ground = total_g;
-            frame->n_obstacle = frame->status ? 0u : total - total_g;  // a frame in error is not clustered
+            frame->n_obstacle = frame->status ? 0u : total_o;  // a frame in error is not clustered
         }
         if (planes)
             for (uint32_t i = tid; i < prm.P * 4; i += SEG_THREADS)
@@ -1376,17 +1461,17 @@ int lpx_write_counts(lpx_ctx *ctx, uint32_t *d_counts)
 // plane of ALL n points (stride-12 device input) through the moment + Jacobi path; out[0..3] plane, out[4] failed
 // Launch geometry of the plane passes and the compaction from prm.n_per (the largest segment of the call): blocks of
 // SEG_CHUNK points, larger ones once a segment would need more than 256 of them (every block of pass t + 1 reads the
-// rows of ALL blocks of its segment), at most 256 points per thread (the bound of the int64 moment lanes); one block
-// more where a segment's 16-byte-aligned window starts before the segment.
+// rows of ALL blocks of its segment) up to 256 points per lane (the bound of the int64 moment lanes); one block more
+// where a segment's 16-byte-aligned window starts before the segment.
 static void seg_geometry(SegParams &prm, uint32_t cap_n)
 {
     uint32_t chunk = SEG_CHUNK;
-    const uint32_t quantum = 4u * SEG_THREADS * PASS_QUADS;  // a whole number of trips per block
+    const uint32_t quantum = 2u * PASS_TRIP;  // an even number of trips per block
     if (prm.n_per / 256u > chunk)
     {
         chunk = ((prm.n_per / 256u + quantum - 1) / quantum) * quantum;
-        if (chunk > 256u * SEG_THREADS)
-            chunk = 256u * SEG_THREADS;
+        if (chunk > 256u * PASS_THREADS)
+            chunk = 256u * PASS_THREADS;  // 256 points per lane: the bound of the int64 moment lanes
     }
     prm.chunk = chunk;
     prm.bps = prm.n_per ? (prm.n_per + 3u + chunk - 1) / chunk : 1;
@@ -1417,10 +1502,10 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
         launch_ingest(ctx, dim3((n + 255) / 256), d_pts, 12, XS, YS, ZS, nullptr, nullptr, nullptr, frame, nullptr);
     // pass 0 leaves the moments of every point, the head of pass 1 (run as the final pass) solves and publishes the plane
     hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(128), 0, ctx->stream, sst, (long long *)ctx->seg_far.p);
-    hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
+    hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(PASS_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
                        0u, sst, part, (long long *)ctx->seg_far.p, (uint8_t *)ctx->flags.p, (uint32_t *)ctx->blk_counts.p,
                        (const FrameState *)frame, fv.fs);
-    hipLaunchKernelGGL((plane_pass_kernel<true>), dim3(prm.bps, 1), dim3(SEG_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
+    hipLaunchKernelGGL((plane_pass_kernel<true>), dim3(prm.bps, 1), dim3(PASS_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
                        1u, sst, part, (long long *)ctx->seg_far.p, (uint8_t *)ctx->flags.p, (uint32_t *)ctx->blk_counts.p,
                        (const FrameState *)frame, fv.fs);
     hipLaunchKernelGGL(dbg_plane_out_kernel, dim3(1), dim3(64), 0, ctx->stream, sst, d_out);
@@ -1552,18 +1637,14 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         {
             const dim3 g2(prm.bps, P, B);
             for (uint32_t t = 0; t < I; ++t)
-                hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, t, sst, part,
+                hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(PASS_THREADS), 0, st, XS, YS, ZS, prm, t, sst, part,
                                    facc, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
-            hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(SEG_THREADS), 0, st, XS, YS, ZS, prm, I, sst, part,
+            hipLaunchKernelGGL((plane_pass_kernel<true>), g2, dim3(PASS_THREADS), 0, st, XS, YS, ZS, prm, I, sst, part,
                                facc, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);
         }
     }
     {
         StageTimer tm(ctx, ST_COMPACT);
-        // one exclusive scan over [ground counts | obstacle counts | sentinel]
-        rc = lpx_exclusive_scan(ctx, blk_counts, blk_counts, 2 * nb + 1, nullptr, nullptr);
-        if (rc)
-            return rc;
         hipLaunchKernelGGL(compact_kernel, dim3(prm.bps, P, B), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p,
                            sidx, XS, YS, ZS, prm, blk_counts, d_labels, d_gidx, d_oidx, (float *)ctx->OX.p,
                            (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p,

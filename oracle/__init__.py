@@ -91,6 +91,25 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+_sort = None
+
+
+def x_sort_order(x, mode):
+    """index order of the reference's x sort (src/segmentation.cpp:114-122) for equal x, as this image's libstdc++
+    produces it: mode "stable" (the canonical (x, index) order of this repository), "serial" (std::sort: a build
+    without TBB headers) or "tbb" (leaves of <= 500 by std::sort, stable merges: oracle/sort_order.cpp)"""
+    global _sort
+    if _sort is None:
+        path = os.path.join(_HERE, "libsortorder.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", _HERE, "-s", "libsortorder.so"], check=True)
+        _sort = C.CDLL(path)
+    xs = np.ascontiguousarray(x, dtype=np.float32)
+    idx = np.zeros(xs.shape[0], np.uint32)
+    _sort.so_order(_p(xs), C.c_uint32(xs.shape[0]), _p(idx), C.c_int({"stable": 0, "serial": 1, "tbb": 2}[mode]))
+    return idx
+
+
 def _as_points(points):
     """(n,k>=3) float32 C-contiguous array -> (array, stride_bytes)"""
     a = np.ascontiguousarray(points, dtype=np.float32)
@@ -188,6 +207,26 @@ def jacobi_svd3(mat):
     s = np.zeros(3, np.float32)
     lib().orc_jacobi_svd3(_p(a), _p(v), _p(s))
     return v.reshape(3, 3), s
+
+
+class FitTrace:
+    """records every plane fit the oracle makes inside the `with` block: .records is an (n, 16) float32 array of
+    cov[9], plane[4], Jacobi sweeps, point count, failed (test instrumentation, tests/golden/make_jacobi_real.py)"""
+
+    def __init__(self, cap=65536):
+        self.buf = np.zeros((cap, 16), np.float32)
+        self.records = self.buf[:0]
+
+    def __enter__(self):
+        lib().orc_trace_fits(_p(self.buf), C.c_uint32(self.buf.shape[0]))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_trace_count.restype = C.c_uint32
+        n = lib().orc_trace_count()
+        lib().orc_trace_fits(None, C.c_uint32(0))
+        self.records = self.buf[:n].copy()
+        return False
 
 
 def convex_hull(xy):

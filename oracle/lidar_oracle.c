@@ -186,9 +186,32 @@ static void rot_right(float *w, int p, int q, jrot j)
     }
 }
 
+/* Test instrumentation (tests/golden/make_jacobi_real.py): every plane fit of orc_segment / orc_plane_from_points can
+ * be recorded -- the float32 covariance handed to the 3x3 solve, the plane it produced, the sweeps the Jacobi loop
+ * took and the point count -- so that the restated solve is checked against float64 LAPACK on the covariances REAL
+ * frames produce, not only on synthetic matrices.  Off unless orc_trace_fits() hands over a buffer; single-threaded
+ * (the fits of orc_segment run on the calling thread). */
+#define ORC_FIT_RECORD 16 /* floats: cov[9], plane[4], sweeps, n, failed */
+static float *g_fit_trace = NULL;
+static uint32_t g_fit_cap = 0, g_fit_count = 0;
+static int g_last_sweeps = 0;
+
+void orc_trace_fits(float *buf, uint32_t cap_records)
+{
+    g_fit_trace = buf;
+    g_fit_cap = buf ? cap_records : 0;
+    g_fit_count = 0;
+}
+
+uint32_t orc_trace_count(void)
+{
+    return g_fit_count;
+}
+
 /* returns 0 on success, 1 if the input is not finite (Eigen: InvalidInput) */
 static int jacobi_svd3(const float *a, float *v, float *sigma)
 {
+    g_last_sweeps = 0;
     float w[9];
     float scale = 0.0f;
     for (int i = 0; i < 9; ++i)
@@ -214,6 +237,7 @@ static int jacobi_svd3(const float *a, float *v, float *sigma)
     while (!finished)
     {
         finished = 1;
+        ++g_last_sweeps;
         for (int p = 1; p < 3; ++p)
         {
             for (int q = 0; q < p; ++q)
@@ -383,14 +407,28 @@ static int plane_from_moments(const moments *m, float *plane)
     const float czz = (float)((i128_to_double(N * m->szz - m->sz * m->sz) / den) * inv40);
     const float cov[9] = {cxx, cxy, cxz, cxy, cyy, cyz, cxz, cyz, czz};
     float v[9];
-    if (jacobi_svd3(cov, v, NULL))
-        return 1;
+    const int failed = jacobi_svd3(cov, v, NULL);
     const float a = v[2], b = v[5], c = v[8];
-    plane[0] = a;
-    plane[1] = b;
-    plane[2] = c;
-    plane[3] = (a * cx + b * cy) + c * cz;
-    return 0;
+    if (!failed)
+    {
+        plane[0] = a;
+        plane[1] = b;
+        plane[2] = c;
+        plane[3] = (a * cx + b * cy) + c * cz;
+    }
+    if (g_fit_trace && g_fit_count < g_fit_cap)
+    {
+        float *r = g_fit_trace + (size_t)ORC_FIT_RECORD * g_fit_count++;
+        memcpy(r, cov, sizeof cov);
+        r[9] = failed ? 0.0f : plane[0];
+        r[10] = failed ? 0.0f : plane[1];
+        r[11] = failed ? 0.0f : plane[2];
+        r[12] = failed ? 0.0f : plane[3];
+        r[13] = (float)g_last_sweeps;
+        r[14] = (float)m->n;
+        r[15] = (float)failed;
+    }
+    return failed;
 }
 
 int orc_plane_from_points(const float *xyz, uint32_t n, float *plane)

@@ -102,6 +102,10 @@ int orc_plane_from_points(const float *xyz, uint32_t n, float *plane);
 
 /* Eigen 3.4 JacobiSVD<Matrix3f> restated: V of a 3x3 float matrix (row-major in/out) */
 void orc_jacobi_svd3(const float *a, float *v, float *sigma);
+/* test instrumentation: record every plane fit (16 floats per fit: cov[9], plane[4], Jacobi sweeps, points, failed)
+ * into buf until cap_records are full; NULL switches it off.  orc_trace_count(): fits recorded so far. */
+void orc_trace_fits(float *buf, uint32_t cap_records);
+uint32_t orc_trace_count(void);
 
 /* N3: Andrew monotone chain, counter-clockwise, collinear points excluded (restated published algorithm; the
  * reference's own implementation lives in the un-vendored Convex-Hull submodule: PARITY UNPINNED).

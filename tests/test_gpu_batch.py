@@ -393,3 +393,44 @@ def test_xcd_affine_launch_geometry_is_a_bijection(mask):
     r = subprocess.run([sys.executable, os.path.join(here, "remap_check.py")], env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "remap check ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("method", ["chunks", "grid"])
+def test_both_component_searches_give_the_single_frame_results(method):
+    """the search path finds the connected components of the d-graph either from the kd groups' chunk tables (the
+    default for frames of 400k points and more) or from the clique-cell grid (smaller frames); LPX_CC forces one --
+    development library, read once per process, hence the subprocess.  Ragged batches in both neighbour modes against
+    the single-frame path (tests/remap_check.py)"""
+    import os
+    import subprocess
+    import sys
+    from lidar_processing_amd import _lib
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, LPX_CC=method, LPX_LIB=_lib.DEV_LIB_PATH,
+               PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(here, "remap_check.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "remap check ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_forked_front_end_gives_the_same_results():
+    """lpx_set_fork: the component grid of a chain on a side stream beside its kd build and chunk tables -- alone and
+    together with lpx_set_overlap, several calls back to back on one context"""
+    clouds = [load_frame(f)[:30_000 + 3000 * i] for i, f in enumerate(FRAMES * 3)]
+    refs = None
+    one = Context(0)
+    try:
+        refs = [single(one, c, SEG, CLU) for c in clouds]
+    finally:
+        one.close()
+    for overlap in (False, True):
+        bctx = Context(0, batch=len(clouds))
+        try:
+            if overlap:
+                bctx.set_overlap(True)
+            bctx.set_fork(True)
+            for _ in range(3):
+                for res, ref in zip(run_batch(bctx, clouds, SEG, CLU), refs):
+                    check_frame(res, ref)
+        finally:
+            bctx.close()

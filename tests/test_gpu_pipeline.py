@@ -253,7 +253,7 @@ def test_list_path_and_search_path_agree(frame):
             c.close()
     assert stats[True]["expansions"] == stats[False]["expansions"]          # the same radius_search calls
     assert stats[True]["replay_entries"] == stats[False]["replay_entries"]  # ... returning the same neighbours
-    assert stats[False]["components"] <= stats[True]["components"]         # grid sets are unions of components
+    assert stats[False]["components"] == stats[True]["components"]         # both paths: the exact components of the d-graph
 
 
 def test_cluster_exact_ec_quality_one(ctx):
@@ -484,6 +484,71 @@ def test_cxx_dropin_headers_run_like_processor(ctx, tmp_path):
     wl, wn = oracle.cluster(pts[want["obstacle_idx"]])
     assert np.array_equal(clu_labels, wl)
     assert nc == wn  # every valid label owns at least one point, so no empty cluster is erased
+
+
+def test_cluster_recognises_the_cloud_segment_left_on_the_device():
+    """processor.cpp:150-178 on ONE context: lpx_cluster of exactly the obstacle cloud lpx_segment has just produced
+    runs on the resident copy (size + position-bound checksum), every other cloud is uploaded: a second clustering of
+    the same cloud (the kd build consumed its input), the cloud with one coordinate changed, with two points swapped,
+    with one point fewer -- all give the reference's labels for the cloud that was PASSED"""
+    from lidar_processing_amd import Context
+    pts = load_frame("0000000077")
+    scfg, ccfg = SegmentationConfiguration(number_of_planar_partitions=6, number_of_iterations=5), ClusteringConfiguration(0.25, 0.5)
+    ocfg = oracle.CluCfg(0.25, 0.5)
+    for mode in ("lists", "search"):
+        c = Context(0)
+        try:
+            c.set_neighbour_mode(mode)
+            _, gi, oi, _ = c.segment(pts, scfg)
+            obs = np.ascontiguousarray(pts[oi])
+            want, wn = oracle.cluster(obs, ocfg)
+            g, o = c.coloured_clouds(len(gi), len(oi))        # what the node does between the two calls
+            lab, nc = c.cluster(obs, ccfg)                    # resident
+            assert nc == wn and np.array_equal(lab, want), mode
+            g2, o2 = c.coloured_clouds(len(gi), len(oi))      # the segmentation's clouds are still in place
+            assert np.array_equal(g, g2) and np.array_equal(o, o2)
+            lab, nc = c.cluster(obs, ccfg)                    # again: uploaded this time
+            assert nc == wn and np.array_equal(lab, want), mode
+            for variant in ("coordinate", "swap", "shorter"):
+                _, gi, oi, _ = c.segment(pts, scfg)
+                other = np.ascontiguousarray(pts[oi])
+                if variant == "coordinate":
+                    other[len(other) // 2, 1] += 0.001
+                elif variant == "swap":
+                    other[[10, 20000]] = other[[20000, 10]]
+                else:
+                    other = other[:-1].copy()
+                lab, nc = c.cluster(other, ccfg)
+                w2, n2 = oracle.cluster(other, ocfg)
+                assert nc == n2 and np.array_equal(lab, w2), (mode, variant)
+        finally:
+            c.close()
+
+
+def test_cxx_dropin_latency_harness_shares_one_context(tmp_path):
+    """tests/cxx/dropin_latency.cpp (what bench.py times as the unchanged node's two calls): default-constructed
+    Segmenter + Clusterer share one context and give the clusters of two objects with a context each"""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "dropin_latency"
+    cmd = ["g++", "-std=c++17", "-O2", f"-I{root}/include", f"-I{root}/include/lidar_processing",
+           f"-I{root}/tests/cxx", f"{root}/tests/cxx/dropin_latency.cpp", "-o", str(exe),
+           f"-L{root}/lidar_processing_amd", "-llpx", f"-Wl,-rpath,{root}/lidar_processing_amd",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    pts = load_frame("0000000000")
+    fin = tmp_path / "in.f32"
+    pts.tofile(fin)
+    r = subprocess.run([str(exe), str(fin), "5", "6", "5", "0.25"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    want = oracle.segment(pts, oracle.SegCfg(number_of_planar_partitions=6, number_of_iterations=5))
+    wl, wn = oracle.cluster(pts[want["obstacle_idx"]], oracle.CluCfg(0.25, 0.5))
+    assert d["obstacle_points"] == len(want["obstacle_idx"]) and d["clusters"] == wn
+    assert 0 < d["segment_plus_cluster_ms"] < 100
 
 
 def test_full_size_5m_label_for_label(ctx):
