@@ -55,11 +55,15 @@ PROFILE_ROUND = "r03"  # committed rocprofv3 summaries this line points at: prof
 WORKLOADS = {
     "kitti": dict(config="configs[1]: 120k-pt KITTI frames (three frames cycled), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                   seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
-                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=1280, batch=64, contexts=20),
+                  clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=1024, batch=64, contexts=16),
+    # The headline shape is the fastest one whose p99 frame completion stays inside the reference's 100 ms frame budget
+    # (reference README.md:4): sixteen closed loops of 64-frame chains, 1024 frames in flight (p99 ~ 90 ms).  Twenty
+    # contexts (1280 in flight: round 3's headline) give 1-2 % more at a p99 of 101-115 ms: reported as
+    # `beyond_latency_budget`, measured by a child process.
     "stream": dict(config="configs[1] parameters on configs[3]'s frames: all 154 data/*.pcd 120k-pt KITTI frames in order "
-                          "(the sequence cycled: 1280 frames per step), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
+                          "(the sequence cycled: 1024 frames per step), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
                    seg=dict(number_of_planar_partitions=6, number_of_iterations=5),
-                   clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=1280, batch=64, contexts=20),
+                   clu=dict(distance_squared=0.25, cluster_quality=0.5), frames_per_step=1024, batch=64, contexts=16),
     "synth1m": dict(config="configs[2]: synthetic 1M-pt plane + boxes, 12 segments, 3 iters, FEC d=0.3 m q=0.5",
                     seg=dict(number_of_planar_partitions=12, number_of_iterations=3),
                     clu=dict(distance_squared=0.09, cluster_quality=0.5), frames_per_step=256, batch=32, contexts=8),
@@ -749,7 +753,8 @@ def inflight_curve(plan, lpx, seconds=0.6):
               (1, 4, "search", False), (1, 4, "lists", False), (16, 1, "lists", False), (2, 8, "search", False),
               (2, 8, "lists", False), (1, 16, "search", False), (1, 16, "lists", False),
               (8, 8, "search", False), (8, 8, "lists", False), (2, 32, "search", False), (2, 32, "lists", False), (4, 32, "search", False), (8, 32, "search", False),
-              (20, 32, "search", False), (plan.C, plan.B, own, plan.overlap)]  # the last row: the headline's own shape
+              (20, 32, "search", False), (20, 64, "search", False),
+              (plan.C, plan.B, own, plan.overlap)]  # the last row: the headline's own shape
     rows = []
     F = plan.F
     for C, B, mode, ovl in shapes:
@@ -908,12 +913,15 @@ def main(argv=None):
         except Exception as e:
             feeder_child = {"error": repr(e)[:200]}
         try:
-            d4 = child(["--workload", "stream", "--overlap", "--contexts", "10", "--batch", "64", "--frames-per-step", "640"])
+            d4 = child(["--workload", "stream", "--contexts", "20", "--batch", "64", "--frames-per-step", "1280"])
             overlap_sub = {"mpts_s": d4["value"], "ms_per_step": d4["ms_per_step"],
                            "frames_per_step": d4["config"]["frames_per_step"], "contexts": d4["config"]["contexts_per_gpu"],
                            "frames_per_launch_chain": d4["config"]["frames_per_launch_chain"],
-                           "what": "the same workload with lpx_set_overlap (replay + labels of a chain on a second stream "
-                                   "beside the context's next chain, two slot sets per context), own process"}
+                           "p50_frame_completion_ms": d4["completion"]["p50_frame_completion_ms"],
+                           "p99_frame_completion_ms": d4["completion"]["p99_frame_completion_ms"],
+                           "verified_mismatches": d4["verified"]["mismatches"],
+                           "what": "the same workload with twenty contexts, 1280 frames in flight (round 3's headline "
+                                   "shape): the rate the device gives when the 100 ms frame budget is ignored; own process"}
         except Exception as e:  # a side measurement must never cost the line
             overlap_sub = {"error": repr(e)[:200]}
         try:
@@ -1079,7 +1087,7 @@ def main(argv=None):
         if sub:
             line["kitti_3_frames_cycled"] = sub
         if overlap_sub:
-            line["with_overlap"] = overlap_sub
+            line["beyond_latency_budget"] = overlap_sub
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:

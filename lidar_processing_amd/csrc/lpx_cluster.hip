@@ -31,12 +31,17 @@ enum : uint8_t
     PT_REMOVED = 2
 };
 
-__global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ frame, uint32_t *__restrict__ root,
-                               uint32_t *__restrict__ iota, uint8_t *__restrict__ state,
-                               uint32_t *__restrict__ valid, uint32_t *__restrict__ cc_lo,
-                               uint32_t *__restrict__ cc_hi, size_t fs)
+// One workgroup per radix-sort tile (LPX_SORT_TILE points, eight per thread): the roots are the keys of the component
+// sort that follows, and the tile's histogram of their lowest byte is left where its first pass expects it (hist,
+// block-major; null: not wanted) -- that pass needs no histogram launch of its own.
+__global__ __launch_bounds__(256) void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ frame,
+                                                      uint32_t *__restrict__ root, uint32_t *__restrict__ iota,
+                                                      uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
+                                                      uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi,
+                                                      uint32_t *__restrict__ hist, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<6>(fs);
+    __shared__ uint32_t h[256];
     parent = lpx_slot(parent, fs);
     frame = lpx_slot(frame, fs);
     root = lpx_slot(root, fs);
@@ -45,23 +50,42 @@ __global__ void flatten_kernel(uint32_t *parent, const FrameState *__restrict__ 
     valid = lpx_slot(valid, fs);
     cc_lo = lpx_slot(cc_lo, fs);
     cc_hi = lpx_slot(cc_hi, fs);
-    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
-    if (i >= frame->n_obstacle)
-        return;
-    uint32_t x = i;
-    for (; !frame->status;)  // (a frame whose lists did not fit has no forest: every point its own root)
+    hist = lpx_slot(hist, fs);
+    const uint32_t tid = threadIdx.x, M = frame->n_obstacle;
+    const bool forest = !frame->status;  // (a frame whose lists did not fit has no forest: every point its own root)
+    if (hist)
     {
-        const uint32_t p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p == x)
-            break;
-        x = p;
+        h[tid] = 0;
+        __syncthreads();
     }
-    root[i] = x;
-    iota[i] = i;
-    state[i] = PT_FRESH;
-    valid[i] = 0;
-    cc_lo[i] = 0;
-    cc_hi[i] = 0;
+#pragma unroll 2
+    for (uint32_t r = 0; r < LPX_SORT_TILE / 256u; ++r)
+    {
+        const uint32_t i = lpx_blk.x * LPX_SORT_TILE + r * 256u + tid;
+        if (i >= M)
+            continue;
+        uint32_t x = i;
+        while (forest)
+        {
+            const uint32_t p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p == x)
+                break;
+            x = p;
+        }
+        root[i] = x;
+        iota[i] = i;
+        state[i] = PT_FRESH;
+        valid[i] = 0;
+        cc_lo[i] = 0;
+        cc_hi[i] = 0;
+        if (hist)
+            atomicAdd(&h[x & 255u], 1u);
+    }
+    if (hist)
+    {
+        __syncthreads();
+        hist[lpx_blk.x * 256u + tid] = h[tid];
+    }
 }
 
 // sorted by root (stable): members of a component are contiguous, ascending original index.
@@ -739,6 +763,14 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 if (am)
                     ch_first = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, __ffsll((long long)am) - 1) *
                                           LPX_GROUP_CHUNKS + lane];
+#ifdef LPX_RS_PAIR
+                // (pair pipeline: the table of the SECOND alive candidate too -- it is expanded unless the first absorbs it)
+                const unsigned long long am2 = am & (am - 1);
+                const int h2 = am2 ? __ffsll((long long)am2) - 1 : -1;
+                ChunkRec ch_second = ch_first;
+                if (h2 >= 0)
+                    ch_second = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, h2) * LPX_GROUP_CHUNKS + lane];
+#endif
                 while (am)
                 {
                     const int h = __ffsll((long long)am) - 1;
@@ -761,6 +793,80 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 // does not depend on the point states, so the searches are software-pipelined: the chunk table of
                 // expansion i + 1 is requested before expansion i is searched, and the first candidate batch of i + 1
                 // goes out before the hits of i are applied (the LDS work of the apply then runs under those loads).
+#ifdef LPX_RS_PAIR
+                // TWO expansions in flight: the candidate batches of expansions A and B go out together (a search does
+                // not depend on the point states), the tables of the next pair are requested behind them, then A's
+                // candidates are tested and its hits applied, then B's -- one round trip per PAIR of expansions where
+                // the single pipeline pays one per expansion.
+#define LPX_RS_Q(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
+                int eA = __ffsll((long long)em) - 1;
+                em &= em - 1;
+                int eB = em ? __ffsll((long long)em) - 1 : -1;
+                if (eB >= 0)
+                    em &= em - 1;
+                ChunkRec chA = ch_first, chB = ch_second;
+                if (eB >= 0 && eB != h2)
+                    chB = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, eB) * LPX_GROUP_CHUNKS + lane];
+                for (;;)
+                {
+                    const float ax = LPX_RS_Q(wx, eA), ay = LPX_RS_Q(wy, eA), az = LPX_RS_Q(wz, eA);
+                    unsigned long long kmA = rs_cull(chA, ax, ay, az, r2);
+                    RsBatch btA;
+                    rs_issue(btA, PR, chA, kmA, lane);
+                    float bx = 0.0f, by = 0.0f, bz = 0.0f;
+                    unsigned long long kmB = 0;
+                    RsBatch btB;
+                    if (eB >= 0)
+                    {
+                        bx = LPX_RS_Q(wx, eB), by = LPX_RS_Q(wy, eB), bz = LPX_RS_Q(wz, eB);
+                        kmB = rs_cull(chB, bx, by, bz, r2);
+                        rs_issue(btB, PR, chB, kmB, lane);
+                    }
+                    // the tables of the next pair
+                    const int eC = em ? __ffsll((long long)em) - 1 : -1;
+                    const unsigned long long em1 = em & (em - 1);
+                    const int eD = em1 ? __ffsll((long long)em1) - 1 : -1;
+                    ChunkRec chC = chA, chD = chA;
+                    if (eC >= 0)
+                        chC = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, eC) * LPX_GROUP_CHUNKS + lane];
+                    if (eD >= 0)
+                        chD = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, eD) * LPX_GROUP_CHUNKS + lane];
+                    RS_LAP(pf_tab, pf_t);
+                    ++st_exp;
+                    rs_consume(btA, PR, ax, ay, az, r2, thr_f, lane, st_cand, collect);
+                    while (kmA)
+                    {
+                        rs_issue(btA, PR, chA, kmA, lane);
+                        rs_consume(btA, PR, ax, ay, az, r2, thr_f, lane, st_cand, collect);
+                    }
+                    RS_LAP(pf_cand, pf_t);
+                    while (hc)
+                        flush64();  // the hits of A, before any hit of B
+                    RS_LAP(pf_apply, pf_t);
+                    if (eB >= 0)
+                    {
+                        ++st_exp;
+                        rs_consume(btB, PR, bx, by, bz, r2, thr_f, lane, st_cand, collect);
+                        while (kmB)
+                        {
+                            rs_issue(btB, PR, chB, kmB, lane);
+                            rs_consume(btB, PR, bx, by, bz, r2, thr_f, lane, st_cand, collect);
+                        }
+                        RS_LAP(pf_cand, pf_t);
+                        while (hc)
+                            flush64();
+                        RS_LAP(pf_apply, pf_t);
+                    }
+                    if (eC < 0)
+                        break;
+                    eA = eC;
+                    eB = eD;
+                    chA = chC;
+                    chB = chD;
+                    em = eD >= 0 ? (em1 & (em1 - 1)) : em1;
+                }
+#undef LPX_RS_Q
+#else
                 int e = __ffsll((long long)em) - 1;
                 em &= em - 1;
                 ChunkRec ch = ch_first;
@@ -805,6 +911,7 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                     if (e_next < 0)
                         break;
                 }
+#endif
             }
             if (lane == 0)
                 valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;  // :113
@@ -1208,9 +1315,16 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     }
     {
         StageTimer tm(ctx, ST_CC);
+        // (the kernel that writes the roots also counts their lowest byte per sort tile: lpx_sort_first_hist)
+        uint32_t *first_hist = skip_sort ? nullptr : lpx_sort_first_hist(ctx, m_max);
+        const dim3 gtile((m_max + LPX_SORT_TILE - 1) / LPX_SORT_TILE, 1, ctx->cur_b);
         if (ctx->use_lists || lpx_cc_from_chunks(m_max))
-            hipLaunchKernelGGL(flatten_kernel, grd, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
-                               (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, fv.fs);
+            hipLaunchKernelGGL(flatten_kernel, gtile, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
+                               (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, first_hist, fv.fs);
+        else if (grid_cc && !skip_grid)
+            rc = lpx_grid_flatten(ctx, m_max, root, iota, first_hist);
+        if (rc)
+            return rc;
         if (skip_sort)
         {
             sroot = root;
@@ -1218,7 +1332,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         }
         else
             rc = lpx_sort_pairs(ctx, root, (uint32_t *)ctx->key_b.p, iota, (uint32_t *)ctx->val_b.p, m_max,
-                                &frame->n_obstacle, bits_for_count(m_max), &sroot, &members);
+                                &frame->n_obstacle, bits_for_count(m_max), &sroot, &members, first_hist != nullptr);
         if (rc)
             return rc;
         hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, (const uint32_t *)sroot, (const uint32_t *)members, frame,

@@ -312,8 +312,13 @@ struct StageTimer
 // ------------------------------------------------------------------------------------------------
 // stable LSD radix sort, 8 bits per pass over key bits [0, bits); result ends in the *_a buffers
 // (function copies if the pass count is odd).  n is a host upper bound; d_n (optional) the device count.
+// first_hist_ready: the producer of keys_a has left the tile histograms of the lowest key byte in lpx_sort_first_hist()
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
-                   const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out);
+                   const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out,
+                   bool first_hist_ready = false);
+// where a kernel that produces the keys of an n-element sort may leave the first pass's tile histograms (block-major,
+// 256 words per LPX_SORT_TILE keys), or null when the sort would not use them (tables beyond the fused-scan limit)
+uint32_t *lpx_sort_first_hist(lpx_ctx *ctx, uint32_t n);
 int lpx_sort_keys64(lpx_ctx *ctx, uint64_t *keys_a, uint64_t *keys_b, uint32_t n, const uint32_t *d_n, uint32_t bits,
                     uint64_t **keys_out);
 // exclusive scan (u32 in, u32 out, in place allowed); total (u64) written to *d_total if not null.
@@ -364,6 +369,8 @@ void lpx_note_enqueue(lpx_ctx *ctx);
 int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2, bool clear_grid);
 bool lpx_cc_from_chunks(uint32_t m_max);  // components of the search path: chunk tables (large frames) or clique-cell grid
 int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota, bool cleared);
+// the last kernel of the grid path, on ctx->stream: roots per point (+ the first histogram of the sort that follows)
+int lpx_grid_flatten(lpx_ctx *ctx, uint32_t m_max, uint32_t *d_root, uint32_t *d_iota, uint32_t *first_hist);
 // the neighbour-list workspace is only allocated for the list path
 int lpx_ensure_lists(lpx_ctx *ctx);
 

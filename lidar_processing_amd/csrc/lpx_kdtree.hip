@@ -1415,11 +1415,22 @@ __device__ uint32_t nb_traverse(const Node *__restrict__ PR, uint32_t M, uint32_
         cur[0].e = M;
     }
     Coop<WAVE>::sync();
-    for (uint32_t lvl = 0; lvl < D; ++lvl)
+    // TWO levels per round trip: with the node of an unexpanded subtree its two children are requested as well (the
+    // pre-order layout knows where they are), and the item is expanded twice from registers -- every level used to be one
+    // dependent global round trip for the whole wavefront, ten of them for a 53k-point cloud, and a wavefront that waits
+    // holds its slot.  (An odd last level is a single step.)
+    for (uint32_t lvl = 0; lvl < D;)
     {
-        const int axis = (int)(lvl % 3);
+#ifdef LPX_TRAVERSE_ONE_LEVEL
+        const bool two = false;
+#else
+        const bool two = lvl + 1 < D;
+#endif
+        const int axis = (int)(lvl % 3), axis2 = (int)((lvl + 1) % 3);
         const float lo_a = axis == 0 ? blo[0] : (axis == 1 ? blo[1] : blo[2]);
         const float hi_a = axis == 0 ? bhi[0] : (axis == 1 ? bhi[1] : bhi[2]);
+        const float lo_b = axis2 == 0 ? blo[0] : (axis2 == 1 ? blo[1] : blo[2]);
+        const float hi_b = axis2 == 0 ? bhi[0] : (axis2 == 1 ? bhi[1] : bhi[2]);
         uint32_t out_base = 0;
         bool overflow = false;
         for (uint32_t c0 = 0; c0 < n_cur; c0 += WAVE)
@@ -1431,20 +1442,46 @@ __device__ uint32_t nb_traverse(const Node *__restrict__ PR, uint32_t M, uint32_
             if (valid)
                 it = cur[c0 + lane];
             const bool fin = it.e == NB_FINAL;
-            uint32_t cnt = 0, mid = 0;
-            bool goL = false, goR = false;
+            // children of the item's root: left [b, mid) at rank + 1, right [mid + 1, e) at rank + 1 + (mid - b)
+            const uint32_t mid = fin ? 0u : it.b + (it.e - it.b) / 2;
+            const bool hasL = valid && !fin && mid > it.b, hasR = valid && !fin && mid + 1 < it.e;
+            const uint32_t rankL = it.rank + 1, rankR = it.rank + 1 + (mid - it.b);
+            Node nd, ndL, ndR;
+            nd = PR[(valid && !fin) ? it.rank : 0u];
+            ndL = PR[(two && hasL) ? rankL : 0u];
+            ndR = PR[(two && hasR) ? rankR : 0u];
+            uint32_t cnt = 0;
+            bool goL = false, goR = false, goLL = false, goLR = false, goRL = false, goRR = false;
+            uint32_t midL = 0, midR = 0;
             if (valid)
             {
                 if (fin)
                     cnt = 1;
                 else
                 {
-                    mid = it.b + (it.e - it.b) / 2;
-                    const Node nd = PR[it.rank];
-                    const float s = akey(nd, axis);
-                    goL = (mid > it.b) && (s >= lo_a);
-                    goR = (mid + 1 < it.e) && (s <= hi_a);
+                    const float s0 = akey(nd, axis);
+                    goL = hasL && (s0 >= lo_a);
+                    goR = hasR && (s0 <= hi_a);
                     cnt = 1u + (goL ? 1u : 0u) + (goR ? 1u : 0u);
+                    if (two)
+                    {
+                        if (goL)
+                        {
+                            midL = it.b + (mid - it.b) / 2;
+                            const float sl = akey(ndL, axis2);
+                            goLL = (midL > it.b) && (sl >= lo_b);
+                            goLR = (midL + 1 < mid) && (sl <= hi_b);
+                            cnt += (goLL ? 1u : 0u) + (goLR ? 1u : 0u);
+                        }
+                        if (goR)
+                        {
+                            midR = (mid + 1) + (it.e - (mid + 1)) / 2;
+                            const float sr = akey(ndR, axis2);
+                            goRL = (midR > mid + 1) && (sr >= lo_b);
+                            goRR = (midR + 1 < it.e) && (sr <= hi_b);
+                            cnt += (goRL ? 1u : 0u) + (goRR ? 1u : 0u);
+                        }
+                    }
                 }
             }
             const uint32_t incl = lpx_wave_incl_scan_u32(cnt);
@@ -1462,23 +1499,71 @@ __device__ uint32_t nb_traverse(const Node *__restrict__ PR, uint32_t M, uint32_
                 else
                 {
                     Item o;
-                    o.rank = it.rank;
+                    o.rank = it.rank;  // the root itself: a single final node
                     o.b = 1;
                     o.e = NB_FINAL;
                     nxt[pos++] = o;
                     if (goL)
                     {
-                        o.rank = it.rank + 1;
-                        o.b = it.b;
-                        o.e = mid;
-                        nxt[pos++] = o;
+                        if (!two)
+                        {
+                            o.rank = rankL;
+                            o.b = it.b;
+                            o.e = mid;
+                            nxt[pos++] = o;
+                        }
+                        else
+                        {
+                            o.rank = rankL;  // the left child's root, then its two subtrees
+                            o.b = 1;
+                            o.e = NB_FINAL;
+                            nxt[pos++] = o;
+                            if (goLL)
+                            {
+                                o.rank = rankL + 1;
+                                o.b = it.b;
+                                o.e = midL;
+                                nxt[pos++] = o;
+                            }
+                            if (goLR)
+                            {
+                                o.rank = rankL + 1 + (midL - it.b);
+                                o.b = midL + 1;
+                                o.e = mid;
+                                nxt[pos++] = o;
+                            }
+                        }
                     }
                     if (goR)
                     {
-                        o.rank = it.rank + 1 + (mid - it.b);
-                        o.b = mid + 1;
-                        o.e = it.e;
-                        nxt[pos++] = o;
+                        if (!two)
+                        {
+                            o.rank = rankR;
+                            o.b = mid + 1;
+                            o.e = it.e;
+                            nxt[pos++] = o;
+                        }
+                        else
+                        {
+                            o.rank = rankR;
+                            o.b = 1;
+                            o.e = NB_FINAL;
+                            nxt[pos++] = o;
+                            if (goRL)
+                            {
+                                o.rank = rankR + 1;
+                                o.b = mid + 1;
+                                o.e = midR;
+                                nxt[pos++] = o;
+                            }
+                            if (goRR)
+                            {
+                                o.rank = rankR + 1 + (midR - (mid + 1));
+                                o.b = midR + 1;
+                                o.e = it.e;
+                                nxt[pos++] = o;
+                            }
+                        }
                     }
                 }
             }
@@ -1490,6 +1575,7 @@ __device__ uint32_t nb_traverse(const Node *__restrict__ PR, uint32_t M, uint32_
         cur = nxt;
         nxt = t;
         n_cur = out_base;
+        lvl += two ? 2u : 1u;
         Coop<WAVE>::sync();
     }
     uint32_t T = 0;
@@ -2791,24 +2877,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
                 continue;
             if (!FAR && uf_find(tparent, sc) == uf_find(tparent, pc))
                 continue;  // united meanwhile through other pairs
-            // every point of the partner against every point of the cell, until the first pair within d
+            // every point of the partner against every point of the cell, until the first pair within d.  Cells hold
+            // 2.6 points on average: PS points of either run are requested TOGETHER and the pairs are tested from
+            // registers, longer runs go on in steps of PS -- the plain double loop (PS = 1) is a chain of na x nb
+            // dependent 16-byte loads in one lane while the other 63 lanes of the wavefront wait.  Measured on one box,
+            // 16 x 64 KITTI frames in flight / the two linking kernels of a chain alone: PS 1 2000-2014 Mpts/s / 1.65 ms;
+            // PS 2 1996-2012 / 1.53; PS 3 1978 / 1.47; PS 6 1879-1899 / 1.62 -- the wider scans are faster alone and
+            // SLOWER under load (every scanning lane requests 2 PS records whatever its runs hold, and with twenty chains
+            // in flight the memory pipeline is what the kernels queue for), so: two.
+#ifdef LPX_PAIR_SCAN_PS
+            constexpr uint32_t PS = LPX_PAIR_SCAN_PS;
+#else
+            constexpr uint32_t PS = 2;
+#endif
             bool joined = false;
             const float4 *A = cpts + tstart[sc], *B = cpts + tstart[pc];
             const uint32_t na = tcount[sc], nb = tcount[pc];
-            for (uint32_t bi = 0; bi < nb && !joined; ++bi)
-            {
-                const float4 pbp = B[bi];
-                for (uint32_t ai = 0; ai < na; ++ai)
+            for (uint32_t b0 = 0; b0 < nb && !joined; b0 += PS)
+                for (uint32_t a0 = 0; a0 < na && !joined; a0 += PS)
                 {
-                    const float4 pap = A[ai];
-                    const float d0 = pap.x - pbp.x, d1 = pap.y - pbp.y, d2 = pap.z - pbp.z;
-                    if (d0 * d0 + (d1 * d1 + d2 * d2) <= r2)  // dist_sqr, src/kdtree.hpp:145-157, inclusive :315
+                    float4 pa[PS], pb[PS];
+#pragma unroll
+                    for (uint32_t i = 0; i < PS; ++i)
                     {
-                        joined = true;
-                        break;
+                        pa[i] = A[min(a0 + i, na - 1)];
+                        pb[i] = B[min(b0 + i, nb - 1)];
                     }
+#pragma unroll
+                    for (uint32_t j = 0; j < PS; ++j)
+#pragma unroll
+                        for (uint32_t i = 0; i < PS; ++i)
+                        {
+                            const float d0 = pa[i].x - pb[j].x, d1 = pa[i].y - pb[j].y, d2 = pa[i].z - pb[j].z;
+                            // dist_sqr, src/kdtree.hpp:145-157, inclusive :315 (a clamped index repeats a point of the run)
+                            joined = joined || (d0 * d0 + (d1 * d1 + d2 * d2) <= r2);
+                        }
                 }
-            }
             if (joined)
                 uf_unite(tparent, sc, pc);
         }
@@ -2838,13 +2942,18 @@ __global__ void grid_compress_kernel(const FrameState *__restrict__ frame, const
 }
 
 // root[i] = a point of the root cell of point i's set (the same word for all its members), iota, state reset
-__global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *tparent,
-                                    const uint32_t *__restrict__ tstart, const uint32_t *__restrict__ cell_of,
-                                    uint32_t *__restrict__ root, uint32_t *__restrict__ iota,
-                                    uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
-                                    uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi, size_t fs)
+// (one workgroup per radix-sort tile, eight points per thread; hist: the tile's histogram of the lowest byte of the
+// roots for the first pass of the component sort that follows, or null -- see flatten_kernel, lpx_cluster.hip)
+__global__ __launch_bounds__(256) void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32_t *tparent,
+                                                           const uint32_t *__restrict__ tstart,
+                                                           const uint32_t *__restrict__ cell_of,
+                                                           uint32_t *__restrict__ root, uint32_t *__restrict__ iota,
+                                                           uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
+                                                           uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi,
+                                                           uint32_t *__restrict__ hist, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<6>(fs);
+    __shared__ uint32_t h[256];
     frame = lpx_slot(frame, fs);
     tparent = lpx_slot(tparent, fs);
     tstart = lpx_slot(tstart, fs);
@@ -2855,23 +2964,42 @@ __global__ void grid_flatten_kernel(const FrameState *__restrict__ frame, uint32
     valid = lpx_slot(valid, fs);
     cc_lo = lpx_slot(cc_lo, fs);
     cc_hi = lpx_slot(cc_hi, fs);
-    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
-    if (i >= frame->n_obstacle)
-        return;
-    uint32_t x = cell_of[i];
-    for (;;)
+    hist = lpx_slot(hist, fs);
+    const uint32_t tid = threadIdx.x, M = frame->n_obstacle;
+    if (hist)
     {
-        const uint32_t p = __hip_atomic_load(tparent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p == x)
-            break;
-        x = p;
+        h[tid] = 0;
+        __syncthreads();
     }
-    root[i] = tstart[x];  // where the points of the root cell begin: one word per set, below M
-    iota[i] = i;
-    state[i] = 0;
-    valid[i] = 0;
-    cc_lo[i] = 0;
-    cc_hi[i] = 0;
+#pragma unroll 2
+    for (uint32_t r = 0; r < LPX_SORT_TILE / 256u; ++r)
+    {
+        const uint32_t i = lpx_blk.x * LPX_SORT_TILE + r * 256u + tid;
+        if (i >= M)
+            continue;
+        uint32_t x = cell_of[i];
+        for (;;)
+        {
+            const uint32_t p = __hip_atomic_load(tparent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p == x)
+                break;
+            x = p;
+        }
+        const uint32_t rt = tstart[x];  // where the points of the root cell begin: one word per set, below M
+        root[i] = rt;
+        iota[i] = i;
+        state[i] = 0;
+        valid[i] = 0;
+        cc_lo[i] = 0;
+        cc_hi[i] = 0;
+        if (hist)
+            atomicAdd(&h[rt & 255u], 1u);
+    }
+    if (hist)
+    {
+        __syncthreads();
+        hist[lpx_blk.x * 256u + tid] = h[tid];
+    }
 }
 
 __global__ void layout_idx_kernel(const Node *__restrict__ nodes, uint32_t m, uint32_t *__restrict__ out)
@@ -3171,10 +3299,19 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
         hipLaunchKernelGGL(grid_pairs_kernel<true>, dim3(pg1, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
 #undef GP_ARGS
     }
-    hipLaunchKernelGGL(grid_flatten_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, tparent,
-                       (const uint32_t *)tstart, (const uint32_t *)ctx->cell_of.p, d_root, d_iota,
-                       (uint8_t *)ctx->state.p, (uint32_t *)ctx->valid.p, (uint32_t *)ctx->cc_lo.p,
-                       (uint32_t *)ctx->cc_hi.p, ctx->fs_tag);
+    LPX_HIP(ctx, hipGetLastError());
+    return LPX_OK;
+}
+
+int lpx_grid_flatten(lpx_ctx *ctx, uint32_t m_max, uint32_t *d_root, uint32_t *d_iota, uint32_t *first_hist)
+{
+    if (m_max == 0)
+        return LPX_OK;
+    const dim3 gtile((m_max + LPX_SORT_TILE - 1) / LPX_SORT_TILE, 1, ctx->cur_b);
+    hipLaunchKernelGGL(grid_flatten_kernel, gtile, dim3(256), 0, ctx->stream, (const FrameState *)ctx->frame.p,
+                       (uint32_t *)ctx->cell_parent.p, (const uint32_t *)ctx->cell_start.p,
+                       (const uint32_t *)ctx->cell_of.p, d_root, d_iota, (uint8_t *)ctx->state.p,
+                       (uint32_t *)ctx->valid.p, (uint32_t *)ctx->cc_lo.p, (uint32_t *)ctx->cc_hi.p, first_hist, ctx->fs_tag);
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
 {
     const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
-    __shared__ uint32_t dsum[SORT_WAVES];
+    __shared__ uint32_t dsum[SORT_WAVES], dsum2[SORT_WAVES];
+    __shared__ uint32_t gofs[RADIX];
+    __shared__ KeyT stage_k[SORT_TILE];
+    __shared__ uint32_t stage_v[HAS_VALS ? SORT_TILE : 1];
     keys_in = lpx_slot(keys_in, fs);
     keys_out = lpx_slot(keys_out, fs);
     vals_in = lpx_slot(vals_in, fs);
@@ -81,6 +84,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
     KeyT k[SORT_ITEMS];
     uint32_t v[SORT_ITEMS];
     uint32_t loc[SORT_ITEMS];
+    // every global load of the block goes out before anything waits: the eight keys and values of the thread here, the
+    // rows of the histogram table right below (they do not depend on the keys), the ranking after both
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r)
     {
@@ -89,6 +94,41 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
         k[r] = valid ? keys_in[e] : (KeyT)0;
         if (HAS_VALS)
             v[r] = valid ? vals_in[e] : 0u;
+    }
+    // Global offset of (digit tid, this block) = counts of the lower digits in all blocks + counts of this digit in
+    // the lower blocks.  Small tables hold raw counts, block-major: thread tid sums its column (coalesced rows, at
+    // most FUSED_SCAN_MAX_BLOCKS of them).  Large tables (hist_rows_kernel) hold per-digit exclusive prefixes over
+    // the blocks and, behind the table, the 256 digit totals.
+    uint32_t below = 0, t = 0;
+    if (large)
+    {
+        below = offs[tid * nblocks + lpx_blk.x];
+        t = offs[RADIX * nblocks + tid];
+    }
+    else
+    {
+        // (32 rows per trip: the 61 rows of a 123k-point frame are two round trips instead of eight -- this loop was
+        // most of a scatter block's lifetime, and a workgroup that waits holds its wave slots: with twenty chains in
+        // flight the device runs out of wave slots, not of bandwidth)
+        for (uint32_t b0 = 0; b0 < nblocks; b0 += 32)
+        {
+            uint32_t c[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                c[u] = (b0 + u < nblocks) ? offs[(b0 + u) * RADIX + tid] : 0u;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+            {
+                t += c[u];
+                below += (b0 + u < lpx_blk.x) ? c[u] : 0u;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r)
+    {
+        const uint32_t e = chunk + r * WAVE + lane;
+        const bool valid = e < n;
         const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
         unsigned long long m = __ballot(valid);
 #pragma unroll
@@ -112,45 +152,36 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
         loc[r] = old + rank;
     }
     __syncthreads();
-    // Global offset of (digit tid, this block) = counts of the lower digits in all blocks + counts of this digit in
-    // the lower blocks.  Small tables hold raw counts, block-major: thread tid sums its column (coalesced rows, at
-    // most FUSED_SCAN_MAX_BLOCKS of them).  Large tables (hist_rows_kernel) hold per-digit exclusive prefixes over
-    // the blocks and, behind the table, the 256 digit totals.
-    uint32_t below = 0, t = 0;
-    if (large)
-    {
-        below = offs[tid * nblocks + lpx_blk.x];
-        t = offs[RADIX * nblocks + tid];
-    }
-    else
-    {
-        for (uint32_t b0 = 0; b0 < nblocks; b0 += 8)
-        {
-            uint32_t c[8];
+    // Thread tid answers for digit tid: dbase = keys of lower digits in the whole array (exclusive scan of the digit
+    // totals over the workgroup), tl = keys of lower digits in THIS tile (the same for the tile's own counts).
+    uint32_t ctile = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                c[u] = (b0 + u < nblocks) ? offs[(b0 + u) * RADIX + tid] : 0u;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-            {
-                t += c[u];
-                below += (b0 + u < lpx_blk.x) ? c[u] : 0u;
-            }
-        }
-    }
-    uint32_t dbase = 0;
+    for (int ww = 0; ww < SORT_WAVES; ++ww)
+        ctile += wcnt[ww][tid];
+    uint32_t dbase = 0, tl = 0;
     {
-        const uint32_t incl = lpx_wave_incl_scan_u32(t);
+        const uint32_t incl = lpx_wave_incl_scan_u32(t), incl2 = lpx_wave_incl_scan_u32(ctile);
         if (lane == WAVE - 1)
+        {
             dsum[w] = incl;
+            dsum2[w] = incl2;
+        }
         __syncthreads();
         for (uint32_t i = 0; i < w; ++i)
+        {
             dbase += dsum[i];
+            tl += dsum2[i];
+        }
         dbase += incl - t;
+        tl += incl2 - ctile;
     }
-    // digit `tid`: exclusive prefix over waves + global offset of this (digit, block)
+    // The keys are first put in order INSIDE the tile (LDS), then written out position by position: consecutive lanes
+    // hold consecutive positions of the tile, and the ~8 keys a digit owns in a tile of 2048 go to consecutive
+    // addresses -- one 32-byte request instead of eight.  (Written straight from the registers, lane by lane to ~55
+    // different places per store instruction, the kernel was bound by the request rate of its scattered 4-byte stores:
+    // 12 % of a launch chain's resident wavefront time for seven passes.)
     {
-        uint32_t run = dbase + below;
+        uint32_t run = tl;  // digit `tid`: where wavefront ww's keys of the digit start inside the tile
 #pragma unroll
         for (int ww = 0; ww < SORT_WAVES; ++ww)
         {
@@ -158,6 +189,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
             wcnt[ww][tid] = run;
             run += c;
         }
+        gofs[tid] = dbase + below - tl;  // position in the tile -> position in the output, for keys of this digit
     }
     __syncthreads();
 #pragma unroll
@@ -167,10 +199,26 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
         if (e < n)
         {
             const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
-            const uint32_t dst = wcnt[w][d] + loc[r];
-            keys_out[dst] = k[r];
+            const uint32_t lp = wcnt[w][d] + loc[r];
+            stage_k[lp] = k[r];
             if (HAS_VALS)
-                vals_out[dst] = v[r];
+                stage_v[lp] = v[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t tile_base = lpx_blk.x * SORT_TILE;
+    const uint32_t tile_n = tile_base < n ? min(n - tile_base, (uint32_t)SORT_TILE) : 0u;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r)
+    {
+        const uint32_t j = r * SORT_THREADS + tid;
+        if (j < tile_n)
+        {
+            const KeyT kk = stage_k[j];
+            const uint32_t dst = gofs[(uint32_t)(kk >> shift) & (RADIX - 1)] + j;
+            keys_out[dst] = kk;
+            if (HAS_VALS)
+                vals_out[dst] = stage_v[j];
         }
     }
 }
@@ -421,8 +469,16 @@ int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t
     return LPX_OK;
 }
 
+uint32_t *lpx_sort_first_hist(lpx_ctx *ctx, uint32_t n)
+{
+    const uint32_t nblocks = sort_blocks(n);
+    if (nblocks > FUSED_SCAN_MAX_BLOCKS || ensure_hist(ctx, nblocks) != LPX_OK)
+        return nullptr;
+    return (uint32_t *)((char *)ctx->hist.p + 64);
+}
+
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
-                   const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out)
+                   const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out, bool first_hist_ready)
 {
     const uint32_t nblocks = sort_blocks(n);
     int rc = ensure_hist(ctx, nblocks);
@@ -435,8 +491,9 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     const size_t fs = ctx->fs_tag;
     for (uint32_t shift = 0; shift < bits; shift += 8)
     {
-        hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka, n,
-                           d_n, shift, hist, nblocks, !large, fs);
+        if (!(shift == 0 && first_hist_ready && !large))
+            hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka,
+                               n, d_n, shift, hist, nblocks, !large, fs);
         if (large)
             hipLaunchKernelGGL(hist_rows_kernel, dim3(RADIX, 1, B), dim3(SORT_THREADS), 0, ctx->stream, hist, nblocks, fs);
         hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,

@@ -111,13 +111,23 @@ __device__ __forceinline__ float ld_f32(const char *p)
     return __uint_as_float((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24));
 }
 
+// One workgroup per radix-sort tile (LPX_SORT_TILE points, eight per thread): besides the records it leaves the tile's
+// histogram of the lowest key byte where the first pass of the x sort expects it (hist, block-major; null: not wanted),
+// which saves that pass its histogram launch.
+constexpr int INGEST_THREADS = 256;
+constexpr int INGEST_ITEMS = LPX_SORT_TILE / INGEST_THREADS;
+
 template <bool ALIGNED>
-__global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOff off, float *__restrict__ X,
-                              float *__restrict__ Y, float *__restrict__ Z, float4 *__restrict__ P4,
-                              uint32_t *__restrict__ key, uint32_t *__restrict__ val,
-                              FrameState *__restrict__ frame, float4 *__restrict__ nodes, FV fv)
+__global__ __launch_bounds__(INGEST_THREADS) void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOff off,
+                                                                 float *__restrict__ X, float *__restrict__ Y,
+                                                                 float *__restrict__ Z, float4 *__restrict__ P4,
+                                                                 uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                                 FrameState *__restrict__ frame,
+                                                                 float4 *__restrict__ nodes, uint32_t *__restrict__ hist,
+                                                                 FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<0>(fv.fs);
+    __shared__ uint32_t h[256];
     pts += (size_t)lpx_blk.z * fv.upitch * stride;
     P4 = lpx_slot(P4, fv.fs);
     X = lpx_slot(X, fv.fs);
@@ -127,36 +137,60 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
     val = lpx_slot(val, fv.fs);
     frame = lpx_slot(frame, fv.fs);
     nodes = lpx_slot(nodes, fv.fs);
-    const uint32_t i = lpx_blk.x * blockDim.x + threadIdx.x;
-    const bool in = i < frame->n_in;  // no early return: the wavefront reduces at the end
-    float x = 0.0f, y = 0.0f, z = 0.0f;
-    if (in)
+    hist = lpx_slot(hist, fv.fs);
+    const uint32_t n = frame->n_in, tid = threadIdx.x;
+    if (hist)
     {
-        const char *p = pts + (size_t)i * stride;
-        x = ld_f32<ALIGNED>(p + off.x);
-        y = ld_f32<ALIGNED>(p + off.y);
-        z = ld_f32<ALIGNED>(p + off.z);
-        if (P4)
-            P4[i] = make_float4(x, y, z, 0.0f);  // one 16-byte record per point: whoever gathers it touches one line
-        else
+        h[tid] = 0;
+        __syncthreads();
+    }
+    float amax = 0.0f, nonfinite = 0.0f;
+    float xs[INGEST_ITEMS], ys[INGEST_ITEMS], zs[INGEST_ITEMS];
+#pragma unroll
+    for (int r = 0; r < INGEST_ITEMS; ++r)  // the loads of a thread's eight records go out together
+    {
+        const uint32_t i = lpx_blk.x * LPX_SORT_TILE + r * INGEST_THREADS + tid;
+        xs[r] = ys[r] = zs[r] = 0.0f;
+        if (i < n)
         {
-            X[i] = x;
-            Y[i] = y;
-            Z[i] = z;
+            const char *p = pts + (size_t)i * stride;
+            xs[r] = ld_f32<ALIGNED>(p + off.x);
+            ys[r] = ld_f32<ALIGNED>(p + off.y);
+            zs[r] = ld_f32<ALIGNED>(p + off.z);
         }
-        if (key)
+    }
+#pragma unroll
+    for (int r = 0; r < INGEST_ITEMS; ++r)
+    {
+        const uint32_t i = lpx_blk.x * LPX_SORT_TILE + r * INGEST_THREADS + tid;
+        const float x = xs[r], y = ys[r], z = zs[r];
+        if (i < n)
         {
-            key[i] = lpx_float_key(x);
-            val[i] = i;
+            if (P4)
+                P4[i] = make_float4(x, y, z, 0.0f);  // one 16-byte record per point: whoever gathers it touches one line
+            else
+            {
+                X[i] = x;
+                Y[i] = y;
+                Z[i] = z;
+            }
+            if (key)
+            {
+                const uint32_t k = lpx_float_key(x);
+                key[i] = k;
+                val[i] = i;
+                if (hist)
+                    atomicAdd(&h[k & 255u], 1u);
+            }
+            if (nodes)
+                nodes[i] = make_float4(x, y, z, __uint_as_float(i));
         }
-        if (nodes)
-            nodes[i] = make_float4(x, y, z, __uint_as_float(i));
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)));  // fmaxf drops a NaN operand, hence:
+        nonfinite += (x - x) + (y - y) + (z - z);                        // 0 for finite input, NaN for NaN / Inf
     }
     // Any finite cloud is processed like the reference does (src/segmentation.cpp:311-345).  NaN / Inf are
     // undefined behaviour upstream (comparators) and flag the frame.  Coordinates beyond +-2048 m leave the
     // int32 fixed-point range of the moment fast path: the plane kernels give those points the wide path.
-    const float amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));  // fmaxf drops a NaN operand, hence:
-    const float nonfinite = (x - x) + (y - y) + (z - z);            // 0 for finite input, NaN for NaN / Inf
     if (!(nonfinite == 0.0f))
     {
         frame->status = (uint32_t)(-LPX_ERR_RANGE);
@@ -164,15 +198,23 @@ __global__ void ingest_kernel(const char *__restrict__ pts, size_t stride, XyzOf
     }
     else if (!(amax < FIX_LIMIT))
         frame->has_far = 1u;
+    if (hist)
+    {
+        __syncthreads();
+        hist[lpx_blk.x * 256u + tid] = h[tid];  // block-major row of this tile, as radix_hist_kernel writes it
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // gather into x-sorted SoA + composite (segment, z) keys
 // ------------------------------------------------------------------------------------------------
-__global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float4 *__restrict__ P4,
-                              float *__restrict__ XS, float *__restrict__ YS, float *__restrict__ ZS,
-                              uint64_t *__restrict__ zkey, SegParams prm, const FrameState *__restrict__ frame,
-                              size_t fs)
+// Eight points per thread: the eight index loads go out together, then the eight dependent 16-byte gathers -- two
+// round trips per wavefront instead of two per 64 points (a wavefront that waits holds its slot: lpx_primitives.hip).
+constexpr int GATHER_ITEMS = 8;
+__global__ __launch_bounds__(256) void gather_kernel(const uint32_t *__restrict__ sidx, const float4 *__restrict__ P4,
+                                                     float *__restrict__ XS, float *__restrict__ YS,
+                                                     float *__restrict__ ZS, uint64_t *__restrict__ zkey, SegParams prm,
+                                                     const FrameState *__restrict__ frame, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<0>(fs);
     sidx = lpx_slot(sidx, fs);
@@ -182,19 +224,34 @@ __global__ void gather_kernel(const uint32_t *__restrict__ sidx, const float4 *_
     ZS = lpx_slot(ZS, fs);
     zkey = lpx_slot(zkey, fs);
     seg_bind(prm, lpx_slot(frame, fs));
-    const uint32_t p = lpx_blk.x * blockDim.x + threadIdx.x;
-    if (p >= prm.n)
-        return;
-    const float4 q = P4[sidx[p]];  // one random 16-byte read per point
-    const float z = q.z;
-    XS[p] = q.x;
-    YS[p] = q.y;
-    ZS[p] = z;
-    uint32_t seg = prm.n_per ? p / prm.n_per : prm.P;
-    if (seg > prm.P)
-        seg = prm.P;  // the N mod P tail (Q2) sorts behind every segment
-    if (zkey)  // only the sort-based seed path needs the composite keys
-        zkey[p] = ((uint64_t)seg << 32) | lpx_float_key(z);
+    const uint32_t p0 = lpx_blk.x * (256u * GATHER_ITEMS) + threadIdx.x;
+    uint32_t si[GATHER_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GATHER_ITEMS; ++r)
+    {
+        const uint32_t p = p0 + r * 256u;
+        si[r] = p < prm.n ? sidx[p] : 0u;
+    }
+    float4 q[GATHER_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GATHER_ITEMS; ++r)
+        q[r] = P4[si[r]];  // one random 16-byte read per point
+#pragma unroll
+    for (int r = 0; r < GATHER_ITEMS; ++r)
+    {
+        const uint32_t p = p0 + r * 256u;
+        if (p >= prm.n)
+            continue;
+        const float z = q[r].z;
+        XS[p] = q[r].x;
+        YS[p] = q[r].y;
+        ZS[p] = z;
+        uint32_t seg = prm.n_per ? p / prm.n_per : prm.P;
+        if (seg > prm.P)
+            seg = prm.P;  // the N mod P tail (Q2) sorts behind every segment
+        if (zkey)  // only the sort-based seed path needs the composite keys
+            zkey[p] = ((uint64_t)seg << 32) | lpx_float_key(z);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,7 +385,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
 // those <= 8192 keys in LDS (bitonic) and sums them with one lane.  Same results as seed_kernel over the
 // sorted segment; replaces five radix-sort passes over all N points.
 // ------------------------------------------------------------------------------------------------
-constexpr int SEL_THREADS = 1024;
+constexpr int SEL_THREADS = 1024;  // (the kernel is written for exactly sixteen wavefronts: 512 threads fault)
 constexpr int SEL_PTS = 24;
 constexpr uint32_t SEL_MAX_POINTS = SEL_THREADS * SEL_PTS;  // 24576 points per segment
 constexpr uint32_t SEL_MAX_LPR = 8192;                     // keys sorted in LDS
@@ -1258,17 +1315,29 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     __syncthreads();
     const unsigned long long lt = lpx_lanemask_lt();
 
-    // each wave owns a contiguous quarter of the chunk
+    // each wave owns a contiguous quarter of the chunk, CR rounds of 64 points at a time: the flags, sorted indices and
+    // coordinates of all CR rounds are requested before the first is used (a round used to be a chain of three
+    // dependent loads, sixteen rounds per wavefront: the wavefront spent its life waiting -- and held its slot)
+    constexpr int CR = 16;
     const uint32_t span = hi > lo ? hi - lo : 0;
     const uint32_t per_w = (span + SEG_WAVES - 1) / SEG_WAVES;
     const uint32_t wlo = min(lo + w * per_w, hi), whi = min(wlo + per_w, hi);
     uint32_t cg = 0, co = 0;
-    for (uint32_t p0 = wlo; p0 < whi; p0 += WAVE)
+    for (uint32_t p0 = wlo; p0 < whi; p0 += WAVE * CR)
     {
-        const uint32_t p = p0 + lane;
-        const uint8_t f = (p < whi) ? flags[p] : 0;
-        cg += __popcll(__ballot(f == 1));
-        co += __popcll(__ballot(f == 2));
+        uint32_t f[CR];
+#pragma unroll
+        for (int r = 0; r < CR; ++r)
+        {
+            const uint32_t p = p0 + r * WAVE + lane;
+            f[r] = (p < whi) ? flags[p] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < CR; ++r)
+        {
+            cg += __popcll(__ballot(f[r] == 1u));
+            co += __popcll(__ballot(f[r] == 2u));
+        }
     }
     if (lane == 0)
     {
@@ -1284,33 +1353,48 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     }
     const bool want_hash = gridDim.z == 1;  // single-frame calls: the host may be handed this cloud back (lpx_cluster)
     uint64_t hsum = 0;
-    for (uint32_t p0 = wlo; p0 < whi; p0 += WAVE)
+    for (uint32_t p0 = wlo; p0 < whi; p0 += WAVE * CR)
     {
-        const uint32_t p = p0 + lane;
-        const bool in = p < whi;
-        const uint8_t f = in ? flags[p] : 0;
-        const unsigned long long mg = __ballot(f == 1), mo = __ballot(f == 2);
-        if (in)
+        uint32_t f[CR], si[CR];
+        float ox[CR], oy[CR], oz[CR];
+#pragma unroll
+        for (int r = 0; r < CR; ++r)
         {
-            const uint32_t i = sidx[p];
-            labels[i] = f;
-            if (f == 1)
-                gidx[gpos + __popcll(mg & lt)] = i;
-            else if (f == 2)
-            {
-                const uint32_t d = opos + __popcll(mo & lt);
-                oidx[d] = i;
-                const float ox = XS[p], oy = YS[p], oz = ZS[p];
-                OX[d] = ox;
-                OY[d] = oy;
-                OZ[d] = oz;
-                nodes[d] = make_float4(ox, oy, oz, __uint_as_float(d));  // kd-tree input, KDTree::rebuild :185-189
-                if (want_hash)
-                    hsum += lpx_obstacle_mix(d, __float_as_uint(ox), __float_as_uint(oy), __float_as_uint(oz));
-            }
+            const uint32_t p = p0 + r * WAVE + lane;
+            const bool in = p < whi;
+            f[r] = in ? flags[p] : 0u;  // (L2 hits: the count pass has just read them)
+            si[r] = in ? sidx[p] : 0u;
+            ox[r] = in ? XS[p] : 0.0f;
+            oy[r] = in ? YS[p] : 0.0f;
+            oz[r] = in ? ZS[p] : 0.0f;
         }
-        gpos += __popcll(mg);
-        opos += __popcll(mo);
+#pragma unroll
+        for (int r = 0; r < CR; ++r)
+        {
+            const uint32_t p = p0 + r * WAVE + lane;
+            const bool in = p < whi;
+            const unsigned long long mg = __ballot(f[r] == 1u), mo = __ballot(f[r] == 2u);
+            if (in)
+            {
+                const uint32_t i = si[r];
+                labels[i] = f[r];
+                if (f[r] == 1u)
+                    gidx[gpos + __popcll(mg & lt)] = i;
+                else if (f[r] == 2u)
+                {
+                    const uint32_t d = opos + __popcll(mo & lt);
+                    oidx[d] = i;
+                    OX[d] = ox[r];
+                    OY[d] = oy[r];
+                    OZ[d] = oz[r];
+                    nodes[d] = make_float4(ox[r], oy[r], oz[r], __uint_as_float(d));  // kd-tree input, KDTree::rebuild :185-189
+                    if (want_hash)
+                        hsum += lpx_obstacle_mix(d, __float_as_uint(ox[r]), __float_as_uint(oy[r]), __float_as_uint(oz[r]));
+                }
+            }
+            gpos += __popcll(mg);
+            opos += __popcll(mo);
+        }
     }
     if (want_hash)
     {
@@ -1414,17 +1498,19 @@ static uint32_t bits_for(uint32_t v)  // number of bits needed to represent valu
     return b ? b : 1;
 }
 
-static void launch_ingest(lpx_ctx *ctx, dim3 grid, const void *d_pts, size_t stride, float *X, float *Y, float *Z,
-                          float4 *P4, uint32_t *key, uint32_t *val, FrameState *frame, float4 *nodes)
+// n: point bound of the largest frame; hist: where the first pass of lpx_sort_pairs expects its tile histograms, or null
+static void launch_ingest(lpx_ctx *ctx, uint32_t n, const void *d_pts, size_t stride, float *X, float *Y, float *Z,
+                          float4 *P4, uint32_t *key, uint32_t *val, FrameState *frame, float4 *nodes, uint32_t *hist)
 {
     const XyzOff off = {ctx->in_off[0], ctx->in_off[1], ctx->in_off[2]};
     const bool aligned = (((uintptr_t)d_pts | stride | off.x | off.y | off.z) & 3u) == 0;
+    const dim3 grid((n + LPX_SORT_TILE - 1) / LPX_SORT_TILE, 1, ctx->cur_b);
     if (aligned)
-        hipLaunchKernelGGL(ingest_kernel<true>, grid, dim3(256), 0, ctx->stream, (const char *)d_pts, stride, off, X, Y,
-                           Z, P4, key, val, frame, nodes, lpx_fv(ctx));
+        hipLaunchKernelGGL(ingest_kernel<true>, grid, dim3(INGEST_THREADS), 0, ctx->stream, (const char *)d_pts, stride,
+                           off, X, Y, Z, P4, key, val, frame, nodes, hist, lpx_fv(ctx));
     else
-        hipLaunchKernelGGL(ingest_kernel<false>, grid, dim3(256), 0, ctx->stream, (const char *)d_pts, stride, off, X, Y,
-                           Z, P4, key, val, frame, nodes, lpx_fv(ctx));
+        hipLaunchKernelGGL(ingest_kernel<false>, grid, dim3(INGEST_THREADS), 0, ctx->stream, (const char *)d_pts, stride,
+                           off, X, Y, Z, P4, key, val, frame, nodes, hist, lpx_fv(ctx));
 }
 
 int lpx_run_colour(lpx_ctx *ctx, uint32_t n_max, const uint32_t *d_gidx, const uint32_t *d_oidx, void *d_grec,
@@ -1499,7 +1585,7 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
     if (rc)
         return rc;
     if (n)
-        launch_ingest(ctx, dim3((n + 255) / 256), d_pts, 12, XS, YS, ZS, nullptr, nullptr, nullptr, frame, nullptr);
+        launch_ingest(ctx, n, d_pts, 12, XS, YS, ZS, nullptr, nullptr, nullptr, frame, nullptr, nullptr);
     // pass 0 leaves the moments of every point, the head of pass 1 (run as the final pass) solves and publishes the plane
     hipLaunchKernelGGL(dbg_all_seed_kernel, dim3(1), dim3(128), 0, ctx->stream, sst, (long long *)ctx->seg_far.p);
     hipLaunchKernelGGL((plane_pass_kernel<false>), dim3(prm.bps, 1), dim3(PASS_THREADS), 0, ctx->stream, XS, YS, ZS, prm,
@@ -1521,8 +1607,8 @@ int lpx_ingest_obstacles(lpx_ctx *ctx, const void *d_pts, size_t stride, uint32_
         return rc;
     if (m)
     {
-        launch_ingest(ctx, dim3((m + 255) / 256), d_pts, stride, (float *)ctx->OX.p, (float *)ctx->OY.p,
-                      (float *)ctx->OZ.p, nullptr, nullptr, nullptr, frame, (float4 *)ctx->nodes.p);
+        launch_ingest(ctx, m, d_pts, stride, (float *)ctx->OX.p, (float *)ctx->OY.p, (float *)ctx->OZ.p, nullptr, nullptr,
+                      nullptr, frame, (float4 *)ctx->nodes.p, nullptr);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
@@ -1571,16 +1657,17 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     float *XS = (float *)ctx->XS.p, *YS = (float *)ctx->YS.p, *ZS = (float *)ctx->ZS.p;
     const dim3 blk(256), grd((n + 255) / 256, 1, B);
 
+    uint32_t *first_hist = lpx_sort_first_hist(ctx, n);  // the ingest also counts the lowest key byte per sort tile
     {
         StageTimer tm(ctx, ST_INGEST);
-        launch_ingest(ctx, grd, d_pts, stride, nullptr, nullptr, nullptr, P4, (uint32_t *)ctx->key_a.p,
-                      (uint32_t *)ctx->val_a.p, frame, nullptr);
+        launch_ingest(ctx, n, d_pts, stride, nullptr, nullptr, nullptr, P4, (uint32_t *)ctx->key_a.p,
+                      (uint32_t *)ctx->val_a.p, frame, nullptr, first_hist);
     }
     uint32_t *skeys = nullptr, *sidx = nullptr;
     {
         StageTimer tm(ctx, ST_XSORT);
         rc = lpx_sort_pairs(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_b.p, (uint32_t *)ctx->val_a.p,
-                            (uint32_t *)ctx->val_b.p, n, &frame->n_in, 32, &skeys, &sidx);
+                            (uint32_t *)ctx->val_b.p, n, &frame->n_in, 32, &skeys, &sidx, first_hist != nullptr);
         if (rc)
             return rc;
     }
@@ -1596,7 +1683,8 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     const bool select_seeds = prm.n_per <= SEL_MAX_POINTS && prm.n_lpr <= SEL_MAX_LPR;
     {
         StageTimer tm(ctx, ST_GATHER);
-        hipLaunchKernelGGL(gather_kernel, grd, blk, 0, st, sidx, (const float4 *)P4, XS, YS, ZS,
+        hipLaunchKernelGGL(gather_kernel, dim3((n + 256 * GATHER_ITEMS - 1) / (256 * GATHER_ITEMS), 1, B), blk, 0, st, sidx,
+                           (const float4 *)P4, XS, YS, ZS,
                            select_seeds ? (uint64_t *)nullptr : (uint64_t *)ctx->key64_a.p, prm,
                            (const FrameState *)frame, fv.fs);
     }

@@ -266,7 +266,7 @@ def test_bench_gpus_2_launches_two_ranks_by_itself_dry_run():
     # what every rank measured by itself is gathered (not only the MAX), and at N > 1 rank 0 runs no side legs while the
     # other ranks would wait in the final barrier holding their GPUs
     assert [p["rank"] for p in line["per_rank"]] == [0, 1] and all(p["frames_per_s"] > 0 for p in line["per_rank"])
-    assert not {"latency", "throughput_vs_inflight", "stream", "kitti_3_frames_cycled", "with_overlap"} & set(line)
+    assert not {"latency", "throughput_vs_inflight", "stream", "kitti_3_frames_cycled", "beyond_latency_budget"} & set(line)
 
 
 def test_bench_under_a_launcher_does_not_spawn():
