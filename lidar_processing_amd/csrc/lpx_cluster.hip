@@ -763,14 +763,6 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 if (am)
                     ch_first = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, __ffsll((long long)am) - 1) *
                                           LPX_GROUP_CHUNKS + lane];
-#ifdef LPX_RS_PAIR
-                // (pair pipeline: the table of the SECOND alive candidate too -- it is expanded unless the first absorbs it)
-                const unsigned long long am2 = am & (am - 1);
-                const int h2 = am2 ? __ffsll((long long)am2) - 1 : -1;
-                ChunkRec ch_second = ch_first;
-                if (h2 >= 0)
-                    ch_second = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, h2) * LPX_GROUP_CHUNKS + lane];
-#endif
                 while (am)
                 {
                     const int h = __ffsll((long long)am) - 1;
@@ -793,80 +785,6 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                 // does not depend on the point states, so the searches are software-pipelined: the chunk table of
                 // expansion i + 1 is requested before expansion i is searched, and the first candidate batch of i + 1
                 // goes out before the hits of i are applied (the LDS work of the apply then runs under those loads).
-#ifdef LPX_RS_PAIR
-                // TWO expansions in flight: the candidate batches of expansions A and B go out together (a search does
-                // not depend on the point states), the tables of the next pair are requested behind them, then A's
-                // candidates are tested and its hits applied, then B's -- one round trip per PAIR of expansions where
-                // the single pipeline pays one per expansion.
-#define LPX_RS_Q(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
-                int eA = __ffsll((long long)em) - 1;
-                em &= em - 1;
-                int eB = em ? __ffsll((long long)em) - 1 : -1;
-                if (eB >= 0)
-                    em &= em - 1;
-                ChunkRec chA = ch_first, chB = ch_second;
-                if (eB >= 0 && eB != h2)
-                    chB = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, eB) * LPX_GROUP_CHUNKS + lane];
-                for (;;)
-                {
-                    const float ax = LPX_RS_Q(wx, eA), ay = LPX_RS_Q(wy, eA), az = LPX_RS_Q(wz, eA);
-                    unsigned long long kmA = rs_cull(chA, ax, ay, az, r2);
-                    RsBatch btA;
-                    rs_issue(btA, PR, chA, kmA, lane);
-                    float bx = 0.0f, by = 0.0f, bz = 0.0f;
-                    unsigned long long kmB = 0;
-                    RsBatch btB;
-                    if (eB >= 0)
-                    {
-                        bx = LPX_RS_Q(wx, eB), by = LPX_RS_Q(wy, eB), bz = LPX_RS_Q(wz, eB);
-                        kmB = rs_cull(chB, bx, by, bz, r2);
-                        rs_issue(btB, PR, chB, kmB, lane);
-                    }
-                    // the tables of the next pair
-                    const int eC = em ? __ffsll((long long)em) - 1 : -1;
-                    const unsigned long long em1 = em & (em - 1);
-                    const int eD = em1 ? __ffsll((long long)em1) - 1 : -1;
-                    ChunkRec chC = chA, chD = chA;
-                    if (eC >= 0)
-                        chC = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, eC) * LPX_GROUP_CHUNKS + lane];
-                    if (eD >= 0)
-                        chD = chunks[(size_t)__builtin_amdgcn_readlane((int)wg, eD) * LPX_GROUP_CHUNKS + lane];
-                    RS_LAP(pf_tab, pf_t);
-                    ++st_exp;
-                    rs_consume(btA, PR, ax, ay, az, r2, thr_f, lane, st_cand, collect);
-                    while (kmA)
-                    {
-                        rs_issue(btA, PR, chA, kmA, lane);
-                        rs_consume(btA, PR, ax, ay, az, r2, thr_f, lane, st_cand, collect);
-                    }
-                    RS_LAP(pf_cand, pf_t);
-                    while (hc)
-                        flush64();  // the hits of A, before any hit of B
-                    RS_LAP(pf_apply, pf_t);
-                    if (eB >= 0)
-                    {
-                        ++st_exp;
-                        rs_consume(btB, PR, bx, by, bz, r2, thr_f, lane, st_cand, collect);
-                        while (kmB)
-                        {
-                            rs_issue(btB, PR, chB, kmB, lane);
-                            rs_consume(btB, PR, bx, by, bz, r2, thr_f, lane, st_cand, collect);
-                        }
-                        RS_LAP(pf_cand, pf_t);
-                        while (hc)
-                            flush64();
-                        RS_LAP(pf_apply, pf_t);
-                    }
-                    if (eC < 0)
-                        break;
-                    eA = eC;
-                    eB = eD;
-                    chA = chC;
-                    chB = chD;
-                    em = eD >= 0 ? (em1 & (em1 - 1)) : em1;
-                }
-#undef LPX_RS_Q
-#else
                 int e = __ffsll((long long)em) - 1;
                 em &= em - 1;
                 ChunkRec ch = ch_first;
@@ -911,7 +829,6 @@ __global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
                     if (e_next < 0)
                         break;
                 }
-#endif
             }
             if (lane == 0)
                 valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;  // :113

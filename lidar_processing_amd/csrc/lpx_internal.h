@@ -312,10 +312,17 @@ struct StageTimer
 // ------------------------------------------------------------------------------------------------
 // stable LSD radix sort, 8 bits per pass over key bits [0, bits); result ends in the *_a buffers
 // (function copies if the pass count is odd).  n is a host upper bound; d_n (optional) the device count.
+// gather (optional): the sorted values index a table of 16-byte records {x, y, z, .}; the LAST pass writes x / y / z of
+// the records in sorted order itself (and leaves the sorted keys unwritten: *keys_out is then not to be read)
+struct LpxSortGather
+{
+    const void *records;
+    float *x, *y, *z;
+};
 // first_hist_ready: the producer of keys_a has left the tile histograms of the lowest key byte in lpx_sort_first_hist()
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
                    const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out,
-                   bool first_hist_ready = false);
+                   bool first_hist_ready = false, const LpxSortGather *gather = nullptr);
 // where a kernel that produces the keys of an n-element sort may leave the first pass's tile histograms (block-major,
 // 256 words per LPX_SORT_TILE keys), or null when the sort would not use them (tables beyond the fused-scan limit)
 uint32_t *lpx_sort_first_hist(lpx_ctx *ctx, uint32_t n);

@@ -51,14 +51,21 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__
         hist[tid * nblocks + lpx_blk.x] = h[tid];
 }
 
-template <typename KeyT, bool HAS_VALS>
+// GATHER (last pass of the x sort): the sorted VALUES are indices into a table of 16-byte records {x, y, z, .}; the
+// pass fetches the record of every value it places and writes the x-sorted SoA itself -- what gather_kernel did in a
+// launch of its own, reading the sorted indices back.  The sorted keys are not written (nobody reads them).
+template <typename KeyT, bool HAS_VALS, bool GATHER = false>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT *__restrict__ keys_in,
                                                                       KeyT *__restrict__ keys_out,
                                                                       const uint32_t *__restrict__ vals_in,
                                                                       uint32_t *__restrict__ vals_out, uint32_t n_max,
                                                                       const uint32_t *__restrict__ d_n, uint32_t shift,
                                                                       const uint32_t *__restrict__ offs,
-                                                                      uint32_t nblocks, int large, size_t fs)
+                                                                      uint32_t nblocks, int large, size_t fs,
+                                                                      const float4 *__restrict__ rec = nullptr,
+                                                                      float *__restrict__ GX = nullptr,
+                                                                      float *__restrict__ GY = nullptr,
+                                                                      float *__restrict__ GZ = nullptr)
 {
     const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
@@ -72,6 +79,13 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
     vals_out = lpx_slot(vals_out, fs);
     d_n = lpx_slot(d_n, fs);
     offs = lpx_slot(offs, fs);
+    if (GATHER)
+    {
+        rec = lpx_slot(rec, fs);
+        GX = lpx_slot(GX, fs);
+        GY = lpx_slot(GY, fs);
+        GZ = lpx_slot(GZ, fs);
+    }
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     const uint32_t tid = threadIdx.x;
     const uint32_t w = tid / WAVE, lane = tid % WAVE;
@@ -208,6 +222,30 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
     __syncthreads();
     const uint32_t tile_base = lpx_blk.x * SORT_TILE;
     const uint32_t tile_n = tile_base < n ? min(n - tile_base, (uint32_t)SORT_TILE) : 0u;
+    if (GATHER)
+    {
+        uint32_t vv[SORT_ITEMS], dd[SORT_ITEMS];
+        float4 q[SORT_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r)  // the eight record fetches of a thread go out together
+        {
+            const uint32_t j = r * SORT_THREADS + tid;
+            const bool in = j < tile_n;
+            vv[r] = in ? stage_v[HAS_VALS ? j : 0] : 0u;
+            dd[r] = in ? gofs[(uint32_t)(stage_k[j] >> shift) & (RADIX - 1)] + j : 0u;
+            q[r] = rec[vv[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r)
+            if (r * SORT_THREADS + tid < tile_n)
+            {
+                vals_out[dd[r]] = vv[r];
+                GX[dd[r]] = q[r].x;
+                GY[dd[r]] = q[r].y;
+                GZ[dd[r]] = q[r].z;
+            }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r)
     {
@@ -478,7 +516,8 @@ uint32_t *lpx_sort_first_hist(lpx_ctx *ctx, uint32_t n)
 }
 
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
-                   const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out, bool first_hist_ready)
+                   const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out, bool first_hist_ready,
+                   const LpxSortGather *gather)
 {
     const uint32_t nblocks = sort_blocks(n);
     int rc = ensure_hist(ctx, nblocks);
@@ -496,8 +535,13 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
                                n, d_n, shift, hist, nblocks, !large, fs);
         if (large)
             hipLaunchKernelGGL(hist_rows_kernel, dim3(RADIX, 1, B), dim3(SORT_THREADS), 0, ctx->stream, hist, nblocks, fs);
-        hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
-                           ctx->stream, ka, kb, va, vb, n, d_n, shift, hist, nblocks, large, fs);
+        if (gather && shift + 8 >= bits)  // the last pass also fetches the records the sorted values name
+            hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
+                               ctx->stream, ka, kb, va, vb, n, d_n, shift, hist, nblocks, large, fs,
+                               (const float4 *)gather->records, gather->x, gather->y, gather->z);
+        else
+            hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
+                               ctx->stream, ka, kb, va, vb, n, d_n, shift, hist, nblocks, large, fs);
         uint32_t *t = ka;
         ka = kb;
         kb = t;

@@ -405,6 +405,10 @@ __device__ __forceinline__ uint32_t sel_block_sum(uint32_t v, uint32_t *red, uin
     return s;
 }
 
+// (Plane pass 0 -- the moments of the seeds -- was folded into this kernel once: it holds every z of the segment in
+// registers, x and y of the seeds are two more loads per point.  One launch less, 0.013 ms more per 64-frame chain alone,
+// and 2 % LESS throughput with sixteen chains in flight: this is a 1024-thread workgroup, the kind that waits longest
+// for a compute unit under load, and everything added to it is added to that wait.  Taken out again.)
 __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *__restrict__ ZS, SegParams prm,
                                                                    SegState *__restrict__ st,
                                                                    long long *__restrict__ facc,
@@ -1663,11 +1667,22 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         launch_ingest(ctx, n, d_pts, stride, nullptr, nullptr, nullptr, P4, (uint32_t *)ctx->key_a.p,
                       (uint32_t *)ctx->val_a.p, frame, nullptr, first_hist);
     }
+    // segments that fit one workgroup's registers get their seed statistics by selection; larger ones (or more
+    // representatives than the LDS sort holds) by the full (segment, z) sort
+    const bool select_seeds = prm.n_per <= SEL_MAX_POINTS && prm.n_lpr <= SEL_MAX_LPR;
+    // (the selection path needs nothing from gather_kernel but the x-sorted SoA: the last pass of the sort writes it)
+#ifdef LPX_NO_FUSED_GATHER
+    const bool fused_gather = false;
+#else
+    const bool fused_gather = select_seeds && !(B == 1 && prm.n_per == 0);
+#endif
+    const LpxSortGather sg = {P4, XS, YS, ZS};
     uint32_t *skeys = nullptr, *sidx = nullptr;
     {
         StageTimer tm(ctx, ST_XSORT);
         rc = lpx_sort_pairs(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_b.p, (uint32_t *)ctx->val_a.p,
-                            (uint32_t *)ctx->val_b.p, n, &frame->n_in, 32, &skeys, &sidx, first_hist != nullptr);
+                            (uint32_t *)ctx->val_b.p, n, &frame->n_in, 32, &skeys, &sidx, first_hist != nullptr,
+                            fused_gather ? &sg : nullptr);
         if (rc)
             return rc;
     }
@@ -1678,9 +1693,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         LPX_HIP(ctx, hipGetLastError());
         return LPX_OK;
     }
-    // segments that fit one workgroup's registers get their seed statistics by selection; larger ones (or more
-    // representatives than the LDS sort holds) by the full (segment, z) sort
-    const bool select_seeds = prm.n_per <= SEL_MAX_POINTS && prm.n_lpr <= SEL_MAX_LPR;
+    if (!fused_gather)
     {
         StageTimer tm(ctx, ST_GATHER);
         hipLaunchKernelGGL(gather_kernel, dim3((n + 256 * GATHER_ITEMS - 1) / (256 * GATHER_ITEMS), 1, B), blk, 0, st, sidx,
