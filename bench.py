@@ -50,7 +50,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md:36; a float4 copy measures 6.29 TB/s there)
 FRAME_BUDGET_MS = 100.0  # the reference's frame budget (10 Hz sensor, reference README.md:4): p99 completion must stay below
-PROFILE_ROUND = "r03"  # committed rocprofv3 summaries this line points at: profiles/<round>_<workload>_*
+PROFILE_ROUND = "r04"  # committed rocprofv3 summaries this line points at: profiles/<round>_<workload>_*
 
 WORKLOADS = {
     "kitti": dict(config="configs[1]: 120k-pt KITTI frames (three frames cycled), 6 segments, 5 iters, FEC d=0.5 m q=0.5",

@@ -152,7 +152,12 @@ int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint32_t n, 
                 uint32_t *n_obstacle, float *planes);
 
 /* Clusterer::cluster (reference src/clustering.cpp:47-125).  labels[m] (int32, dense 0..L-1 in
- * seed order, LPX_CLUSTER_INVALID for rejected groups); n_clusters may be NULL. */
+ * seed order, LPX_CLUSTER_INVALID for rejected groups); n_clusters may be NULL.
+ * On the context whose last call was lpx_segment* (what two drop-in objects on one context do, reference
+ * src/processor.cpp:150-178), a cloud of exactly that call's obstacle count whose position-bound checksum over all m
+ * points (x, y, z words, computed here on the host) equals the one the device kept is clustered where it lies: no
+ * upload.  Every other cloud -- another size, one changed coordinate, two swapped points, a second clustering of the
+ * same cloud -- is uploaded.  The result never depends on which way a call went. */
 int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint32_t m, const lpx_clu_cfg *cfg,
                 int32_t *labels, uint32_t *n_clusters);
 

@@ -2,7 +2,7 @@
 # Regenerates the measured artefacts under gpurun_out/<tag>/ on the GPU box (copy them to profiles/ afterwards):
 # per workload the bench line, the rocprofv3 kernel stats of the default command and of --contexts 1 (launch
 # durations of the kernels alone), and FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes).
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift
 WORKLOADS=${@:-kitti synth1m synth5m stream}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
