@@ -248,7 +248,9 @@ def dropin_cxx_latency(frame, wl):
         d = json.loads(r.stdout.strip().splitlines()[-1])
     d["what"] = ("lidar_processing::Segmenter::segment + Clusterer::cluster (include/lidar_processing/*.hpp, C++, pageable "
                  "PCL clouds) as reference src/processor.cpp:150 and :178 call them; default-constructed objects share "
-                 "one context, so cluster() finds the obstacle cloud on the device")
+                 "one context: cluster() finds the obstacle cloud on the device and, from the second message on, its "
+                 "clustering already enqueued by segment() (lpx_set_lookahead); lookahead_off: the same without that; "
+                 "callback_ms: segment() entered -> cluster() returned, the node's recolour copy in between included")
     return d
 
 

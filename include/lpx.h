@@ -136,6 +136,17 @@ int lpx_set_overlap(lpx_ctx *ctx, int on);
  * Results are the same; a call completes sooner (one frame in LPX_NEIGHBOURS_SEARCH mode, a chain of frames), at the
  * price of a second hardware queue while the fork is open.  Call it after lpx_set_overlap if both are wanted. */
 int lpx_set_fork(lpx_ctx *ctx, int on);
+/* Look-ahead of the two-call form.  The unchanged node calls Segmenter::segment and, a few lines later,
+ * Clusterer::cluster on the obstacle cloud it got back (reference src/processor.cpp:150 and :178) -- two blocking calls
+ * where the device could run one chain.  With the look-ahead on (the default), a context on which an lpx_cluster call
+ * has just been served from the resident cloud of the lpx_segment* call before it remembers that call's configuration;
+ * its next lpx_segment* call enqueues the clustering with that configuration right behind the segmentation and returns
+ * as soon as the segmentation's own results are down (they are copied on a second stream).  An lpx_cluster call for
+ * that cloud with that configuration then finds its chain running and only waits for it; any other call on the context
+ * waits for the chain like for any earlier work, the guess is dropped, and nothing is guessed again until an
+ * lpx_cluster call is served from a resident cloud once more.  Results never differ -- a mismatch takes the plain
+ * path (upload and cluster) -- only the blocking time of the two calls does.  on = 0 turns it off. */
+int lpx_set_lookahead(lpx_ctx *ctx, int on);
 /* host wait until every batch call of an overlapped context but the LAST one is complete (a pipelined caller enqueues
  * call k, then collects call k - 1); without overlap the same as lpx_synchronize */
 int lpx_wait_previous(lpx_ctx *ctx);

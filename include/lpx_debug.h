@@ -30,6 +30,8 @@ int lpx_dbg_neighbours(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uin
                        float *dist, uint64_t capacity);
 /* connected-component root (smallest original index of the component) per point */
 int lpx_dbg_components(lpx_ctx *ctx, const float *xyz, uint32_t m, float r2, uint32_t *root);
+/* lpx_cluster calls of this context that found their clustering already enqueued by lpx_segment* (lpx_set_lookahead) */
+uint64_t lpx_dbg_lookahead_hits(lpx_ctx *ctx);
 /* statistics of the last frame processed by this context (synchronises): out[12] =
  * {n_ground, n_obstacle, n_clusters, status, neighbour entries lo/hi, components, expansions,
  *  entries read by the replay lo/hi, words of list storage handed out lo/hi} */

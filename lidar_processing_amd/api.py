@@ -132,6 +132,14 @@ class Context:
         """lpx_set_fork: the component search of a call runs on a side stream beside its kd build and chunk tables"""
         self.check(self._L.lpx_set_fork(self._h, 1 if on else 0))
 
+    def set_lookahead(self, on=True):
+        """lpx_set_lookahead: segment() enqueues the clustering the cluster() call that follows it will ask for"""
+        self.check(self._L.lpx_set_lookahead(self._h, 1 if on else 0))
+
+    def lookahead_hits(self):
+        """cluster() calls of this context that found their clustering already enqueued by segment()"""
+        return int(self._L.lpx_dbg_lookahead_hits(self._h))
+
     def wait_previous(self):
         """lpx_wait_previous: every batch call but the last one is complete (overlapped contexts)"""
         self.check(self._L.lpx_wait_previous(self._h))

@@ -219,6 +219,13 @@ static int begin_call(lpx_ctx *ctx, uint32_t frames, uint32_t upitch)
     ctx->upitch = upitch;
     ctx->seg_valid = false;  // set again at the end of a host segmentation call (what lpx_coloured_clouds serves)
     ctx->seg_fresh = false;
+    if (ctx->la_pending)
+    {
+        // a look-ahead clustering nobody asked for (lpx_cluster takes its flag down before it gets here): stop guessing
+        // until an lpx_cluster call is served from a resident cloud again
+        ctx->la_pending = false;
+        ctx->la_armed = false;
+    }
     ctx->in_off[0] = 0;  // PCL records: x, y, z lead the record; the *_fields entry points overwrite this
     ctx->in_off[1] = 4;
     ctx->in_off[2] = 8;
@@ -512,6 +519,12 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
         lpx_destroy(ctx->twin);
         ctx->twin = nullptr;
     }
+    if (ctx->ev_seg)
+        hipEventDestroy(ctx->ev_seg);
+    if (ctx->copy_stream)
+        hipStreamDestroy(ctx->copy_stream);
+    if (ctx->h_frame)
+        hipHostFree(ctx->h_frame);
     if (ctx->ev_fork)
         hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join)
@@ -667,6 +680,21 @@ extern "C" int lpx_set_fork(lpx_ctx *ctx, int on)
         c->fork = on != 0;
     }
     return LPX_OK;
+}
+
+extern "C" int lpx_set_lookahead(lpx_ctx *ctx, int on)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    ctx->lookahead = on ? 1 : 0;
+    if (!on)
+        ctx->la_armed = false;
+    return LPX_OK;
+}
+
+extern "C" uint64_t lpx_dbg_lookahead_hits(lpx_ctx *ctx)
+{
+    return ctx ? ctx->la_hits : 0;
 }
 
 static int overlap_arm(lpx_ctx *c)
@@ -1011,14 +1039,37 @@ static int read_frame(lpx_ctx *ctx, FrameState *fs)
     return LPX_OK;
 }
 
+// The resources of the look-ahead (lpx_set_lookahead), made on first use
+static bool lookahead_ready(lpx_ctx *ctx)
+{
+    if (ctx->copy_stream && ctx->ev_seg && ctx->h_frame)
+        return true;
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
+        ctx->copy_stream = nullptr;
+    if (!ctx->ev_seg && hipEventCreateWithFlags(&ctx->ev_seg, hipEventDisableTiming) != hipSuccess)
+        ctx->ev_seg = nullptr;
+    if (!ctx->h_frame && hipHostMalloc(&ctx->h_frame, sizeof(FrameState), hipHostMallocDefault) != hipSuccess)
+        ctx->h_frame = nullptr;
+    return ctx->copy_stream && ctx->ev_seg && ctx->h_frame;  // (not ready: the call goes the plain way)
+}
+
+// snapshot: the frame state is already on its way to pinned memory (ctx->ev_seg follows it); otherwise read here
 static int download_segment(lpx_ctx *ctx, uint32_t n, uint32_t P, uint32_t *labels, uint32_t *gidx, uint32_t *n_ground,
-                            uint32_t *oidx, uint32_t *n_obstacle, float *planes, FrameState *fs)
+                            uint32_t *oidx, uint32_t *n_obstacle, float *planes, FrameState *fs,
+                            const FrameState *snapshot = nullptr)
 {
     if (labels && n)
         LPX_HIP(ctx, hipMemcpyAsync(labels, ctx->d_labels.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
     if (planes)
         LPX_HIP(ctx, hipMemcpyAsync(planes, ctx->d_planes.p, sizeof(float) * 4 * P, hipMemcpyDeviceToHost, ctx->stream));
-    int rc = read_frame(ctx, fs);
+    int rc = LPX_OK;
+    if (snapshot)
+    {
+        LPX_HIP(ctx, hipEventSynchronize(ctx->ev_seg));
+        *fs = *snapshot;
+    }
+    else
+        rc = read_frame(ctx, fs);
     if (rc)
         return rc;
     if ((rc = status_to_rc(ctx, fs->status)) && rc != LPX_ERR_CAPACITY)
@@ -1061,13 +1112,32 @@ static int segment_impl(lpx_ctx *ctx, const void *pts, size_t stride, const uint
                               (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
         return rc;
     FrameState fs;
-    if ((rc = download_segment(ctx, n, cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle, planes,
-                               &fs)))
+    const bool ahead = ctx->lookahead && ctx->la_armed && n > 0 && lookahead_ready(ctx);
+    if (ahead)
+    {
+        // the frame state as the segmentation leaves it (the clustering writes into the same record), then the
+        // clustering right behind; the downloads wait for the segmentation only, on a stream of their own
+        LPX_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->frame.p, sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
+        LPX_HIP(ctx, hipEventRecord(ctx->ev_seg, ctx->stream));
+        if ((rc = lpx_run_cluster(ctx, n, &ctx->la_cfg, (int32_t *)ctx->d_clabels.p, nullptr, false)))
+            return rc;
+        hipStream_t const main_stream = ctx->stream;
+        LPX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_seg, 0));
+        ctx->stream = ctx->copy_stream;
+        rc = download_segment(ctx, n, cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle, planes,
+                              &fs, (const FrameState *)ctx->h_frame);
+        ctx->stream = main_stream;
+        if (rc)
+            return rc;
+    }
+    else if ((rc = download_segment(ctx, n, cfg->number_of_planar_partitions, labels, gidx, n_ground, oidx, n_obstacle,
+                                    planes, &fs)))
         return rc;
     ctx->seg_valid = true;
     ctx->seg_ground = fs.n_ground;
     ctx->seg_obstacle = fs.n_obstacle;
-    ctx->seg_fresh = true;  // the obstacle SoA and the kd input are as the compaction wrote them
+    ctx->seg_fresh = !ahead;  // the obstacle SoA and the kd input are as the compaction wrote them ...
+    ctx->la_pending = ahead;  // ... or the clustering that consumes them is on its way
     ctx->seg_hash = fs.obs_hash;
     return LPX_OK;
 }
@@ -1089,7 +1159,8 @@ extern "C" int lpx_segment_fields(lpx_ctx *ctx, const void *data, uint32_t point
 
 // Runs the clustering of the obstacle SoA resident in ctx (count on the device, at most m_bound points) and
 // reads the frame state back; grows the neighbour workspace and retries when the frame needs more.
-static int cluster_resident(lpx_ctx *ctx, uint32_t m_bound, const lpx_clu_cfg *cfg, FrameState *fs)
+static int cluster_resident(lpx_ctx *ctx, uint32_t m_bound, const lpx_clu_cfg *cfg, FrameState *fs,
+                            bool first_enqueued = false)
 {
     int rc;
     for (int attempt = 0; attempt < 3; ++attempt)
@@ -1098,11 +1169,14 @@ static int cluster_resident(lpx_ctx *ctx, uint32_t m_bound, const lpx_clu_cfg *c
         // the layout depends on the input order, src/kdtree.hpp:174-225)
         // A retry counts every list (no single-pass reservations): which groups win a reservation depends on
         // scheduling, so only then is nb_total the exact requirement, and the attempt after it always fits.
-        ctx->exact_lists_only = attempt > 0;
-        rc = lpx_run_cluster(ctx, m_bound, cfg, (int32_t *)ctx->d_clabels.p, nullptr, attempt > 0);
-        ctx->exact_lists_only = false;
-        if (rc)
-            return rc;
+        if (attempt > 0 || !first_enqueued)  // (first_enqueued: the look-ahead of lpx_segment has enqueued attempt 0)
+        {
+            ctx->exact_lists_only = attempt > 0;
+            rc = lpx_run_cluster(ctx, m_bound, cfg, (int32_t *)ctx->d_clabels.p, nullptr, attempt > 0);
+            ctx->exact_lists_only = false;
+            if (rc)
+                return rc;
+        }
         if ((rc = read_frame(ctx, fs)))
             return rc;
         if (fs->status != (uint32_t)(-LPX_ERR_CAPACITY) || attempt == 2)
@@ -1153,7 +1227,11 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
     // position-bound checksum (lpx_obstacle_mix over all m points, ~30 us on the host) the upload and the ingest are
     // skipped.  Anything else (another cloud, a second clustering of the same one: the kd build consumes its input)
     // takes the upload.
-    if (ctx->seg_valid && ctx->seg_fresh && m == ctx->seg_obstacle && m <= ctx->cap_n)
+    // Look-ahead: when the lpx_segment call has already enqueued this very clustering (same cloud, same configuration --
+    // what the call before this one asked for), there is nothing to enqueue, only to wait for.  A look-ahead with
+    // another configuration has consumed the kd input like any clustering: upload.
+    const bool ahead = ctx->la_pending && memcmp(cfg, &ctx->la_cfg, sizeof(*cfg)) == 0;
+    if (ctx->seg_valid && (ctx->seg_fresh || ahead) && m == ctx->seg_obstacle && m <= ctx->cap_n)
     {
         uint64_t h = 0;
         const char *p = (const char *)pts;
@@ -1166,10 +1244,11 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
         if (h == ctx->seg_hash)
         {
             const uint32_t ng = ctx->seg_ground, last_n = ctx->last_n;
+            ctx->la_pending = false;  // (used, not mispredicted: begin_call must not take the guess down)
             if ((rc = begin_call(ctx, 1, 0)))
                 return rc;
             FrameState fs;
-            if ((rc = cluster_resident(ctx, m, cfg, &fs)))
+            if ((rc = cluster_resident(ctx, m, cfg, &fs, ahead)))
                 return rc;
             if ((rc = download_clusters(ctx, fs, labels, n_clusters)))
                 return rc;
@@ -1178,6 +1257,9 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
             ctx->seg_ground = ng;
             ctx->seg_obstacle = m;
             ctx->last_n = last_n;
+            ctx->la_cfg = *cfg;  // the caller runs segment() then cluster() on one context: look ahead next time
+            ctx->la_armed = true;
+            ctx->la_hits += ahead ? 1u : 0u;
             return LPX_OK;
         }
     }

@@ -19,6 +19,7 @@
 #include "lpx_internal.h"
 
 #include <math.h>
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1156,6 +1157,78 @@ __global__ void hull_pack_kernel(const uint32_t *__restrict__ off, const uint32_
     }
 }
 
+#ifdef LPX_DEV_KNOBS
+// Development build only (tools/r4_probe14.sh): what is the device short of with many chains in flight?  Two kernels
+// that add a KNOWN amount of ONE resource to every chain -- vector-ALU issue cycles (no memory traffic) or scattered
+// 64-byte line requests (a handful of instructions each) -- so that the throughput they cost names the resource.
+__global__ __launch_bounds__(256) void burn_alu_kernel(float *sink, uint32_t iters)
+{
+    float a = (float)threadIdx.x * 1.0e-3f, b = a + 1.0f, c = a + 2.0f, d = a + 3.0f;
+    for (uint32_t i = 0; i < iters; ++i)
+    {
+        a = __builtin_fmaf(a, 0.999999f, 0.5f);
+        b = __builtin_fmaf(b, 0.999998f, 0.25f);
+        c = __builtin_fmaf(c, 0.999997f, 0.125f);
+        d = __builtin_fmaf(d, 0.999996f, 0.0625f);
+    }
+    if (a + b + c + d == 123.456f)
+        sink[0] = a;
+}
+
+__global__ __launch_bounds__(256) void burn_mem_kernel(const uint4 *__restrict__ buf, uint32_t line_mask, uint32_t iters,
+                                                       uint32_t *sink, uint32_t salt)
+{
+    uint32_t s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + salt;
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < iters; i += 4)
+    {
+        uint32_t idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            s = s * 1664525u + 1013904223u;
+            idx[u] = (s >> 4) & line_mask;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            acc ^= buf[(size_t)idx[u] * 4u].x;  // one 16-byte word of a random 64-byte line
+    }
+    if (acc == 0x12345u)
+        sink[0] = acc;
+}
+
+static void burn_resources(lpx_ctx *ctx)
+{
+    static const uint32_t alu = LPX_KNOB("LPX_BURN_ALU") ? (uint32_t)atoi(LPX_KNOB("LPX_BURN_ALU")) : 0u;
+    static const uint32_t mem = LPX_KNOB("LPX_BURN_MEM") ? (uint32_t)atoi(LPX_KNOB("LPX_BURN_MEM")) : 0u;
+    static const uint32_t blocks = LPX_KNOB("LPX_BURN_BLOCKS") ? (uint32_t)atoi(LPX_KNOB("LPX_BURN_BLOCKS")) : 1024u;
+    if (!alu && !mem)
+        return;
+    static void *buf = nullptr;
+    static uint32_t salt = 0;
+    constexpr size_t BYTES = 4ull << 30;  // far beyond L2 and the 256 MB of last-level cache
+    if (!buf)
+    {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!buf)
+        {
+            void *p = nullptr;
+            if (hipMalloc(&p, BYTES) != hipSuccess)
+                return;
+            hipMemset(p, 1, BYTES);
+            hipDeviceSynchronize();
+            buf = p;
+        }
+    }
+    if (alu)
+        hipLaunchKernelGGL(burn_alu_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (float *)buf, alu);
+    if (mem)
+        hipLaunchKernelGGL(burn_mem_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)buf,
+                           (uint32_t)(BYTES / 64 - 1), mem, (uint32_t *)buf, ++salt);
+}
+#endif
+
 static uint32_t bits_for_count(uint32_t n)  // bits to hold values 0..n-1
 {
     uint32_t b = 1;
@@ -1182,9 +1255,17 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     // Forked front end (lpx_set_fork): the component grid goes to a side stream BEFORE the kd build is enqueued here --
     // both start from the obstacle cloud alone and touch disjoint buffers; the join sits where the first consumer of
     // the components (the sort by root) is enqueued.
-    const bool grid_cc = !ctx->use_lists && !skip_grid && !lpx_cc_from_chunks(m_max);
+#ifdef LPX_DEV_KNOBS
+    const bool sweep_cc = !ctx->use_lists && !skip_grid && !lpx_cc_from_chunks(m_max) && lpx_cc_from_sweep(m_max);
+#else
+    const bool sweep_cc = false;
+#endif
+    const bool grid_cc = !ctx->use_lists && !skip_grid && !lpx_cc_from_chunks(m_max) && !sweep_cc;
     const bool forked = grid_cc && ctx->fork && ctx->fork_stream && ctx->ev_fork && ctx->ev_join;
     int rc = LPX_OK;
+#ifdef LPX_DEV_KNOBS
+    burn_resources(ctx);
+#endif
     if (forked)
     {
         LPX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
@@ -1227,6 +1308,10 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
             (grid_cc && !forked &&
              (rc = lpx_grid_components(ctx, m_max, cfg->distance_squared, root, iota, clear_in_index))))
             return rc;
+#ifdef LPX_DEV_KNOBS
+        if (sweep_cc && (rc = lpx_sweep_components(ctx, m_max, cfg->distance_squared)))
+            return rc;
+#endif
         if (forked)
             LPX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
@@ -1235,7 +1320,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // (the kernel that writes the roots also counts their lowest byte per sort tile: lpx_sort_first_hist)
         uint32_t *first_hist = skip_sort ? nullptr : lpx_sort_first_hist(ctx, m_max);
         const dim3 gtile((m_max + LPX_SORT_TILE - 1) / LPX_SORT_TILE, 1, ctx->cur_b);
-        if (ctx->use_lists || lpx_cc_from_chunks(m_max))
+        if (ctx->use_lists || lpx_cc_from_chunks(m_max) || sweep_cc)
             hipLaunchKernelGGL(flatten_kernel, gtile, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
                                (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, first_hist, fv.fs);
         else if (grid_cc && !skip_grid)

@@ -198,6 +198,18 @@ struct lpx_ctx
     // of a cloud with this count and checksum runs on it without an upload; cleared once a clustering has consumed it
     bool seg_fresh = false;
     uint64_t seg_hash = 0;
+    // Look-ahead of the two-call form (lpx_set_lookahead): once an lpx_cluster call has found the obstacle cloud of the
+    // lpx_segment call before it resident, the next lpx_segment enqueues the clustering with that call's configuration
+    // right behind its own kernels and returns as soon as ITS results are down; a matching lpx_cluster then only waits
+    // for the chain that is already running.
+    int lookahead = 1;             // 1: learn and look ahead, 0: never
+    bool la_armed = false;         // the last lpx_cluster call was served from the resident cloud: la_cfg is what it asked for
+    bool la_pending = false;       // a clustering enqueued by lpx_segment is (or was) running on the resident cloud
+    lpx_clu_cfg la_cfg = {};
+    uint64_t la_hits = 0;          // lpx_cluster calls that found their clustering already enqueued (tests)
+    hipStream_t copy_stream = nullptr;  // downloads of the segmentation beside the look-ahead clustering
+    hipEvent_t ev_seg = nullptr;        // the segmentation's kernels (and the snapshot of its frame state) are done
+    void *h_frame = nullptr;            // pinned: that snapshot
     Buf pts4;                  // the cloud in original order, float4 {x, y, z, 0} per point
     Buf key_a, key_b;          // u32 keys ping-pong
     Buf val_a, val_b;          // u32 values ping-pong
@@ -375,6 +387,10 @@ void lpx_note_enqueue(lpx_ctx *ctx);
 // clear_grid: also empty the cell table of the component grid (lpx_grid_components(..., cleared = true) follows)
 int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2, bool clear_grid);
 bool lpx_cc_from_chunks(uint32_t m_max);  // components of the search path: chunk tables (large frames) or clique-cell grid
+#ifdef LPX_DEV_KNOBS
+bool lpx_cc_from_sweep(uint32_t m_max);   // ... or (development build, LPX_CC=sweep) a sweep over y-sorted x slabs
+int lpx_sweep_components(lpx_ctx *ctx, uint32_t m_max, float r2);  // leaves the forest in ctx->parent
+#endif
 int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root, uint32_t *d_iota, bool cleared);
 // the last kernel of the grid path, on ctx->stream: roots per point (+ the first histogram of the sort that follows)
 int lpx_grid_flatten(lpx_ctx *ctx, uint32_t m_max, uint32_t *d_root, uint32_t *d_iota, uint32_t *first_hist);

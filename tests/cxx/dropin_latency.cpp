@@ -30,7 +30,7 @@ static double median(std::vector<double> v)
 
 struct Timing
 {
-    double segment, recolour, cluster;
+    double segment, recolour, cluster, callback;  // callback: segment() entered -> cluster() returned
     std::size_t obstacles, clusters;
 };
 
@@ -43,7 +43,7 @@ static Timing run(lp::Segmenter &segmenter, lp::Clusterer &clusterer, const pcl:
     std::vector<lp::ClusteringLabel> clu_labels;
     pcl::PointCloud<pcl::PointXYZI> ground, obstacles;
     pcl::PointCloud<pcl::PointXYZRGBL> coloured;
-    std::vector<double> t_seg, t_col, t_clu;
+    std::vector<double> t_seg, t_col, t_clu, t_all;
     Timing out{};
     for (int r = 0; r < reps + 3; ++r)
     {
@@ -62,6 +62,7 @@ static Timing run(lp::Segmenter &segmenter, lp::Clusterer &clusterer, const pcl:
             t_seg.push_back(ms(t0, t1));
             t_col.push_back(ms(t1, t2));
             t_clu.push_back(ms(t2, t3));
+            t_all.push_back(ms(t0, t3));
         }
         out.obstacles = obstacles.size();
         out.clusters = clu_labels.empty() ? 0 : (std::size_t)(*std::max_element(clu_labels.begin(), clu_labels.end()) + 1);
@@ -69,6 +70,7 @@ static Timing run(lp::Segmenter &segmenter, lp::Clusterer &clusterer, const pcl:
     out.segment = median(t_seg);
     out.recolour = median(t_col);
     out.cluster = median(t_clu);
+    out.callback = median(t_all);
     return out;
 }
 
@@ -99,11 +101,18 @@ int main(int argc, char **argv)
         scfg.number_of_iterations = (std::uint32_t)std::atoi(argv[4]);
         ccfg.distance_squared = (float)std::atof(argv[5]);
     }
-    Timing shared{}, separate{};
+    Timing shared{}, plain{}, separate{};
     {
         lp::Segmenter segmenter;  // as the node constructs them: one shared context
         lp::Clusterer clusterer;
         shared = run(segmenter, clusterer, cloud, reps, scfg, ccfg);
+    }
+    {
+        auto context = std::make_shared<lp::detail::LpxContext>();
+        lpx_set_lookahead(context->get(), 0);
+        lp::Segmenter segmenter{context};
+        lp::Clusterer clusterer{context};
+        plain = run(segmenter, clusterer, cloud, reps, scfg, ccfg);
     }
     {
         lp::Segmenter segmenter{std::make_shared<lp::detail::LpxContext>()};
@@ -111,11 +120,15 @@ int main(int argc, char **argv)
         separate = run(segmenter, clusterer, cloud, reps, scfg, ccfg);
     }
     std::printf("{\"points\": %zu, \"obstacle_points\": %zu, \"clusters\": %zu, \"reps\": %d, "
-                "\"segment_ms\": %.4f, \"cluster_ms\": %.4f, \"segment_plus_cluster_ms\": %.4f, "
-                "\"node_recolour_copy_ms\": %.4f, \"separate_contexts\": {\"segment_ms\": %.4f, \"cluster_ms\": %.4f, "
-                "\"segment_plus_cluster_ms\": %.4f}}\n",
+                "\"segment_ms\": %.4f, \"cluster_ms\": %.4f, \"segment_plus_cluster_ms\": %.4f, \"callback_ms\": %.4f, "
+                "\"node_recolour_copy_ms\": %.4f, "
+                "\"lookahead_off\": {\"segment_ms\": %.4f, \"cluster_ms\": %.4f, \"segment_plus_cluster_ms\": %.4f, "
+                "\"callback_ms\": %.4f}, "
+                "\"separate_contexts\": {\"segment_ms\": %.4f, \"cluster_ms\": %.4f, "
+                "\"segment_plus_cluster_ms\": %.4f, \"callback_ms\": %.4f}}\n",
                 cloud.size(), shared.obstacles, shared.clusters, reps, shared.segment, shared.cluster,
-                shared.segment + shared.cluster, shared.recolour, separate.segment, separate.cluster,
-                separate.segment + separate.cluster);
-    return shared.clusters == separate.clusters ? 0 : 2;
+                shared.segment + shared.cluster, shared.callback, shared.recolour, plain.segment, plain.cluster,
+                plain.segment + plain.cluster, plain.callback, separate.segment, separate.cluster,
+                separate.segment + separate.cluster, separate.callback);
+    return shared.clusters == separate.clusters && shared.clusters == plain.clusters ? 0 : 2;
 }

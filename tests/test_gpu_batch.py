@@ -395,7 +395,7 @@ def test_xcd_affine_launch_geometry_is_a_bijection(mask):
     assert r.returncode == 0 and "remap check ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("method", ["chunks", "grid"])
+@pytest.mark.parametrize("method", ["chunks", "grid", "sweep", "sweep_plain"])
 def test_both_component_searches_give_the_single_frame_results(method):
     """the search path finds the connected components of the d-graph either from the kd groups' chunk tables (the
     default for frames of 400k points and more) or from the clique-cell grid (smaller frames); LPX_CC forces one --
@@ -406,7 +406,8 @@ def test_both_component_searches_give_the_single_frame_results(method):
     import sys
     from lidar_processing_amd import _lib
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, LPX_CC=method, LPX_LIB=_lib.DEV_LIB_PATH,
+    env = dict(os.environ, LPX_CC=method.split("_")[0], LPX_SWEEP_PLAIN="1" if method.endswith("_plain") else "0",
+               LPX_LIB=_lib.DEV_LIB_PATH,
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get("PYTHONPATH", "")]))
     r = subprocess.run([sys.executable, os.path.join(here, "remap_check.py")], env=env, capture_output=True, text=True,
                        timeout=900)

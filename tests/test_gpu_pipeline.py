@@ -525,6 +525,62 @@ def test_cluster_recognises_the_cloud_segment_left_on_the_device():
             c.close()
 
 
+def test_segment_looks_ahead_to_the_clustering_the_node_asks_for_next():
+    """lpx_set_lookahead (on by default): once cluster() has been served from the cloud segment() left on the device,
+    the next segment() enqueues that clustering itself and cluster() only waits for it -- frame after frame, with the
+    node's coloured_clouds() in between; a cluster() call with another configuration, another cloud, or no cluster() call
+    at all drops the guess and gives the plain results; turned off, nothing is guessed"""
+    from lidar_processing_amd import Context
+    frames = [load_frame(f) for f in FRAMES]
+    scfg, ccfg = SegmentationConfiguration(number_of_planar_partitions=6, number_of_iterations=5), ClusteringConfiguration(0.25, 0.5)
+    ocfg, ocfg2 = oracle.CluCfg(0.25, 0.5), oracle.CluCfg(0.18, 0.5)
+    oseg = oracle.SegCfg(number_of_planar_partitions=6, number_of_iterations=5)
+    wants = []
+    for pts in frames:
+        w = oracle.segment(pts, oseg)
+        wants.append((w, oracle.cluster(pts[w["obstacle_idx"]], ocfg), oracle.cluster(pts[w["obstacle_idx"]], ocfg2)))
+
+    def pair(c, k, cfg=ccfg, which=1, clouds=True):
+        pts, (w, *clu) = frames[k], wants[k]
+        lab, gi, oi, _ = c.segment(pts, scfg)
+        assert np.array_equal(lab, w["labels"]) and np.array_equal(gi, w["ground_idx"]) and np.array_equal(oi, w["obstacle_idx"])
+        if clouds:
+            g, o = c.coloured_clouds(len(gi), len(oi))
+            assert np.array_equal(o.view(np.float32)[:, :3], pts[oi][:, :3]) and np.array_equal(g.view(np.float32)[:, :3], pts[gi][:, :3])
+        got, nc = c.cluster(np.ascontiguousarray(pts[oi]), cfg)
+        assert nc == clu[which - 1][1] and np.array_equal(got, clu[which - 1][0])
+
+    for mode in ("lists", "search"):
+        c = Context(0)
+        try:
+            c.set_neighbour_mode(mode)
+            for k in range(6):
+                pair(c, k % len(frames), clouds=k % 2 == 0)
+            assert c.lookahead_hits() == 5, mode                 # every pair but the first
+            pair(c, 0, ClusteringConfiguration(0.18, 0.5), which=2)  # another configuration: the guess was wrong
+            assert c.lookahead_hits() == 5
+            pair(c, 1, ClusteringConfiguration(0.18, 0.5), which=2)  # nothing guessed; served from the resident cloud
+            assert c.lookahead_hits() == 5
+            pair(c, 2, ClusteringConfiguration(0.18, 0.5), which=2)  # guessed again, with the new configuration
+            assert c.lookahead_hits() == 6
+            c.segment(frames[0], scfg)                            # a guess nobody collects ...
+            pair(c, 1, ClusteringConfiguration(0.18, 0.5), which=2)  # ... is dropped
+            assert c.lookahead_hits() == 6
+            pair(c, 2, ClusteringConfiguration(0.18, 0.5), which=2)
+            assert c.lookahead_hits() == 7
+            other = np.ascontiguousarray(frames[0][wants[0][0]["obstacle_idx"]][:-1])
+            c.segment(frames[0], scfg)
+            got, nc = c.cluster(other, ClusteringConfiguration(0.18, 0.5))  # guessed for a cloud that is not the one passed
+            w2, n2 = oracle.cluster(other, ocfg2)
+            assert nc == n2 and np.array_equal(got, w2) and c.lookahead_hits() == 7
+            c.set_lookahead(False)
+            for k in range(3):
+                pair(c, k % len(frames), ClusteringConfiguration(0.18, 0.5), which=2)
+            assert c.lookahead_hits() == 7
+        finally:
+            c.close()
+
+
 def test_cxx_dropin_latency_harness_shares_one_context(tmp_path):
     """tests/cxx/dropin_latency.cpp (what bench.py times as the unchanged node's two calls): default-constructed
     Segmenter + Clusterer share one context and give the clusters of two objects with a context each"""
