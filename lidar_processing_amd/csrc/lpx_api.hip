@@ -1112,15 +1112,16 @@ static int segment_impl(lpx_ctx *ctx, const void *pts, size_t stride, const uint
                               (uint32_t *)ctx->d_gidx.p, (uint32_t *)ctx->d_oidx.p, (float *)ctx->d_planes.p)))
         return rc;
     FrameState fs;
-    const bool ahead = ctx->lookahead && ctx->la_armed && n > 0 && lookahead_ready(ctx);
+    bool ahead = ctx->lookahead && ctx->la_armed && n > 0 && lookahead_ready(ctx);
     if (ahead)
     {
         // the frame state as the segmentation leaves it (the clustering writes into the same record), then the
         // clustering right behind; the downloads wait for the segmentation only, on a stream of their own
         LPX_HIP(ctx, hipMemcpyAsync(ctx->h_frame, ctx->frame.p, sizeof(FrameState), hipMemcpyDeviceToHost, ctx->stream));
         LPX_HIP(ctx, hipEventRecord(ctx->ev_seg, ctx->stream));
-        if ((rc = lpx_run_cluster(ctx, n, &ctx->la_cfg, (int32_t *)ctx->d_clabels.p, nullptr, false)))
-            return rc;
+        ctx->la_failed = lpx_run_cluster(ctx, n, &ctx->la_cfg, (int32_t *)ctx->d_clabels.p, nullptr, false) != LPX_OK;
+        // (a clustering nobody asked for must not fail the segmentation: whatever of it was enqueued runs out harmlessly,
+        // the resident cloud counts as consumed, and lpx_cluster takes the plain path)
         hipStream_t const main_stream = ctx->stream;
         LPX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_seg, 0));
         ctx->stream = ctx->copy_stream;
@@ -1136,8 +1137,10 @@ static int segment_impl(lpx_ctx *ctx, const void *pts, size_t stride, const uint
     ctx->seg_valid = true;
     ctx->seg_ground = fs.n_ground;
     ctx->seg_obstacle = fs.n_obstacle;
-    ctx->seg_fresh = !ahead;  // the obstacle SoA and the kd input are as the compaction wrote them ...
-    ctx->la_pending = ahead;  // ... or the clustering that consumes them is on its way
+    ctx->seg_fresh = !ahead;                     // the obstacle SoA and the kd input are as the compaction wrote them ...
+    ctx->la_pending = ahead && !ctx->la_failed;  // ... or the clustering that consumes them is on its way
+    if (ahead && ctx->la_failed)
+        ctx->la_armed = false;
     ctx->seg_hash = fs.obs_hash;
     return LPX_OK;
 }
@@ -1407,13 +1410,24 @@ extern "C" int lpx_coloured_clouds(lpx_ctx *ctx, void *ground_records, void *obs
     char *grec = (char *)ctx->rec_out.p, *orec = grec + 32 * (size_t)n;
     ctx->cur_b = 1;
     ctx->upitch = 0;
-    if ((rc = lpx_run_colour(ctx, n, (const uint32_t *)ctx->d_gidx.p, (const uint32_t *)ctx->d_oidx.p, grec, orec)))
+    // While a look-ahead clustering runs on the context's stream the records are made beside it, on the stream that
+    // carried the segmentation's downloads: they need the points, the labels and the index lists only, none of which
+    // the clustering writes.
+    hipStream_t const main_stream = ctx->stream;
+    if (ctx->la_pending && ctx->copy_stream)
+        ctx->stream = ctx->copy_stream;
+    rc = lpx_run_colour(ctx, n, (const uint32_t *)ctx->d_gidx.p, (const uint32_t *)ctx->d_oidx.p, grec, orec);
+    hipError_t he = hipSuccess;
+    if (!rc && ng)
+        he = hipMemcpyAsync(ground_records, grec, 32 * (size_t)ng, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && he == hipSuccess && no)
+        he = hipMemcpyAsync(obstacle_records, orec, 32 * (size_t)no, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && he == hipSuccess)
+        he = hipStreamSynchronize(ctx->stream);
+    ctx->stream = main_stream;
+    if (rc)
         return rc;
-    if (ng)
-        LPX_HIP(ctx, hipMemcpyAsync(ground_records, grec, 32 * (size_t)ng, hipMemcpyDeviceToHost, ctx->stream));
-    if (no)
-        LPX_HIP(ctx, hipMemcpyAsync(obstacle_records, orec, 32 * (size_t)no, hipMemcpyDeviceToHost, ctx->stream));
-    LPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LPX_HIP(ctx, he);
     if (n_ground)
         *n_ground = ng;
     if (n_obstacle)

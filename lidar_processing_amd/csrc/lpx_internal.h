@@ -205,6 +205,7 @@ struct lpx_ctx
     int lookahead = 1;             // 1: learn and look ahead, 0: never
     bool la_armed = false;         // the last lpx_cluster call was served from the resident cloud: la_cfg is what it asked for
     bool la_pending = false;       // a clustering enqueued by lpx_segment is (or was) running on the resident cloud
+    bool la_failed = false;        // ... could not be enqueued (the segmentation call still succeeds)
     lpx_clu_cfg la_cfg = {};
     uint64_t la_hits = 0;          // lpx_cluster calls that found their clustering already enqueued (tests)
     hipStream_t copy_stream = nullptr;  // downloads of the segmentation beside the look-ahead clustering
