@@ -101,6 +101,32 @@ def test_stream_154_frames_match_reference_goldens(stream, cname):
     assert not bad, bad[:3]
 
 
+@pytest.mark.parametrize("mode", ["lists", "search"])
+def test_stream_through_the_two_calls_of_the_node(stream, mode):
+    """the unchanged node's form on all 154 frames in order: segment(), then cluster() on the obstacle cloud it returned,
+    one context -- from the second frame on every cluster() finds its clustering enqueued by segment()
+    (lpx_set_lookahead); every frame's outputs against the goldens of the reference build"""
+    cname = "p6i5_d025q05"
+    skw, ckw = STREAM_CONFIGS[cname]
+    scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
+    g = stream_gold()
+    c = Context(0)
+    bad = []
+    try:
+        c.set_neighbour_mode(mode)
+        for j, pts in enumerate(stream):
+            labels, gi, oi, planes = c.segment(pts, scfg)
+            cl, nc = c.cluster(np.ascontiguousarray(pts[oi]), ccfg)
+            row = golden_row(dict(n_ground=len(gi), n_obstacle=len(oi), n_clusters=nc, labels=labels, obstacle_idx=oi,
+                                  cluster_labels=cl, planes=planes))
+            if row != [int(v) for v in g[cname][j]]:
+                bad.append((stream_names()[j], row, g[cname][j].tolist()))
+        assert c.lookahead_hits() == len(stream) - 1
+    finally:
+        c.close()
+    assert not bad, bad[:3]
+
+
 @pytest.mark.parametrize("shape", [(256, 32, 8, 2, False), (640, 64, 10, 4, False), (512, 64, 4, 2, True),
                                    (1280, 64, 20, 4, False)],
                          ids=["8x32", "10x64", "4x64-overlap", "20x64"])
