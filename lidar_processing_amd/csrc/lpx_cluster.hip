@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void flatten_kernel(uint32_t *parent, const Fr
             x = p;
         }
         root[i] = x;
-        iota[i] = i;
+        if (iota)
+            iota[i] = i;
         state[i] = PT_FRESH;
         valid[i] = 0;
         cc_lo[i] = 0;
@@ -1320,11 +1321,14 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         // (the kernel that writes the roots also counts their lowest byte per sort tile: lpx_sort_first_hist)
         uint32_t *first_hist = skip_sort ? nullptr : lpx_sort_first_hist(ctx, m_max);
         const dim3 gtile((m_max + LPX_SORT_TILE - 1) / LPX_SORT_TILE, 1, ctx->cur_b);
+        // (the members going into the sort are the positions 0, 1, 2, ...: nobody writes them, the first pass makes
+        // them up -- lpx_sort_pairs(iota_vals))
+        uint32_t *const iota_out = skip_sort ? iota : (uint32_t *)nullptr;
         if (ctx->use_lists || lpx_cc_from_chunks(m_max) || sweep_cc)
-            hipLaunchKernelGGL(flatten_kernel, gtile, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota,
+            hipLaunchKernelGGL(flatten_kernel, gtile, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota_out,
                                (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, first_hist, fv.fs);
         else if (grid_cc && !skip_grid)
-            rc = lpx_grid_flatten(ctx, m_max, root, iota, first_hist);
+            rc = lpx_grid_flatten(ctx, m_max, root, iota_out, first_hist);
         if (rc)
             return rc;
         if (skip_sort)
@@ -1334,7 +1338,8 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         }
         else
             rc = lpx_sort_pairs(ctx, root, (uint32_t *)ctx->key_b.p, iota, (uint32_t *)ctx->val_b.p, m_max,
-                                &frame->n_obstacle, bits_for_count(m_max), &sroot, &members, first_hist != nullptr);
+                                &frame->n_obstacle, bits_for_count(m_max), &sroot, &members, first_hist != nullptr, nullptr,
+                                true);
         if (rc)
             return rc;
         hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, (const uint32_t *)sroot, (const uint32_t *)members, frame,

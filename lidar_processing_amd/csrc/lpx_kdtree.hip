@@ -2987,7 +2987,8 @@ __global__ __launch_bounds__(256) void grid_flatten_kernel(const FrameState *__r
         }
         const uint32_t rt = tstart[x];  // where the points of the root cell begin: one word per set, below M
         root[i] = rt;
-        iota[i] = i;
+        if (iota)
+            iota[i] = i;
         state[i] = 0;
         valid[i] = 0;
         cc_lo[i] = 0;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
         const bool valid = e < n;
         k[r] = valid ? keys_in[e] : (KeyT)0;
         if (HAS_VALS)
-            v[r] = valid ? vals_in[e] : 0u;
+            v[r] = valid ? (vals_in ? vals_in[e] : e) : 0u;  // (no value array: the values are the positions 0, 1, 2, ...)
     }
     // Global offset of (digit tid, this block) = counts of the lower digits in all blocks + counts of this digit in
     // the lower blocks.  Small tables hold raw counts, block-major: thread tid sums its column (coalesced rows, at
@@ -517,7 +517,7 @@ uint32_t *lpx_sort_first_hist(lpx_ctx *ctx, uint32_t n)
 
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
                    const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out, bool first_hist_ready,
-                   const LpxSortGather *gather)
+                   const LpxSortGather *gather, bool iota_vals)
 {
     const uint32_t nblocks = sort_blocks(n);
     int rc = ensure_hist(ctx, nblocks);
@@ -535,13 +535,16 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
                                n, d_n, shift, hist, nblocks, !large, fs);
         if (large)
             hipLaunchKernelGGL(hist_rows_kernel, dim3(RADIX, 1, B), dim3(SORT_THREADS), 0, ctx->stream, hist, nblocks, fs);
+        // iota_vals: the values going in are the positions themselves -- the first pass makes them up instead of
+        // reading an array somebody had to write first (4 bytes per element written and read back, for nothing)
+        const uint32_t *vin = (shift == 0 && iota_vals) ? (const uint32_t *)nullptr : va;
         if (gather && shift + 8 >= bits)  // the last pass also fetches the records the sorted values name
             hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
-                               ctx->stream, ka, kb, va, vb, n, d_n, shift, hist, nblocks, large, fs,
+                               ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large, fs,
                                (const float4 *)gather->records, gather->x, gather->y, gather->z);
         else
             hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
-                               ctx->stream, ka, kb, va, vb, n, d_n, shift, hist, nblocks, large, fs);
+                               ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large, fs);
         uint32_t *t = ka;
         ka = kb;
         kb = t;

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(INGEST_THREADS) void ingest_kernel(const char *__re
             {
                 const uint32_t k = lpx_float_key(x);
                 key[i] = k;
-                val[i] = i;
+                if (val)
+                    val[i] = i;
                 if (hist)
                     atomicAdd(&h[k & 255u], 1u);
             }
@@ -1665,7 +1666,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     {
         StageTimer tm(ctx, ST_INGEST);
         launch_ingest(ctx, n, d_pts, stride, nullptr, nullptr, nullptr, P4, (uint32_t *)ctx->key_a.p,
-                      (uint32_t *)ctx->val_a.p, frame, nullptr, first_hist);
+                      (uint32_t *)nullptr, frame, nullptr, first_hist);  // (the sort's values are the positions: iota_vals)
     }
     // segments that fit one workgroup's registers get their seed statistics by selection; larger ones (or more
     // representatives than the LDS sort holds) by the full (segment, z) sort
@@ -1682,7 +1683,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         StageTimer tm(ctx, ST_XSORT);
         rc = lpx_sort_pairs(ctx, (uint32_t *)ctx->key_a.p, (uint32_t *)ctx->key_b.p, (uint32_t *)ctx->val_a.p,
                             (uint32_t *)ctx->val_b.p, n, &frame->n_in, 32, &skeys, &sidx, first_hist != nullptr,
-                            fused_gather ? &sg : nullptr);
+                            fused_gather ? &sg : nullptr, true);
         if (rc)
             return rc;
     }
