@@ -1224,9 +1224,13 @@ static void burn_resources(lpx_ctx *ctx)
     }
     if (alu)
         hipLaunchKernelGGL(burn_alu_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (float *)buf, alu);
+    // LPX_BURN_SPAN_MB: the lines come from the first so many MB of the buffer (a power of two): 4096 = memory,
+    // 64 = what the 256 MB last-level cache holds, 2 = what one L2 holds
+    static const uint32_t span_mb = LPX_KNOB("LPX_BURN_SPAN_MB") ? (uint32_t)atoi(LPX_KNOB("LPX_BURN_SPAN_MB")) : 4096u;
+    const size_t span = ((size_t)(span_mb < 1u ? 1u : (span_mb > 4096u ? 4096u : span_mb))) << 20;
     if (mem)
         hipLaunchKernelGGL(burn_mem_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)buf,
-                           (uint32_t)(BYTES / 64 - 1), mem, (uint32_t *)buf, ++salt);
+                           (uint32_t)(span / 64 - 1), mem, (uint32_t *)buf, ++salt);
 }
 #endif
 
