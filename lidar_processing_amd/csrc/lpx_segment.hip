@@ -18,6 +18,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace
 {
@@ -406,6 +407,114 @@ __device__ __forceinline__ uint32_t sel_block_sum(uint32_t v, uint32_t *red, uin
     return s;
 }
 
+// the <= SEL_MAX_LPR keys in s_buf (padded with 0xffffffff to n_sort, a power of two), ascending; all SEL_THREADS threads
+__device__ __forceinline__ void sel_bitonic_sort(uint32_t *s_buf, uint32_t n_sort, uint32_t tid)
+{
+    // Bitonic sort, ascending, of the 8 keys per thread i = 512 w + 64 t + lane.  A compare-exchange at
+    // distance j2 pairs: the same lane of another register (j2 = 64, 128, 256), another lane of the same
+    // register (j2 < 64, one cross-lane read) or another wavefront's block (j2 >= 512, through LDS with
+    // workgroup barriers: 10 of the 91 stages).
+    const uint32_t w = tid / WAVE, lane = tid % WAVE;
+    uint32_t e[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        e[t] = s_buf[w * 512 + t * WAVE + lane];
+    for (uint32_t k2 = 2; k2 <= n_sort; k2 <<= 1)
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1)
+        {
+            if (j2 >= 512)
+            {
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    s_buf[w * 512 + t * WAVE + lane] = e[t];
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                {
+                    const uint32_t i = w * 512 + t * WAVE + lane;
+                    const uint32_t pv = s_buf[(i ^ j2) & (SEL_MAX_LPR - 1)];
+                    const bool keep_min = ((i & j2) == 0) == ((i & k2) == 0);
+                    e[t] = keep_min ? min(e[t], pv) : max(e[t], pv);
+                }
+            }
+            else if (j2 >= (uint32_t)WAVE)
+            {
+                // registers (a, b = a + j2 / 64) of one thread: a holds the lower index of the pair
+#define SEL_CE(a, b)                                                              \
+{                                                                             \
+    const bool up = (((w * 512 + (a) * WAVE + lane) & k2) == 0);              \
+    const uint32_t mn = min(e[a], e[b]), mx = max(e[a], e[b]);                \
+    e[a] = up ? mn : mx;                                                      \
+    e[b] = up ? mx : mn;                                                      \
+}
+                if (j2 == 64)
+                {
+                    SEL_CE(0, 1) SEL_CE(2, 3) SEL_CE(4, 5) SEL_CE(6, 7)
+                }
+                else if (j2 == 128)
+                {
+                    SEL_CE(0, 2) SEL_CE(1, 3) SEL_CE(4, 6) SEL_CE(5, 7)
+                }
+                else
+                {
+                    SEL_CE(0, 4) SEL_CE(1, 5) SEL_CE(2, 6) SEL_CE(3, 7)
+                }
+#undef SEL_CE
+            }
+            else
+            {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                {
+                    const uint32_t i = w * 512 + t * WAVE + lane;
+                    const uint32_t pv = (uint32_t)__shfl_xor((int)e[t], (int)j2, WAVE);
+                    const bool keep_min = ((i & j2) == 0) == ((i & k2) == 0);
+                    e[t] = keep_min ? min(e[t], pv) : max(e[t], pv);
+                }
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        s_buf[w * 512 + t * WAVE + lane] = e[t];
+    __syncthreads();
+}
+
+// mean of the n_rep lowest z (float bits in s_buf, ascending) + threshold; thread 0 only
+__device__ __forceinline__ float sel_sequential_zmax(const uint32_t *s_buf, uint32_t n_rep, float seed_thr)
+{
+    // strictly sequential adds in ascending z (bit-exact with the reference's loop, :193-197); the LDS reads
+    // are hoisted sixteen at a time so that only the add chain is serial
+    const float *zf = (const float *)s_buf;
+    float sum = 0.0f;
+    uint32_t i = 0;
+    for (; i + 16 <= n_rep; i += 16)
+    {
+        const float4 a = *(const float4 *)&zf[i], b = *(const float4 *)&zf[i + 4];
+        const float4 c4 = *(const float4 *)&zf[i + 8], d = *(const float4 *)&zf[i + 12];
+        sum += a.x;
+        sum += a.y;
+        sum += a.z;
+        sum += a.w;
+        sum += b.x;
+        sum += b.y;
+        sum += b.z;
+        sum += b.w;
+        sum += c4.x;
+        sum += c4.y;
+        sum += c4.z;
+        sum += c4.w;
+        sum += d.x;
+        sum += d.y;
+        sum += d.z;
+        sum += d.w;
+    }
+    for (; i < n_rep; ++i)
+        sum += zf[i];
+    return sum / (float)n_rep + seed_thr;
+}
+
 // (Plane pass 0 -- the moments of the seeds -- was folded into this kernel once: it holds every z of the segment in
 // registers, x and y of the seeds are two more loads per point.  One launch less, 0.013 ms more per 64-frame chain alone,
 // and 2 % LESS throughput with sixteen chains in flight: this is a 1024-thread workgroup, the kind that waits longest
@@ -535,112 +644,14 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
         for (uint32_t i = tid; i < need; i += SEL_THREADS)
             s_buf[below + i] = K;
         __syncthreads();
-        // Bitonic sort, ascending, of the 8 keys per thread i = 512 w + 64 t + lane.  A compare-exchange at
-        // distance j2 pairs: the same lane of another register (j2 = 64, 128, 256), another lane of the same
-        // register (j2 < 64, one cross-lane read) or another wavefront's block (j2 >= 512, through LDS with
-        // workgroup barriers: 10 of the 91 stages).
-        const uint32_t w = tid / WAVE, lane = tid % WAVE;
-        uint32_t e[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-            e[t] = s_buf[w * 512 + t * WAVE + lane];
-        for (uint32_t k2 = 2; k2 <= n_sort; k2 <<= 1)
-            for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1)
-            {
-                if (j2 >= 512)
-                {
-                    __syncthreads();
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        s_buf[w * 512 + t * WAVE + lane] = e[t];
-                    __syncthreads();
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                    {
-                        const uint32_t i = w * 512 + t * WAVE + lane;
-                        const uint32_t pv = s_buf[(i ^ j2) & (SEL_MAX_LPR - 1)];
-                        const bool keep_min = ((i & j2) == 0) == ((i & k2) == 0);
-                        e[t] = keep_min ? min(e[t], pv) : max(e[t], pv);
-                    }
-                }
-                else if (j2 >= (uint32_t)WAVE)
-                {
-                    // registers (a, b = a + j2 / 64) of one thread: a holds the lower index of the pair
-#define SEL_CE(a, b)                                                              \
-    {                                                                             \
-        const bool up = (((w * 512 + (a) * WAVE + lane) & k2) == 0);              \
-        const uint32_t mn = min(e[a], e[b]), mx = max(e[a], e[b]);                \
-        e[a] = up ? mn : mx;                                                      \
-        e[b] = up ? mx : mn;                                                      \
-    }
-                    if (j2 == 64)
-                    {
-                        SEL_CE(0, 1) SEL_CE(2, 3) SEL_CE(4, 5) SEL_CE(6, 7)
-                    }
-                    else if (j2 == 128)
-                    {
-                        SEL_CE(0, 2) SEL_CE(1, 3) SEL_CE(4, 6) SEL_CE(5, 7)
-                    }
-                    else
-                    {
-                        SEL_CE(0, 4) SEL_CE(1, 5) SEL_CE(2, 6) SEL_CE(3, 7)
-                    }
-#undef SEL_CE
-                }
-                else
-                {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                    {
-                        const uint32_t i = w * 512 + t * WAVE + lane;
-                        const uint32_t pv = (uint32_t)__shfl_xor((int)e[t], (int)j2, WAVE);
-                        const bool keep_min = ((i & j2) == 0) == ((i & k2) == 0);
-                        e[t] = keep_min ? min(e[t], pv) : max(e[t], pv);
-                    }
-                }
-            }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-            s_buf[w * 512 + t * WAVE + lane] = e[t];
-        __syncthreads();
+        sel_bitonic_sort(s_buf, n_sort, tid);
         // keys -> float bits in place, so that the summing lane reads floats
         for (uint32_t i = tid; i < n_sort; i += SEL_THREADS)
             s_buf[i] = __float_as_uint(lpx_key_float(s_buf[i]));
     }
     __syncthreads();
     if (tid == 0)
-    {
-        // strictly sequential adds in ascending z (bit-exact with the reference's loop, :193-197); the LDS reads
-        // are hoisted sixteen at a time so that only the add chain is serial
-        const float *zf = (const float *)s_buf;
-        float sum = 0.0f;
-        uint32_t i = 0;
-        for (; i + 16 <= n_rep; i += 16)
-        {
-            const float4 a = *(const float4 *)&zf[i], b = *(const float4 *)&zf[i + 4];
-            const float4 c4 = *(const float4 *)&zf[i + 8], d = *(const float4 *)&zf[i + 12];
-            sum += a.x;
-            sum += a.y;
-            sum += a.z;
-            sum += a.w;
-            sum += b.x;
-            sum += b.y;
-            sum += b.z;
-            sum += b.w;
-            sum += c4.x;
-            sum += c4.y;
-            sum += c4.z;
-            sum += c4.w;
-            sum += d.x;
-            sum += d.y;
-            sum += d.z;
-            sum += d.w;
-        }
-        for (; i < n_rep; ++i)
-            sum += zf[i];
-        s_zmax = sum / (float)n_rep + prm.seed_thr;
-    }
+        s_zmax = sel_sequential_zmax(s_buf, n_rep, prm.seed_thr);
     __syncthreads();
     const float z_max = s_zmax;
     // points of the remainder up to z_max; none above z_max -> no seeds (Q4)
@@ -656,6 +667,265 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
         o.lo_excl = (cut > 0) ? prm.z_floor : -INFINITY;
         o.hi_incl = z_max;
         o.has_seeds = n_seed > 0;
+        o.failed = (ns < 3) ? 2u : 0u;  // :224-229 nothing is labelled
+        o.plane[0] = o.plane[1] = o.plane[2] = o.plane[3] = 0.0f;
+        o.fitted = 0;
+        o.thr = 0.0f;
+        o.pad[0] = o.pad[1] = 0;
+        st[s] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same selection for segments that do not fit one workgroup's registers (BASELINE's 1M- and 5M-point clouds hold
+// 83k and 208k points per segment).  They used to take the full (segment, z) sort -- a gather launch that also built
+// 64-bit keys and five radix passes over all N of them, 1.5 GB of the 10.7 GB a 5M-point frame moves -- for statistics
+// that need the n_lpr lowest z of a segment.  Here the radix select runs over the keys where they lie: four histogram
+// passes over ZS (9 + 9 + 9 + 5 bits; tiles of 8192 keys, one workgroup each, private LDS histograms added to the
+// segment's 512 global bins), every workgroup of pass r first reading the bin that pass r - 1 settled on; then one
+// pass that collects the keys below the key of rank n_rep, and one workgroup per segment that sorts and sums them
+// exactly like seed_select_kernel.  The rank is taken among ALL keys of the segment: the keys at or below the floor
+// are its `cut` lowest, so the n_rep lowest of the remainder are ranks cut + 1 .. cut + n_rep (:171-182).  Whether any
+// remainder point lies above z_max -- the only use of the count at :205-217 -- follows from the segment's largest key.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t SELW_TILE = 8192;
+constexpr int SELW_THREADS = 256;
+struct SelWide  // per segment, in the 64-bit key scratch (unused on this path)
+{
+    uint32_t c_floor;  // keys at or below the floor
+    uint32_t max_key;  // the segment's largest key
+    uint32_t fill;     // keys collected
+    uint32_t pad;
+    uint32_t hist[4][SEL_BINS];
+    uint32_t keys[SEL_MAX_LPR];
+};
+struct SelPick
+{
+    uint32_t cut, nrem, n_rep, prefix, pmask, need;
+};
+
+// What the histograms of rounds [0, upto) say (all NT threads of the workgroup; s_scr: NT / 64 + 2 words)
+template <int NT>
+__device__ __forceinline__ SelPick selw_pick(const SelWide *sw, uint32_t ns, uint32_t n_lpr, int upto, uint32_t *s_scr,
+                                             uint32_t tid)
+{
+    SelPick p;
+    const uint32_t c_floor = sw->c_floor;
+    p.cut = (c_floor < ns) ? c_floor : 0u;  // :171-182 no point above the floor -> nothing dropped
+    p.nrem = ns - p.cut;
+    p.n_rep = min(p.nrem, n_lpr);
+    p.prefix = 0;
+    p.pmask = 0;
+    uint32_t need = p.cut + p.n_rep;  // 1-based rank among all keys of the segment
+    const int shifts[4] = {23, 14, 5, 0}, bits[4] = {9, 9, 9, 5};
+    for (int r = 0; r < upto; ++r)
+    {
+        uint32_t h0 = 0, h1 = 0;  // thread t < 256 owns bins 2 t and 2 t + 1
+        if (tid < (uint32_t)SEL_BINS / 2u)
+        {
+            h0 = sw->hist[r][2u * tid];
+            h1 = sw->hist[r][2u * tid + 1u];
+        }
+        const uint32_t hs = h0 + h1;
+        const uint32_t incl = lpx_wave_incl_scan_u32(hs);
+        if ((tid % WAVE) == WAVE - 1)
+            s_scr[tid / WAVE] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t i = 0; i < tid / WAVE; ++i)
+            wbase += s_scr[i];
+        const uint32_t before = wbase + incl - hs;  // keys in bins below 2 t
+        if (tid < (uint32_t)SEL_BINS / 2u)
+        {
+            if (before < need && need <= before + h0)
+            {
+                s_scr[NT / WAVE] = 2u * tid;
+                s_scr[NT / WAVE + 1] = before;
+            }
+            else if (before + h0 < need && need <= before + hs)
+            {
+                s_scr[NT / WAVE] = 2u * tid + 1u;
+                s_scr[NT / WAVE + 1] = before + h0;
+            }
+        }
+        __syncthreads();
+        p.prefix |= s_scr[NT / WAVE] << shifts[r];
+        p.pmask |= ((1u << bits[r]) - 1u) << shifts[r];
+        need -= s_scr[NT / WAVE + 1];
+        __syncthreads();
+    }
+    p.need = need;
+    return p;
+}
+
+__global__ void selw_clear_kernel(SelWide *__restrict__ sw, size_t fs)
+{
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
+    sw = lpx_slot(sw, fs) + lpx_blk.x;
+    uint32_t *w = (uint32_t *)sw;
+    for (uint32_t i = threadIdx.x; i < 4u + 4u * SEL_BINS; i += blockDim.x)
+        w[i] = 0;
+}
+
+template <int R>  // R = 0 .. 3: histogram of round R; R = 4: collect the keys below the key the four rounds settled on
+__global__ __launch_bounds__(SELW_THREADS) void selw_pass_kernel(const float *__restrict__ ZS, SegParams prm,
+                                                                  SelWide *__restrict__ sw,
+                                                                  const FrameState *__restrict__ frame, size_t fs)
+{
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
+    __shared__ uint32_t s_hist[SELW_THREADS / WAVE][SEL_BINS];
+    __shared__ uint32_t s_scr[SELW_THREADS / WAVE + 2];
+    ZS = lpx_slot(ZS, fs);
+    seg_bind(prm, lpx_slot(frame, fs));
+    const uint32_t s = lpx_blk.y, tid = threadIdx.x, ns = prm.n_per;
+    const uint32_t t0 = lpx_blk.x * SELW_TILE;
+    if (t0 >= ns)
+        return;
+    SelWide *w = lpx_slot(sw, fs) + s;
+    const uint32_t base = s * ns, floor_key = lpx_float_key(prm.z_floor);
+    const SelPick pk = selw_pick<SELW_THREADS>(w, ns, prm.n_lpr, R < 4 ? R : 4, s_scr, tid);
+    const int shifts[4] = {23, 14, 5, 0}, bits[4] = {9, 9, 9, 5};
+    if (R < 4)
+    {
+        for (uint32_t i = tid; i < (SELW_THREADS / WAVE) * SEL_BINS; i += SELW_THREADS)
+            (&s_hist[0][0])[i] = 0;
+        __syncthreads();
+    }
+    const uint32_t wv = tid / WAVE;
+    const unsigned long long lt = lpx_lanemask_lt();
+    uint32_t cfl = 0, mx = 0;
+    for (uint32_t i0 = 0; i0 < SELW_TILE; i0 += 4 * SELW_THREADS)
+    {
+        uint32_t k[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)  // four keys per thread and trip: the loads go out together
+        {
+            const uint32_t q = t0 + i0 + u * SELW_THREADS + tid;
+            in[u] = q < ns;
+            k[u] = in[u] ? lpx_float_key(ZS[base + q]) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            if (R == 0 && in[u])
+            {
+                cfl += k[u] <= floor_key;
+                mx = max(mx, k[u]);
+            }
+            if (R < 4)
+            {
+                if (in[u] && (k[u] & pk.pmask) == pk.prefix)
+                    atomicAdd(&s_hist[wv][(k[u] >> shifts[R & 3]) & ((1u << bits[R & 3]) - 1u)], 1u);
+            }
+            else
+            {
+                // the n_rep lowest of the remainder without the copies of K itself: below K, above the floor if any
+                // key was dropped there; one atomic per wavefront and slot
+                const bool take = in[u] && k[u] < pk.prefix && (pk.cut == 0u || k[u] > floor_key);
+                const unsigned long long tm = __ballot(take);
+                if (tm)
+                {
+                    uint32_t pos = 0;
+                    if ((tid % WAVE) == 0)
+                        pos = atomicAdd(&w->fill, (uint32_t)__popcll(tm));
+                    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                    if (take)
+                        w->keys[pos + __popcll(tm & lt)] = k[u];
+                }
+            }
+        }
+    }
+    if (R < 4)
+    {
+        __syncthreads();
+        for (uint32_t b = tid; b < (uint32_t)SEL_BINS; b += SELW_THREADS)
+        {
+            uint32_t h = 0;
+#pragma unroll
+            for (int ww = 0; ww < SELW_THREADS / WAVE; ++ww)
+                h += s_hist[ww][b];
+            if (h)
+                atomicAdd(&w->hist[R & 3][b], h);
+        }
+    }
+    if (R == 0)
+    {
+        cfl = lpx_wave_sum_u32(cfl);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        if ((tid % WAVE) == 0)
+        {
+            if (cfl)
+                atomicAdd(&w->c_floor, cfl);
+            atomicMax(&w->max_key, mx);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void selw_final_kernel(SegParams prm, const SelWide *__restrict__ sw,
+                                                                  SegState *__restrict__ st, long long *__restrict__ facc,
+                                                                  const FrameState *__restrict__ frame, size_t fs)
+{
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[SEL_MAX_LPR];
+    __shared__ uint32_t s_scr[SEL_THREADS / WAVE + 2];
+    __shared__ float s_zmax, s_zmin;
+    st = lpx_slot(st, fs);
+    facc = lpx_slot(facc, fs);
+    seg_bind(prm, lpx_slot(frame, fs));
+    const uint32_t s = lpx_blk.x, tid = threadIdx.x, ns = prm.n_per;
+    const SelWide *w = lpx_slot(sw, fs) + s;
+    seg_far_reset(facc, s, tid);
+    if (ns == 0)
+    {
+        if (tid == 0)
+        {
+            const float none = (float)ns;  // (a frame of the batch with fewer points than partitions)
+            SegState o;
+            o.lo_excl = -INFINITY;
+            o.hi_incl = none / none + prm.seed_thr;  // as seed_select_kernel leaves it: the mean of nothing
+            o.has_seeds = 0;
+            o.failed = 2u;
+            o.plane[0] = o.plane[1] = o.plane[2] = o.plane[3] = 0.0f;
+            o.fitted = 0;
+            o.thr = 0.0f;
+            o.pad[0] = o.pad[1] = 0;
+            st[s] = o;
+        }
+        return;
+    }
+    const SelPick pk = selw_pick<SEL_THREADS>(w, ns, prm.n_lpr, 4, s_scr, tid);
+    const uint32_t K = pk.prefix, n_rep = pk.n_rep, below = n_rep - pk.need;  // == w->fill
+    uint32_t n_sort = 1;
+    while (n_sort < n_rep)
+        n_sort <<= 1;
+    for (uint32_t i = tid; i < SEL_MAX_LPR; i += SEL_THREADS)
+        s_buf[i] = i < below ? w->keys[i] : (i < n_rep ? K : 0xffffffffu);
+    __syncthreads();
+    sel_bitonic_sort(s_buf, n_sort, tid);
+    // keys -> float bits in place, so that the summing lane reads floats
+    for (uint32_t i = tid; i < n_sort; i += SEL_THREADS)
+        s_buf[i] = __float_as_uint(lpx_key_float(s_buf[i]));
+    __syncthreads();
+    if (tid == 0)
+    {
+        s_zmin = __uint_as_float(s_buf[0]);
+        s_zmax = sel_sequential_zmax(s_buf, n_rep, prm.seed_thr);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        // seeds = the points of the remainder up to z_max; none above z_max -> no seeds (Q4).  Some remainder point is
+        // up to z_max iff the lowest one is; some lies above iff the segment's highest point does (when keys were cut
+        // at the floor, the highest point is above it and belongs to the remainder).
+        const float z_max = s_zmax;
+        const bool some_le = !(s_zmin > z_max), some_gt = lpx_key_float(w->max_key) > z_max;
+        SegState o;
+        o.lo_excl = (pk.cut > 0) ? prm.z_floor : -INFINITY;
+        o.hi_incl = z_max;
+        o.has_seeds = some_le && some_gt;
         o.failed = (ns < 3) ? 2u : 0u;  // :224-229 nothing is labelled
         o.plane[0] = o.plane[1] = o.plane[2] = o.plane[3] = 0.0f;
         o.fitted = 0;
@@ -1672,10 +1942,15 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     // representatives than the LDS sort holds) by the full (segment, z) sort
     const bool select_seeds = prm.n_per <= SEL_MAX_POINTS && prm.n_lpr <= SEL_MAX_LPR;
     // (the selection path needs nothing from gather_kernel but the x-sorted SoA: the last pass of the sort writes it)
+    // ... and longer segments by the same selection spread over many workgroups (selw_*), unless the development build
+    // says LPX_SEEDS=sort
+    static const char *seeds_env = LPX_KNOB("LPX_SEEDS");
+    const bool select_wide = !select_seeds && prm.n_lpr <= SEL_MAX_LPR && sizeof(SelWide) * (size_t)P <= ctx->key64_a.bytes &&
+                             !(seeds_env && strcmp(seeds_env, "sort") == 0);
 #ifdef LPX_NO_FUSED_GATHER
     const bool fused_gather = false;
 #else
-    const bool fused_gather = select_seeds && !(B == 1 && prm.n_per == 0);
+    const bool fused_gather = (select_seeds || select_wide) && !(B == 1 && prm.n_per == 0);
 #endif
     const LpxSortGather sg = {P4, XS, YS, ZS};
     uint32_t *skeys = nullptr, *sidx = nullptr;
@@ -1699,7 +1974,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         StageTimer tm(ctx, ST_GATHER);
         hipLaunchKernelGGL(gather_kernel, dim3((n + 256 * GATHER_ITEMS - 1) / (256 * GATHER_ITEMS), 1, B), blk, 0, st, sidx,
                            (const float4 *)P4, XS, YS, ZS,
-                           select_seeds ? (uint64_t *)nullptr : (uint64_t *)ctx->key64_a.p, prm,
+                           (select_seeds || select_wide) ? (uint64_t *)nullptr : (uint64_t *)ctx->key64_a.p, prm,
                            (const FrameState *)frame, fv.fs);
     }
     SegState *sst = (SegState *)ctx->seg_state.p;
@@ -1709,6 +1984,20 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     {
         StageTimer tm(ctx, ST_SEEDS);
         hipLaunchKernelGGL(seed_select_kernel, dim3(P, 1, B), dim3(SEL_THREADS), 0, st, ZS, prm, sst, facc,
+                           (const FrameState *)frame, fv.fs);
+    }
+    else if (select_wide)
+    {
+        StageTimer tm(ctx, ST_SEEDS);
+        SelWide *sw = (SelWide *)ctx->key64_a.p;
+        const dim3 gw((prm.n_per + SELW_TILE - 1) / SELW_TILE, P, B), bw(SELW_THREADS);
+        hipLaunchKernelGGL(selw_clear_kernel, dim3(P, 1, B), dim3(256), 0, st, sw, fv.fs);
+        hipLaunchKernelGGL(selw_pass_kernel<0>, gw, bw, 0, st, ZS, prm, sw, (const FrameState *)frame, fv.fs);
+        hipLaunchKernelGGL(selw_pass_kernel<1>, gw, bw, 0, st, ZS, prm, sw, (const FrameState *)frame, fv.fs);
+        hipLaunchKernelGGL(selw_pass_kernel<2>, gw, bw, 0, st, ZS, prm, sw, (const FrameState *)frame, fv.fs);
+        hipLaunchKernelGGL(selw_pass_kernel<3>, gw, bw, 0, st, ZS, prm, sw, (const FrameState *)frame, fv.fs);
+        hipLaunchKernelGGL(selw_pass_kernel<4>, gw, bw, 0, st, ZS, prm, sw, (const FrameState *)frame, fv.fs);
+        hipLaunchKernelGGL(selw_final_kernel, dim3(P, 1, B), dim3(SEL_THREADS), 0, st, prm, (const SelWide *)sw, sst, facc,
                            (const FrameState *)frame, fv.fs);
     }
     else

@@ -414,6 +414,23 @@ def test_both_component_searches_give_the_single_frame_results(method):
     assert r.returncode == 0 and "remap check ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_ragged_batch_with_long_segments(ctx):
+    """one frame whose segments exceed a workgroup's registers puts the whole chain on the many-workgroup seed selection:
+    the short frames beside it (down to fewer points than partitions) must still equal their single-frame results"""
+    big = np.concatenate([load_frame(f) for f in FRAMES])[:200_000]
+    clouds = [big, load_frame(FRAMES[0])[:1], load_frame(FRAMES[1])[:100], load_frame(FRAMES[2])[:30_000], big[:60_001]]
+    seg = dict(number_of_planar_partitions=2, number_of_iterations=3)
+    for mode in ("search", "lists"):
+        bctx = Context(0, batch=len(clouds))
+        try:
+            bctx.set_neighbour_mode(mode)
+            res = run_batch(bctx, clouds, seg, CLU)
+        finally:
+            bctx.close()
+        for c, r in zip(clouds, res):
+            check_frame(r, single(ctx, c, seg, CLU))
+
+
 def test_forked_front_end_gives_the_same_results():
     """lpx_set_fork: the component grid of a chain on a side stream beside its kd build and chunk tables -- alone and
     together with lpx_set_overlap, several calls back to back on one context"""

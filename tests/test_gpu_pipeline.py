@@ -82,6 +82,34 @@ def test_segment_single_workgroup_limit(ctx, n_per):
     check_segment(ctx, pts, number_of_planar_partitions=3, number_of_iterations=4)
 
 
+@pytest.mark.parametrize("case", ["ties", "few_values", "all_below_floor", "half_below_floor", "no_seeds", "floor_ties",
+                                  "ramp"])
+def test_segment_wide_selection_edge_cases(ctx, case):
+    """segments longer than one workgroup holds (30 000 points each) take the selection that is spread over many
+    workgroups (selw_*): ties at the key of rank n_rep, keys at or below the floor (:171-182), every point within the
+    seed threshold (:202-216), against the oracle; and with more representatives than the selection sorts (the sort path)"""
+    rng = np.random.default_rng(11)
+    n = 60_000
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, 0] = rng.random(n) * 60 - 30
+    pts[:, 1] = rng.random(n) * 60 - 30
+    z = {
+        "ties": np.full(n, -1.7),
+        "few_values": rng.choice(np.array([-1.9, -1.7, -1.65, 0.4, 2.0]), n),
+        "all_below_floor": np.full(n, -5.0) + rng.random(n) * 0.01,
+        "half_below_floor": np.where(rng.random(n) < 0.5, -4.0, -1.7 + rng.normal(0, 0.05, n)),
+        "no_seeds": -1.7 + rng.random(n) * 0.2,
+        "floor_ties": np.where(rng.random(n) < 0.3, -1.5 * 1.73, -1.7 + rng.normal(0, 0.1, n)),
+        "ramp": np.linspace(-2.0, 3.0, n)[rng.permutation(n)],
+    }[case]
+    pts[:, 2] = z.astype(np.float32)
+    if case in ("ties", "few_values", "ramp"):
+        pts[: n // 4, 2] += np.float32(1.5)
+    for n_lpr in (1, 5000, 8192, 9000):
+        check_segment(ctx, pts, number_of_planar_partitions=2, number_of_iterations=2,
+                      number_of_lower_point_representatives=n_lpr)
+
+
 @pytest.mark.parametrize("kw", [dict(number_of_planar_partitions=256, number_of_iterations=2),
                                 dict(number_of_planar_partitions=1, number_of_iterations=64),
                                 dict(number_of_planar_partitions=5, number_of_iterations=1, sensor_height_m=2.5,
