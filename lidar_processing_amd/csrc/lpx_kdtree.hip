@@ -607,7 +607,10 @@ constexpr int BLK_CAP_BATCH = 1984;  // batches: kd_lds_kernel needs 20 B x 1984
 constexpr int BLK_CAP_MAX = 4096;  // most nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch (blk_cap is a launch argument)
 constexpr int BLK_TAIL = 1024;  // batches, upper levels: the active range is staged in LDS once it is this small
 constexpr int WAVE_TAIL = 1024;  // kd_block_kernel: a staged range this small is finished by one wavefront
-constexpr uint32_t BLK_WIDE = 80000;  // batches: levels whose ranges may exceed this many nodes get 1024-thread workgroups,
+// batches: levels whose ranges may exceed BLK_WIDE nodes get 1024-thread workgroups -- none does (it was 80 000): under
+// load a 1024-thread workgroup waits for a whole compute unit, and 256 threads on every level are as fast for 120k-point
+// chains (1 990 against 1 987 Mpts/s) and 3 % faster for 1M-point ones (1 518 against 1 450-1 488, tools/r4_probe25.sh)
+constexpr uint32_t BLK_WIDE = 0xffffffffu;
 constexpr uint32_t BLK_MID = 0;       // ... this many 256 threads, shorter ones a single wavefront
 constexpr int SUB_LEAF = 4;    // at or below this one lane finishes a subtree on its own
 

@@ -490,8 +490,14 @@ int lpx_exclusive_scan(lpx_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t
         const dim3 grid(tiles, 1, ctx->cur_b);
         hipLaunchKernelGGL(scan_tiles_kernel<false>, grid, dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, sums,
                            ctx->fs_tag);
-        hipLaunchKernelGGL(scan_kernel<SCAN_THREADS>, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream,
-                           (const uint32_t *)sums, sums, tiles, (const uint32_t *)nullptr, d_total, ctx->fs_tag);
+        // (the tile sums of a frame are a few hundred words: in a chain a 256-thread workgroup, which a loaded device
+        // places at once, where a 1024-thread one waited 4.5 ms per 1M-point chain for a whole compute unit)
+        if (chain)
+            hipLaunchKernelGGL(scan_kernel<256>, dim3(1, 1, ctx->cur_b), dim3(256), 0, ctx->stream, (const uint32_t *)sums,
+                               sums, tiles, (const uint32_t *)nullptr, d_total, ctx->fs_tag);
+        else
+            hipLaunchKernelGGL(scan_kernel<SCAN_THREADS>, dim3(1, 1, ctx->cur_b), dim3(SCAN_THREADS), 0, ctx->stream,
+                               (const uint32_t *)sums, sums, tiles, (const uint32_t *)nullptr, d_total, ctx->fs_tag);
         hipLaunchKernelGGL(scan_tiles_kernel<true>, grid, dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_n, sums,
                            ctx->fs_tag);
         LPX_HIP(ctx, hipGetLastError());
