@@ -123,6 +123,20 @@ def test_dropin_headers_compile_like_processor(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_latency_harness_compiles_against_the_headers(tmp_path):
+    """tests/cxx/dropin_latency.cpp -- what bench.py builds on the GPU box for latency.dropin_cxx (three set-ups: shared
+    context with the look-ahead, without it, a context each) -- compiles and links here"""
+    from lidar_processing_amd import _lib
+    _lib.build()
+    exe = tmp_path / "dropin_latency"
+    cmd = ["g++", "-std=c++17", "-O1", f"-I{ROOT}/include", f"-I{ROOT}/include/lidar_processing",
+           f"-I{ROOT}/tests/cxx", f"{ROOT}/tests/cxx/dropin_latency.cpp", "-o", str(exe),
+           f"-L{ROOT}/lidar_processing_amd", "-llpx", f"-Wl,-rpath,{ROOT}/lidar_processing_amd",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_binding_recipe_survives_quoted_include_resolution(tmp_path):
     """src/processor.cpp includes "segmentation.hpp" / "clustering.hpp" with quotes, and a quoted include searches
     the including file's own directory before any -I path.  A caller that sits NEXT TO same-named CPU headers (as
