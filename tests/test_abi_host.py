@@ -259,6 +259,46 @@ def test_multi_rank_aggregation_gloo():
     assert res == [(0, 1.5, 3000.0), (1, 1.5, 3000.0)]
 
 
+def _worker_world1(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    calls = []
+    real_ar, real_ag = dist.all_reduce, dist.all_gather
+    dist.all_reduce = lambda *a, **k: (calls.append("all_reduce"), real_ar(*a, **k))[1]
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), real_ag(*a, **k))[1]
+    agg = bench.aggregate(0.125, 1000.0, torch.device("cpu"), 1, 64)
+    rows = bench.gather_per_rank([1.5, -2.25], torch.device("cpu"), 1)
+    dist.destroy_process_group()
+    q.put((agg, rows, calls))
+
+
+def test_world_1_group_still_runs_the_collectives():
+    """the RCCL self-test (`bench.py --dist-selftest`, world 1) must EXECUTE the all-reduces and the all-gather of the
+    N > 1 line, not skip them because world == 1: with a process group alive aggregate() / gather_per_rank() go through
+    torch.distributed (gloo here; the RCCL run is tests/test_gpu_stream.py::test_rccl_world_1_selftest)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_world1, args=(31500 + os.getpid() % 2000, q))
+    p.start()
+    agg, rows, calls = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert agg == (0.125, 1000.0, 64.0) and rows == [[1.5, -2.25]]
+    assert calls == ["all_reduce", "all_reduce", "all_gather"]
+    # and without a group nothing distributed is touched at world 1
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.aggregate(0.5, 10.0, torch.device("cpu"), 1) == (0.5, 10.0)
+    assert bench.gather_per_rank([3.0], torch.device("cpu"), 1) == [[3.0]]
+    assert bench.pci_id_str(-1.0) is None and bench.pci_id_str(float((1 << 16) | (0x2f << 8) | 3)) == "0001:2f:03.0"
+
+
 def test_bench_gpus_2_launches_two_ranks_by_itself_dry_run():
     """`python bench.py --gpus 2` without a launcher starts its two ranks itself (frame i -> GPU i mod N,
     no data-path collective) and rank 0 reports the world it ran in.  --dry-run --backend gloo walks main() end to

@@ -207,3 +207,25 @@ def test_bench_line_verifies_its_own_timed_region():
     assert line["completion"]["p99_frame_completion_ms"] > 0 and line["completion"]["frames_in_flight"] > 0
     assert "release build" in line["config"]["env"]["library_build"], line["config"]["env"]
     assert len(line["per_rank"]) == 1 and line["per_rank"][0]["verified_mismatches"] == 0
+    # the N = 1 line has run the RCCL leg once (world 1, child process) and says which RCCL
+    assert "self-test ok" in line["config"]["distributed_backend"], line["config"]["distributed_backend"]
+    assert line["config"]["distributed_selftest"]["ok"] is True
+
+
+def test_rccl_world_1_selftest():
+    """the reporting collectives of the N > 1 line -- barrier, float64 MAX / SUM all-reduce, all-gather on
+    device tensors -- executed on RCCL (torch.distributed backend "nccl") in a world of one rank bound to cuda:0,
+    through the very functions the N > 1 line uses (bench.aggregate, bench.gather_per_rank)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dist-selftest"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["dist_selftest"]
+    assert rec["ok"] is True and rec["world"] == 1 and rec["backend"].startswith("nccl")
+    assert rec["rccl_version"].count(".") >= 1 and "self-test ok" in rec["summary"]
+    assert rec["gpu_pci"] is None or rec["gpu_pci"].count(":") == 2
