@@ -439,7 +439,10 @@ class Plan:
                 errors.append(e)
                 gate.abort()
 
-        th = [threading.Thread(target=loop, args=(i,)) for i in range(C)]
+        # daemon threads + abort in every way out: whatever raises in this thread between the gates (self.sync(), the
+        # barrier -- an RCCL error, a peer rank that died --, a KeyboardInterrupt) must not leave the enqueue threads
+        # parked at the gate for ever with the process holding its GPU while the other ranks hang in a collective
+        th = [threading.Thread(target=loop, args=(i,), daemon=True) for i in range(C)]
         for x in th:
             x.start()
         try:
@@ -459,6 +462,11 @@ class Plan:
             for x in th:
                 x.join()
             raise SystemExit(f"an enqueue thread failed: {errors[:1]}")
+        except BaseException as e:
+            gate.abort()  # releases every thread waiting at (or arriving at) the gate with BrokenBarrierError
+            for x in th:
+                x.join(30)
+            raise SystemExit(f"the timed region failed in the main thread: {e!r}") from e
         for x in th:
             x.join()
         counts = self.d_counts.cpu().numpy().view(np.uint32)

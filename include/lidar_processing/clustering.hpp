@@ -15,7 +15,10 @@
 
 #include <cmath>
 #include <cstdint>
+#include <iostream>
 #include <limits>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 namespace lidar_processing
@@ -59,15 +62,25 @@ class Clusterer final
         lpx_reserve(context_->get(), number_of_points, 0U);
     }
 
+    // Like the reference's, this call does not fail on a non-empty cloud (src/clustering.cpp:47-125: the only throw on
+    // its path, KDTree::rebuild's, is unreachable after the empty check at :51-54).  Should the device report an error
+    // (workspace, a transient HIP status), the call is repeated once on a re-reserved workspace; if that fails too the
+    // object degrades the way the reference's Segmenter does (src/segmentation.cpp:251-259): a line on std::cerr and a
+    // defined result -- every point INVALID, i.e. "no cluster", which the caller accepts (src/processor.cpp:180-200
+    // throws only on UNDEFINED) -- never an exception one layer above the C-ABI.
     template <typename PointT>
     void cluster(const pcl::PointCloud<PointT> &cloud_in, std::vector<ClusteringLabel> &labels)
     {
         labels.assign(cloud_in.size(), UNDEFINED);
+        last_size_ = 0U;
+        last_clusters_ = 0U;
+        last_epoch_ = 0U;
         if (cloud_in.empty())
         {
             return;
         }
         std::lock_guard<std::mutex> lock(context_->mutex());
+        context_->cluster_owner = nullptr;
 
         lpx_clu_cfg cfg{};
         cfg.distance_squared = configuration_.distance_squared;
@@ -75,25 +88,36 @@ class Clusterer final
         cfg.min_cluster_size = configuration_.min_cluster_size;
         cfg.max_cluster_size = configuration_.max_cluster_size;
 
+        const std::uint32_t number_of_points = static_cast<std::uint32_t>(cloud_in.size());
         std::uint32_t number_of_clusters = 0U;
-        const int rc = lpx_cluster(context_->get(), detail::points_base(cloud_in.points.data()), sizeof(PointT),
-                                   static_cast<std::uint32_t>(cloud_in.size()), &cfg, labels.data(),
-                                   &number_of_clusters);
+        int rc = lpx_cluster(context_->get(), detail::points_base(cloud_in.points.data()), sizeof(PointT),
+                             number_of_points, &cfg, labels.data(), &number_of_clusters);
+        if (rc != LPX_OK && rc != LPX_ERR_ARG && rc != LPX_ERR_RANGE)
+        {
+            std::cerr << "Clustering: " << lpx_last_error(context_->get()) << " -- retrying once" << std::endl;
+            lpx_reserve(context_->get(), number_of_points > 100'000U ? 2U * number_of_points : 200'000U, 0U);
+            labels.assign(cloud_in.size(), UNDEFINED);
+            rc = lpx_cluster(context_->get(), detail::points_base(cloud_in.points.data()), sizeof(PointT),
+                             number_of_points, &cfg, labels.data(), &number_of_clusters);
+        }
         if (rc != LPX_OK)
         {
-            // The reference's only failure is KDTree::rebuild throwing std::runtime_error
-            // (src/kdtree.hpp:221-224); labels stay UNDEFINED, which the caller treats as fatal
-            // (src/processor.cpp:186-189).
-            throw std::runtime_error(std::string("clustering failed: ") + lpx_last_error(context_->get()));
+            std::cerr << "Failed clustering: " << lpx_last_error(context_->get()) << std::endl;
+            labels.assign(cloud_in.size(), INVALID);
+            return;
         }
-        last_size_ = static_cast<std::uint32_t>(cloud_in.size());
+        last_size_ = number_of_points;
         last_clusters_ = number_of_clusters;
+        last_epoch_ = lpx_cluster_epoch(context_->get());
+        context_->cluster_owner = this;
     }
 
     // Optional fast path for the regrouping the reference's caller does right after cluster()
     // (src/processor.cpp:180-200): one cloud per valid cluster, clusters in label order, points in
     // index order, INVALID dropped.  The grouping is computed on the device from the labels of the last
-    // cluster() call; only the points are gathered here.  `cloud_in` must be the cloud just clustered.
+    // cluster() call; only the points are gathered here.  `cloud_in` must be the cloud just clustered, and nothing else
+    // may have used the (possibly shared) context since: call it right after cluster(), as processor.cpp does its own
+    // regrouping -- otherwise it throws (check_resident).
     template <typename PointT, typename PointOutT>
     void regroup(const pcl::PointCloud<PointT> &cloud_in, std::vector<pcl::PointCloud<PointOutT>> &clustered_cloud)
     {
@@ -106,6 +130,7 @@ class Clusterer final
         group_indices_.resize(last_size_);
         std::uint32_t number_of_valid = 0U;
         std::lock_guard<std::mutex> lock(context_->mutex());
+        check_resident("cluster regrouping");
         const int rc = lpx_cluster_groups(context_->get(), last_size_, last_clusters_, group_offsets_.data(),
                                           group_indices_.data(), &number_of_valid);
         if (rc != LPX_OK)
@@ -143,6 +168,7 @@ class Clusterer final
         hull_xy_.resize(2U * static_cast<std::size_t>(last_size_));
         std::uint32_t number_of_hull_points = 0U;
         std::lock_guard<std::mutex> lock(context_->mutex());
+        check_resident("convex outlines");
         const int rc = lpx_cluster_hulls(context_->get(), last_size_, last_clusters_, max_points, hull_offsets_.data(),
                                          hull_indices_.data(), hull_xy_.data(), &number_of_hull_points);
         if (rc != LPX_OK)
@@ -166,8 +192,22 @@ class Clusterer final
     }
 
   private:
+    // regroup() / convex_outlines() read the labels cluster() left on the device.  On a shared context (the default) any
+    // call of another object in between -- a Segmenter::segment, whose look-ahead clusters the NEXT cloud, or another
+    // Clusterer -- replaces them: the context's owner mark and the library's clustering epoch (0 once anything else has
+    // run) must still be this object's, or the caller would silently get groups of a different cloud.
+    void check_resident(const char *what) const
+    {
+        if (context_->cluster_owner != this || lpx_cluster_epoch(context_->get()) != last_epoch_)
+        {
+            throw std::runtime_error(std::string(what) +
+                                     " failed: the shared context has been used since this object's cluster() call");
+        }
+    }
+
     std::shared_ptr<detail::LpxContext> context_;
     ClusteringConfiguration configuration_;
+    std::uint64_t last_epoch_{0U};
     std::vector<std::uint32_t> hull_offsets_;
     std::vector<std::uint32_t> hull_indices_;
     std::vector<float> hull_xy_;

@@ -48,6 +48,9 @@ class LpxContext final
 
     // which object's segmentation the resident clouds belong to (Segmenter::coloured_clouds checks it)
     const void *segment_owner{nullptr};
+    // which Clusterer's labels are resident (Clusterer::regroup / convex_outlines check it; Segmenter::segment and every
+    // Clusterer::cluster reset it)
+    const void *cluster_owner{nullptr};
 
   private:
     lpx_ctx *ctx_{nullptr};

@@ -83,6 +83,7 @@ class Segmenter final
         static_assert(sizeof(SegmentationLabel) == sizeof(std::uint32_t), "label layout");
         std::lock_guard<std::mutex> lock(context_->mutex());
         context_->segment_owner = this;
+        context_->cluster_owner = nullptr;  // the look-ahead may cluster THIS cloud into the label buffer
         labels.resize(cloud_in.size(), SegmentationLabel::UNKNOWN);
         ground_cloud.clear();
         obstacle_cloud.clear();

@@ -168,9 +168,20 @@ int lpx_segment(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint32_t n, 
  * src/processor.cpp:150-178), a cloud of exactly that call's obstacle count whose position-bound checksum over all m
  * points (x, y, z words, computed here on the host) equals the one the device kept is clustered where it lies: no
  * upload.  Every other cloud -- another size, one changed coordinate, two swapped points, a second clustering of the
- * same cloud -- is uploaded.  The result never depends on which way a call went. */
+ * same cloud -- is uploaded.  "Equals" means: the size and TWO independent 64-bit position-bound wrapping sums over
+ * every point's x, y, z words (lpx_internal.h: lpx_obstacle_mix, lpx_obstacle_mix2) agree -- a probabilistic witness
+ * (two unrelated non-cryptographic mixes; ~2^-128 for clouds that are not built to collide), not a byte comparison:
+ * a caller that must rule out even that gives its Clusterer a context of its own (the explicit constructor of
+ * lidar_processing::Clusterer, or a second lpx_create), on which every cloud is uploaded.  Apart from that residual
+ * the result never depends on which way a call went. */
 int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride_bytes, uint32_t m, const lpx_clu_cfg *cfg,
                 int32_t *labels, uint32_t *n_clusters);
+
+/* Counts the HOST clusterings (lpx_cluster, lpx_segment_cluster*) this context has completed; 0 while the labels of the
+ * last one are NOT resident any more (any other call in between, a look-ahead clustering enqueued by lpx_segment
+ * included).  lpx_cluster_groups / lpx_cluster_hulls serve exactly the clustering this number names and return
+ * LPX_ERR_ARG when the labels are gone or m / n_clusters are not that call's. */
+uint64_t lpx_cluster_epoch(const lpx_ctx *ctx);
 
 /* Both calls back to back with the obstacle cloud kept on the device between them (what
  * Processor::process does at :150-178).  cluster_labels[i] belongs to obstacle_idx[i]. */
@@ -210,7 +221,9 @@ int lpx_coloured_clouds(lpx_ctx *ctx, void *ground_records, void *obstacle_recor
  * the points of every valid cluster, clusters in label order, points in ascending index order,
  * INVALID dropped.  Works on the labels of the LAST lpx_cluster / lpx_segment_cluster call of this
  * context (still resident on the device): offsets[n_clusters + 1], indices[n_valid] (indices into the
- * clustered cloud), *n_valid = offsets[n_clusters]. */
+ * clustered cloud), *n_valid = offsets[n_clusters].  m and n_clusters must be that call's, and no other call but
+ * lpx_cluster_groups / lpx_cluster_hulls / lpx_coloured_clouds may have run on the context since (a look-ahead
+ * lpx_segment overwrites the labels): otherwise LPX_ERR_ARG, never the groups of another cloud (lpx_cluster_epoch). */
 int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, uint32_t *offsets, uint32_t *indices,
                        uint32_t *n_valid);
 

@@ -155,6 +155,7 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
         // whatever an earlier call left in the slots is gone with the old arena: every caller that grows the workspace
         // (begin_call paths, lpx_reserve, lpx_reserve_single_pass, the switch to the search tables) passes through here
         ctx->seg_valid = false;
+        ctx->clu_valid = false;
         ctx->last_n = 0;
         LPX_HIP(ctx, hipMalloc(&ctx->arena, total * ctx->batch));
         // zero once: frame states and scratch heads
@@ -219,6 +220,7 @@ static int begin_call(lpx_ctx *ctx, uint32_t frames, uint32_t upitch)
     ctx->upitch = upitch;
     ctx->seg_valid = false;  // set again at the end of a host segmentation call (what lpx_coloured_clouds serves)
     ctx->seg_fresh = false;
+    ctx->clu_valid = false;  // set again at the end of a host clustering (what lpx_cluster_groups / _hulls serve)
     if (ctx->la_pending)
     {
         // a look-ahead clustering nobody asked for (lpx_cluster takes its flag down before it gets here): stop guessing
@@ -1142,6 +1144,7 @@ static int segment_impl(lpx_ctx *ctx, const void *pts, size_t stride, const uint
     if (ahead && ctx->la_failed)
         ctx->la_armed = false;
     ctx->seg_hash = fs.obs_hash;
+    ctx->seg_hash2 = fs.obs_hash2;
     return LPX_OK;
 }
 
@@ -1209,6 +1212,33 @@ static int download_clusters(lpx_ctx *ctx, const FrameState &fs, int32_t *labels
     return LPX_OK;
 }
 
+// a host clustering is complete: d_clabels holds the labels of m points in n_clusters clusters
+static void clustering_done(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters)
+{
+    ctx->clu_valid = true;
+    ctx->clu_m = m;
+    ctx->clu_clusters = n_clusters;
+    ++ctx->clu_epoch;
+}
+
+extern "C" uint64_t lpx_cluster_epoch(const lpx_ctx *ctx)
+{
+    return ctx && ctx->clu_valid ? ctx->clu_epoch : 0;
+}
+
+// lpx_cluster_groups / lpx_cluster_hulls: the caller's m / n_clusters must be those of the clustering whose labels are
+// resident (0 = fine)
+static int check_resident_labels(lpx_ctx *ctx, const char *who, uint32_t m, uint32_t n_clusters)
+{
+    if (!ctx->clu_valid)
+        return lpx_fail(ctx, LPX_ERR_ARG, "%s: the last call on this context was not a host clustering (lpx_cluster / "
+                                          "lpx_segment_cluster*); its labels are gone", who);
+    if (m != ctx->clu_m || n_clusters != ctx->clu_clusters)
+        return lpx_fail(ctx, LPX_ERR_ARG, "%s: %u points / %u clusters, but the resident labels are those of %u points / "
+                                          "%u clusters", who, m, n_clusters, ctx->clu_m, ctx->clu_clusters);
+    return LPX_OK;
+}
+
 extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_t m, const lpx_clu_cfg *cfg,
                            int32_t *labels, uint32_t *n_clusters)
 {
@@ -1220,9 +1250,22 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
     if (rc)
         return rc;
     if (m == 0)  // src/clustering.cpp:51-54
+    {
+        ctx->clu_valid = false;
         return LPX_OK;
+    }
     if (!pts)
         return lpx_fail(ctx, LPX_ERR_ARG, "null points");
+    if (const char *e = LPX_KNOB("LPX_FAIL_CLUSTER"))  // development build: the first k calls of the process fail
+    {                                                   // (what the degrade path of Clusterer::cluster is tested with)
+        static int failed = 0;
+        if (failed < atoi(e))
+        {
+            ++failed;
+            ctx->clu_valid = false;
+            return lpx_fail(ctx, LPX_ERR_CAPACITY, "forced failure %d of lpx_cluster (LPX_FAIL_CLUSTER)", failed);
+        }
+    }
     LPX_HIP(ctx, hipSetDevice(ctx->device));
     // The unchanged node hands Clusterer::cluster the obstacle cloud Segmenter::segment has just built from this very
     // context's index list (src/processor.cpp:150-178).  That cloud is still resident -- obstacle SoA, kd input, frame
@@ -1236,15 +1279,17 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
     const bool ahead = ctx->la_pending && memcmp(cfg, &ctx->la_cfg, sizeof(*cfg)) == 0;
     if (ctx->seg_valid && (ctx->seg_fresh || ahead) && m == ctx->seg_obstacle && m <= ctx->cap_n)
     {
-        uint64_t h = 0;
+        // two independent position-bound sums over ALL m points (lpx_obstacle_mix, lpx_obstacle_mix2): both must agree
+        uint64_t h = 0, h2 = 0;
         const char *p = (const char *)pts;
         for (uint32_t i = 0; i < m; ++i, p += stride)
         {
             uint32_t w[3];
-            memcpy(w, p, 12);
+            memcpy(w, p, 12);  // x, y, z are the first three floats of a record (lpx.h: lpx_cluster)
             h += lpx_obstacle_mix(i, w[0], w[1], w[2]);
+            h2 += lpx_obstacle_mix2(i, w[0], w[1], w[2]);
         }
-        if (h == ctx->seg_hash)
+        if (h == ctx->seg_hash && h2 == ctx->seg_hash2)
         {
             const uint32_t ng = ctx->seg_ground, last_n = ctx->last_n;
             ctx->la_pending = false;  // (used, not mispredicted: begin_call must not take the guess down)
@@ -1263,6 +1308,7 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
             ctx->la_cfg = *cfg;  // the caller runs segment() then cluster() on one context: look ahead next time
             ctx->la_armed = true;
             ctx->la_hits += ahead ? 1u : 0u;
+            clustering_done(ctx, m, fs.n_clusters);
             return LPX_OK;
         }
     }
@@ -1271,9 +1317,10 @@ extern "C" int lpx_cluster(lpx_ctx *ctx, const void *pts, size_t stride, uint32_
     if ((rc = lpx_ingest_obstacles(ctx, ctx->in_aos.p, stride, m)))
         return rc;
     FrameState fs;
-    if ((rc = cluster_resident(ctx, m, cfg, &fs)))
+    if ((rc = cluster_resident(ctx, m, cfg, &fs)) || (rc = download_clusters(ctx, fs, labels, n_clusters)))
         return rc;
-    return download_clusters(ctx, fs, labels, n_clusters);
+    clustering_done(ctx, m, fs.n_clusters);
+    return LPX_OK;
 }
 
 static int segment_cluster_impl(lpx_ctx *ctx, const void *pts, size_t stride, const uint32_t *offs, uint32_t n,
@@ -1329,6 +1376,7 @@ static int segment_cluster_impl(lpx_ctx *ctx, const void *pts, size_t stride, co
     ctx->seg_valid = true;
     ctx->seg_ground = fs.n_ground;
     ctx->seg_obstacle = fs.n_obstacle;
+    clustering_done(ctx, fs.n_obstacle, fs.n_clusters);
     return LPX_OK;
 }
 
@@ -1445,19 +1493,25 @@ extern "C" int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters,
     if (n_valid)
         *n_valid = 0;
     offsets[0] = 0;
-    if (m == 0 || n_clusters == 0)
+    if (m == 0)
     {
         for (uint32_t c = 0; c <= n_clusters; ++c)
             offsets[c] = 0;
         return LPX_OK;
     }
+    int rc = check_resident_labels(ctx, "lpx_cluster_groups", m, n_clusters);
+    if (rc)
+        return rc;
+    if (n_clusters == 0)
+        return LPX_OK;
     LPX_HIP(ctx, hipSetDevice(ctx->device));
     // offsets / indices go to kd-build scratch (free once the clustering is done): the index lists of the
     // segmentation stay resident for lpx_coloured_clouds
     uint32_t *d_off = (uint32_t *)ctx->lpos.p, *d_ind = (uint32_t *)ctx->rpos.p;
     const bool seg_valid = ctx->seg_valid;  // regrouping touches neither the frame state nor the segmentation's buffers
-    int rc = begin_call(ctx, 1, 0);
+    rc = begin_call(ctx, 1, 0);
     ctx->seg_valid = seg_valid;
+    ctx->clu_valid = true;                  // ... nor the labels
     if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)))
         return rc;
     LPX_HIP(ctx, hipMemcpyAsync(offsets, d_off, sizeof(uint32_t) * ((size_t)n_clusters + 1),
@@ -1484,9 +1538,19 @@ extern "C" int lpx_cluster_hulls(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, 
         return LPX_ERR_ARG;
     if (n_hull_points)
         *n_hull_points = 0;
+    hull_offsets[0] = 0;
+    if (m == 0)
+    {
+        for (uint32_t c = 0; c <= n_clusters; ++c)
+            hull_offsets[c] = 0;
+        return LPX_OK;
+    }
+    int rc = check_resident_labels(ctx, "lpx_cluster_hulls", m, n_clusters);  // (before n_clusters sizes a write)
+    if (rc)
+        return rc;
     for (uint32_t c = 0; c <= n_clusters; ++c)
         hull_offsets[c] = 0;
-    if (m == 0 || n_clusters == 0)
+    if (n_clusters == 0)
         return LPX_OK;
     if (m > ctx->cap_n || n_clusters > m)
         return lpx_fail(ctx, LPX_ERR_ARG, "%u points / %u clusters do not match the last clustering call", m, n_clusters);
@@ -1495,8 +1559,9 @@ extern "C" int lpx_cluster_hulls(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, 
     uint32_t *d_hoff = (uint32_t *)ctx->nb_off.p, *d_hidx = (uint32_t *)ctx->nb_len.p;
     float *d_hxy = (float *)ctx->key64_a.p;
     const bool seg_valid = ctx->seg_valid;  // (as lpx_cluster_groups)
-    int rc = begin_call(ctx, 1, 0);
+    rc = begin_call(ctx, 1, 0);
     ctx->seg_valid = seg_valid;
+    ctx->clu_valid = true;
     if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)) ||
         (rc = lpx_run_hulls(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind, max_points, d_hoff, d_hidx, d_hxy)))
         return rc;

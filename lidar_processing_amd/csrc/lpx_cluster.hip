@@ -1271,16 +1271,39 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
 #ifdef LPX_DEV_KNOBS
     burn_resources(ctx);
 #endif
+    // While the fork is open the side stream may hold grid kernels of this call: EVERY way out of this function -- an
+    // error of the grid itself, of the kd build or of the chunk tables included -- joins it to the context's stream first,
+    // so that the next call on the slot set cannot overtake leftover grid kernels.
+    struct ForkJoin
+    {
+        lpx_ctx *ctx;
+        hipStream_t st;
+        bool open = false;
+        int join()
+        {
+            if (!open)
+                return LPX_OK;
+            open = false;
+            if (hipEventRecord(ctx->ev_join, ctx->fork_stream) != hipSuccess ||
+                hipStreamWaitEvent(st, ctx->ev_join, 0) != hipSuccess)
+            {
+                (void)hipStreamSynchronize(ctx->fork_stream);  // last resort: the host waits
+                return lpx_fail(ctx, LPX_ERR_HIP, "joining the forked component grid failed");
+            }
+            return LPX_OK;
+        }
+        ~ForkJoin() { (void)join(); }
+    } fork_join{ctx, st};
     if (forked)
     {
         LPX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
         LPX_HIP(ctx, hipStreamWaitEvent(ctx->fork_stream, ctx->ev_fork, 0));
+        fork_join.open = true;
         ctx->stream = ctx->fork_stream;
         rc = lpx_grid_components(ctx, m_max, cfg->distance_squared, root, iota, false);
         ctx->stream = st;
         if (rc)
-            return rc;
-        LPX_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->fork_stream));
+            return rc;  // (fork_join joins)
     }
     rc = (kd_ready || skip_kd) ? LPX_OK : lpx_kd_build(ctx, m_max);
     if (rc)
@@ -1317,8 +1340,8 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         if (sweep_cc && (rc = lpx_sweep_components(ctx, m_max, cfg->distance_squared)))
             return rc;
 #endif
-        if (forked)
-            LPX_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+        if ((rc = fork_join.join()))
+            return rc;
     }
     {
         StageTimer tm(ctx, ST_CC);

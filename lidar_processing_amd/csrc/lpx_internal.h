@@ -67,6 +67,7 @@ struct alignas(128) FrameState
     // position-bound checksum of the obstacle cloud the compaction wrote (single-frame calls): what lets lpx_cluster
     // recognise the cloud lpx_segment left on the device and skip the upload (lpx_obstacle_mix)
     alignas(128) uint64_t obs_hash;
+    uint64_t obs_hash2;       // second, independent witness (lpx_obstacle_mix2): same line, same atomics
     // The single-pass region of the list workspace is handed out from LPX_RS_STRIPES sub-regions with a cursor each
     // (group g bumps cursor g % LPX_RS_STRIPES): thousands of bumps of ONE word per frame serialise at L2.
     FrameStripe rs_stripe[LPX_RS_STRIPES];
@@ -82,6 +83,21 @@ __host__ __device__ static inline uint64_t lpx_obstacle_mix(uint32_t i, uint32_t
     h += ((uint64_t)zb << 32) | i;
     h *= 0xBF58476D1CE4E5B9ull;
     h ^= h >> 32;
+    return h;
+}
+
+// The second witness of the same cloud: other constants, another structure (the position is bound by a multiplication
+// of its own, z enters first, x and y are rotated apart), so that a crafted or accidental collision has to hit two
+// unrelated 64-bit wrapping sums at once.  lpx_cluster takes the resident path only when BOTH sums (and the size) agree.
+__host__ __device__ static inline uint64_t lpx_obstacle_mix2(uint32_t i, uint32_t xb, uint32_t yb, uint32_t zb)
+{
+    uint64_t h = ((uint64_t)(i + 1u) * 0xD6E8FEB86659FD93ull) ^ (((uint64_t)zb << 32) | xb);
+    h *= 0xFF51AFD7ED558CCDull;
+    h ^= h >> 33;
+    h += ((uint64_t)yb << 17) | ((uint64_t)yb >> 15);
+    h ^= (uint64_t)xb << 41;
+    h *= 0xC4CEB9FE1A85EC53ull;
+    h ^= h >> 31;
     return h;
 }
 
@@ -197,7 +213,14 @@ struct lpx_ctx
     // the obstacle cloud of that call is still resident exactly as the compaction left it (SoA + kd input): lpx_cluster
     // of a cloud with this count and checksum runs on it without an upload; cleared once a clustering has consumed it
     bool seg_fresh = false;
-    uint64_t seg_hash = 0;
+    uint64_t seg_hash = 0, seg_hash2 = 0;
+    // host-side memory of the last HOST clustering (lpx_cluster, lpx_segment_cluster*): what d_clabels holds, i.e. what
+    // lpx_cluster_groups / lpx_cluster_hulls may regroup.  Cleared by begin_call -- every other call, a look-ahead
+    // clustering enqueued by lpx_segment included, may overwrite the labels -- and checked against the caller's m /
+    // n_clusters, so that groups or hulls of ANOTHER cloud are an LPX_ERR_ARG, never a silent answer.
+    bool clu_valid = false;
+    uint32_t clu_m = 0, clu_clusters = 0;
+    uint64_t clu_epoch = 0;        // counts the host clusterings of this context (lpx_cluster_epoch)
     // Look-ahead of the two-call form (lpx_set_lookahead): once an lpx_cluster call has found the obstacle cloud of the
     // lpx_segment call before it resident, the next lpx_segment enqueues the clustering with that call's configuration
     // right behind its own kernels and returns as soon as ITS results are down; a matching lpx_cluster then only waits

@@ -2218,14 +2218,16 @@ constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B +
 #define LPX_IX_BOX_UNROLL 4
 #endif
 
+// (frame and wframe name the SAME record -- read-only view and the two words the table clear resets -- so neither is
+// __restrict__: aliased restrict pointers with a write through one of them would be undefined behaviour)
 __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__restrict__ PR,
-                                                               const FrameState *__restrict__ frame, float rr,
+                                                               const FrameState *frame, float rr,
                                                                ChunkRec *__restrict__ chunks,
                                                                float4 *__restrict__ grp_of, uint32_t spine_max,
                                                                uint32_t bucket, uint32_t *parent, float r2,
                                                                unsigned long long *__restrict__ tkey,
                                                                uint32_t *__restrict__ tparent, uint32_t *__restrict__ thead,
-                                                               uint32_t cap_max, FrameState *__restrict__ wframe, FV fv)
+                                                               uint32_t cap_max, FrameState *wframe, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
     parent = lpx_slot(parent, fv.fs);

@@ -1627,7 +1627,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
         opos += wo[i];
     }
     const bool want_hash = gridDim.z == 1;  // single-frame calls: the host may be handed this cloud back (lpx_cluster)
-    uint64_t hsum = 0;
+    uint64_t hsum = 0, hsum2 = 0;
     for (uint32_t p0 = wlo; p0 < whi; p0 += WAVE * CR)
     {
         uint32_t f[CR], si[CR];
@@ -1664,7 +1664,10 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
                     OZ[d] = oz[r];
                     nodes[d] = make_float4(ox[r], oy[r], oz[r], __uint_as_float(d));  // kd-tree input, KDTree::rebuild :185-189
                     if (want_hash)
+                    {
                         hsum += lpx_obstacle_mix(d, __float_as_uint(ox[r]), __float_as_uint(oy[r]), __float_as_uint(oz[r]));
+                        hsum2 += lpx_obstacle_mix2(d, __float_as_uint(ox[r]), __float_as_uint(oy[r]), __float_as_uint(oz[r]));
+                    }
                 }
             }
             gpos += __popcll(mg);
@@ -1676,6 +1679,9 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
         hsum = (uint64_t)lpx_wave_sum_i64((long long)hsum);  // wrapping sum, valid in lane 0
         if (lane == 0 && hsum)
             atomicAdd((unsigned long long *)&frame->obs_hash, (unsigned long long)hsum);
+        hsum2 = (uint64_t)lpx_wave_sum_i64((long long)hsum2);
+        if (lane == 0 && hsum2)
+            atomicAdd((unsigned long long *)&frame->obs_hash2, (unsigned long long)hsum2);
     }
     if (s == 0 && b == 0)
     {

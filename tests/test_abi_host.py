@@ -137,6 +137,20 @@ def test_latency_harness_compiles_against_the_headers(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_degrade_harness_compiles_against_the_headers(tmp_path):
+    """tests/cxx/dropin_degrade.cpp (Clusterer::cluster's no-throw degrade path and the ownership guard of regroup /
+    convex_outlines, run on the GPU by tests/test_gpu_pipeline.py) compiles and links here"""
+    from lidar_processing_amd import _lib
+    _lib.build()
+    exe = tmp_path / "dropin_degrade"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{ROOT}/include", f"-I{ROOT}/include/lidar_processing",
+           f"-I{ROOT}/tests/cxx", f"{ROOT}/tests/cxx/dropin_degrade.cpp", "-o", str(exe),
+           f"{ROOT}/lidar_processing_amd/liblpx_dev.so", f"-Wl,-rpath,{ROOT}/lidar_processing_amd",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_binding_recipe_survives_quoted_include_resolution(tmp_path):
     """src/processor.cpp includes "segmentation.hpp" / "clustering.hpp" with quotes, and a quoted include searches
     the including file's own directory before any -I path.  A caller that sits NEXT TO same-named CPU headers (as

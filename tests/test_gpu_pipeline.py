@@ -601,10 +601,27 @@ def test_segment_looks_ahead_to_the_clustering_the_node_asks_for_next():
             got, nc = c.cluster(other, ClusteringConfiguration(0.18, 0.5))  # guessed for a cloud that is not the one passed
             w2, n2 = oracle.cluster(other, ocfg2)
             assert nc == n2 and np.array_equal(got, w2) and c.lookahead_hits() == 7
+            # ... and for SAME-SIZE clouds that differ in one coordinate / in the order of two points while the guessed
+            # clustering is pending: both witnesses of the resident cloud must agree, so these are uploaded
+            pair(c, 2, ClusteringConfiguration(0.18, 0.5), which=2)     # (re-arms the look-ahead)
+            for variant in ("coordinate", "swap"):
+                c.segment(frames[0], scfg)
+                other = np.ascontiguousarray(frames[0][wants[0][0]["obstacle_idx"]])
+                if variant == "coordinate":
+                    other[len(other) // 3, 2] += 0.001
+                else:
+                    other[[7, 30000]] = other[[30000, 7]]
+                hits = c.lookahead_hits()
+                got, nc = c.cluster(other, ClusteringConfiguration(0.18, 0.5))
+                w2, n2 = oracle.cluster(other, ocfg2)
+                assert nc == n2 and np.array_equal(got, w2) and c.lookahead_hits() == hits, (mode, variant)
+                pair(c, 1, ClusteringConfiguration(0.18, 0.5), which=2)
+                pair(c, 2, ClusteringConfiguration(0.18, 0.5), which=2)
+            hits7 = c.lookahead_hits()
             c.set_lookahead(False)
             for k in range(3):
                 pair(c, k % len(frames), ClusteringConfiguration(0.18, 0.5), which=2)
-            assert c.lookahead_hits() == 7
+            assert c.lookahead_hits() == hits7
         finally:
             c.close()
 
@@ -633,6 +650,50 @@ def test_cxx_dropin_latency_harness_shares_one_context(tmp_path):
     wl, wn = oracle.cluster(pts[want["obstacle_idx"]], oracle.CluCfg(0.25, 0.5))
     assert d["obstacle_points"] == len(want["obstacle_idx"]) and d["clusters"] == wn
     assert 0 < d["segment_plus_cluster_ms"] < 100
+
+
+def test_cxx_clusterer_degrades_without_throwing_and_guards_its_resident_labels(tmp_path):
+    """tests/cxx/dropin_degrade.cpp through include/lidar_processing/*.hpp: (1) Clusterer::cluster never throws on a
+    device error -- the reference's cannot fail on a non-empty cloud (src/clustering.cpp:47-125) -- it retries once
+    (forced failure 1 of 1: the reference's labels) and else degrades to every point INVALID with a line on stderr
+    (forced failures 2 of 2), liblpx_dev.so's LPX_FAIL_CLUSTER; (2) regroup() / convex_outlines() throw instead of
+    serving another cloud's labels after a Segmenter::segment (look-ahead) or another Clusterer used the shared
+    context, and work frame after frame in the node's own order."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "dropin_degrade"
+    cmd = ["g++", "-std=c++17", "-O1", f"-I{root}/include", f"-I{root}/include/lidar_processing",
+           f"-I{root}/tests/cxx", f"{root}/tests/cxx/dropin_degrade.cpp", "-o", str(exe),
+           f"{root}/lidar_processing_amd/liblpx_dev.so", f"-Wl,-rpath,{root}/lidar_processing_amd",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    pts = load_frame("0000000077")
+    fin = tmp_path / "in.f32"
+    pts.tofile(fin)
+    want = oracle.segment(pts)
+    wl, wn = oracle.cluster(pts[want["obstacle_idx"]])
+    no = len(want["obstacle_idx"])
+
+    def run(fail):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("LPX_")}
+        if fail:
+            env["LPX_FAIL_CLUSTER"] = str(fail)
+        r = subprocess.run([str(exe), str(fin)], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return {k: int(v) for k, v in (kv.split("=") for kv in r.stdout.split())}, r.stderr
+
+    for fail in (0, 1):  # no failure / one forced failure, repeated successfully
+        d, err = run(fail)
+        assert d["threw"] == 0 and d["obstacle"] == d["labels"] == no and d["undefined"] == 0, d
+        assert d["clusters"] == wn and d["invalid"] == int((wl == -1).sum()) and d["groups"] == wn, (fail, d)
+        assert ("retrying once" in err) == bool(fail) and "Failed clustering" not in err
+        assert d["ok_pairs"] == 3 and d["after_segment"] == 2 and d["after_other"] == 2 and d["other_ok"] == 1, d
+    d, err = run(2)  # both attempts fail: every point INVALID, reported on stderr, nothing thrown, no groups
+    assert d["threw"] == 0 and d["labels"] == no and d["invalid"] == no and d["undefined"] == 0 and d["clusters"] == 0, d
+    assert d["groups"] == 0 and "Failed clustering: forced failure 2" in err
+    assert d["ok_pairs"] == 3 and d["after_segment"] == 2 and d["after_other"] == 2  # the object works again afterwards
 
 
 def test_full_size_5m_label_for_label(ctx):
