@@ -50,7 +50,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md:36; a float4 copy measures 6.29 TB/s there)
 FRAME_BUDGET_MS = 100.0  # the reference's frame budget (10 Hz sensor, reference README.md:4): p99 completion must stay below
-PROFILE_ROUND = "r04"  # committed rocprofv3 summaries this line points at: profiles/<round>_<workload>_*
+PROFILE_ROUND = "r05"  # committed rocprofv3 summaries this line points at: profiles/<round>_<workload>_*
 
 WORKLOADS = {
     "kitti": dict(config="configs[1]: 120k-pt KITTI frames (three frames cycled), 6 segments, 5 iters, FEC d=0.5 m q=0.5",
@@ -132,6 +132,74 @@ def pmc_traffic(stage, workload, kernel=None):
                    for name, v in d.items() if name.startswith((kernel or STAGE_KERNEL[stage])[:40]))
     except Exception:
         return None
+
+
+def library_source_hash(lpx=None):
+    """the hash of the sources the loaded library was built from (lpx_build_info: `src <hash>`), or None"""
+    try:
+        from lidar_processing_amd import _lib
+        info = _lib.lib().lpx_build_info().decode()
+        return info.rsplit("src ", 1)[1].strip() if "src " in info else None
+    except Exception:
+        return None
+
+
+def profile_source_hash():
+    """the hash tools/refresh_profiles.sh stamped on the committed profiles of PROFILE_ROUND, or None"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_source_hash.json")))["library_source_hash"]
+    except Exception:
+        return None
+
+
+SIMDS, SIMD_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs (guides/MI355X_MICROARCH.md)
+
+
+def binding_resources(workload, chain_ms, frames_per_chain, frames_per_s):
+    """What the loaded device runs out of on this path is memory REQUESTS and dependent round trips, not bytes
+    (DESIGN.md 5): so next to the HBM fraction the line carries the committed request counters of one launch chain
+    (profiles/<round>_<workload>_requests.json: TCC_EA0_RDREQ + WRREQ, the L2 <-> fabric requests of every own kernel,
+    tools/probe.sh requests), the rate they amount to at THIS run's throughput against the rate the burner kernel reached
+    with nothing but scattered 64-byte line requests (profiles/r04_stream_burners.json), and the share of the vector
+    ALUs' cycles the chain's instructions occupy (SQ_ACTIVE_INST_VALU of every own kernel, quad-cycles).  None of it is
+    measured in this run; `traffic_stale` says whether the profiles were made by the library that is loaded."""
+    out = {"what": "committed PMC summaries of ONE launch chain alone on the device, priced at this run's rate"}
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_requests.json")))
+        per_chain = float(r["fabric_requests_per_chain"])
+        burn = json.load(open(os.path.join(ROOT, "profiles", "r04_stream_burners.json")))
+        lines = 1024 * 256 * 96  # LPX_BURN_MEM=96: loads of one launch, each its own 64-byte line
+        ceiling = lines / (burn["burners_alone_ms_per_launch"]["mem96"] * 1e-3)
+        per_frame = per_chain / frames_per_chain
+        out["requests"] = {"fabric_per_chain": int(per_chain), "fabric_per_frame": int(per_frame),
+                           "atomics_per_chain": int(r["per_chain_total"]["fabric_atomic"]),
+                           "l2_per_chain": int(r["per_chain_total"]["l2_req"]),
+                           "per_s_at_this_rate": round(per_frame * frames_per_s),
+                           "ceiling_per_s": round(ceiling), "frac": round(per_frame * frames_per_s / ceiling, 4),
+                           "ceiling_what": "scattered 64-byte line requests per second of burn_mem_kernel alone on the "
+                                           "device (profiles/r04_stream_burners.json)",
+                           "source": f"profiles/{PROFILE_ROUND}_{workload}_requests.json"}
+    except Exception as e:
+        out["requests"] = {"error": repr(e)[:160]}
+    try:
+        path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_pmc_active.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r04_stream_pmc_active1.json")
+        d = json.load(open(path))
+        d = d.get("kernels", d)
+        own = {k: v for k, v in d.items() if not k.startswith(("__amd", "at::", "copy_kernel", "burn_"))}
+        chains = [v for k, v in own.items() if k.startswith("frame_init_kernel")][0]["SQ_ACTIVE_INST_VALU"]["launches"]
+        quad = sum(v["SQ_ACTIVE_INST_VALU"]["avg"] * v["SQ_ACTIVE_INST_VALU"]["launches"] for v in own.values()
+                   if "SQ_ACTIVE_INST_VALU" in v) / chains
+        out["valu_busy"] = {"frac": round(4.0 * quad / (SIMDS * SIMD_CLOCK_HZ * chain_ms * 1e-3), 4),
+                            "valu_cycles_per_chain": int(4.0 * quad),
+                            "simd_cycles_the_chain_gets": int(SIMDS * SIMD_CLOCK_HZ * chain_ms * 1e-3),
+                            "source": os.path.relpath(path, ROOT)}
+    except Exception as e:
+        out["valu_busy"] = {"error": repr(e)[:160]}
+    lh, ph = library_source_hash(), profile_source_hash()
+    out.update(library_source_hash=lh, profile_source_hash=ph, traffic_stale=not (lh and ph and lh == ph))
+    return out
 
 
 PMC_FRAMES_PER_LAUNCH = {"stream": 64, "kitti": 64, "synth1m": 8, "synth5m": 1}  # launch shape of the committed --pmc runs
@@ -742,6 +810,11 @@ def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_lau
             "streaming_kernels": {s: stage_row(s) for s in STREAMING if per_launch.get(s, 0) > 0},
             "plane_passes": stage_row("plane_passes") if per_launch.get("plane_passes", 0) > 0 else None,
             "hbm_copy_kernel_gbs": round(copy_gbs, 1),
+            # the resources that DO bind (requests against the burner's ceiling, vector-ALU busy) and whether the
+            # committed profiles `traffic` and these come from were made by the loaded library
+            "binding": binding_resources(plan.name, step_ms / max(1.0, F * world / max(1, frames_per_launch)), frames_per_launch,
+                                         F * world / (step_ms * 1e-3)),
+            "traffic_stale": not (library_source_hash() and library_source_hash() == profile_source_hash()),
             "stage_ms_per_launch_alone": {k: round(v, 5) for k, v in per_launch.items()}}
 
 

@@ -477,9 +477,18 @@ static int create_common(int device, hipStream_t stream, bool own, uint32_t batc
 // and 10.7 k with 32 queues).  That variable belongs to the PROCESS (HIP reads it once, on its first call): the host
 // program's launcher sets it (bench.py, tests/conftest.py and the tools do; INTEGRATION.md for a ROS 2 launch file).
 // The library never touches the environment; lpx_build_info() reports what it found.
+// The hash of the library's sources (csrc/*.hip, lpx_internal.h, include/*.h), made by the Makefile: what ties a
+// committed profile (profiles/*: `library_source_hash`) to the library that produced it -- bench.py marks
+// `roofline.traffic` stale when the two differ.
+#if __has_include("lpx_source_hash.h")
+#include "lpx_source_hash.h"
+#endif
+#ifndef LPX_SOURCE_HASH
+#define LPX_SOURCE_HASH "unknown"
+#endif
 extern "C" const char *lpx_build_info(void)
 {
-    static char info[192];
+    static char info[224];
     static std::once_flag once;
     std::call_once(once, [] {
         const char *q = getenv("GPU_MAX_HW_QUEUES");
@@ -488,7 +497,8 @@ extern "C" const char *lpx_build_info(void)
 #else
         const char *flavour = "release build: no LPX_* environment knobs";
 #endif
-        snprintf(info, sizeof info, "liblpx gfx950, %s; GPU_MAX_HW_QUEUES=%s", flavour, q ? q : "unset (HIP default 4)");
+        snprintf(info, sizeof info, "liblpx gfx950, %s; GPU_MAX_HW_QUEUES=%s; src %s", flavour,
+                 q ? q : "unset (HIP default 4)", LPX_SOURCE_HASH);
     });
     return info;
 }

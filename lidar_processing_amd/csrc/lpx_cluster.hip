@@ -1159,79 +1159,7 @@ __global__ void hull_pack_kernel(const uint32_t *__restrict__ off, const uint32_
 }
 
 #ifdef LPX_DEV_KNOBS
-// Development build only (tools/r4_probe14.sh): what is the device short of with many chains in flight?  Two kernels
-// that add a KNOWN amount of ONE resource to every chain -- vector-ALU issue cycles (no memory traffic) or scattered
-// 64-byte line requests (a handful of instructions each) -- so that the throughput they cost names the resource.
-__global__ __launch_bounds__(256) void burn_alu_kernel(float *sink, uint32_t iters)
-{
-    float a = (float)threadIdx.x * 1.0e-3f, b = a + 1.0f, c = a + 2.0f, d = a + 3.0f;
-    for (uint32_t i = 0; i < iters; ++i)
-    {
-        a = __builtin_fmaf(a, 0.999999f, 0.5f);
-        b = __builtin_fmaf(b, 0.999998f, 0.25f);
-        c = __builtin_fmaf(c, 0.999997f, 0.125f);
-        d = __builtin_fmaf(d, 0.999996f, 0.0625f);
-    }
-    if (a + b + c + d == 123.456f)
-        sink[0] = a;
-}
-
-__global__ __launch_bounds__(256) void burn_mem_kernel(const uint4 *__restrict__ buf, uint32_t line_mask, uint32_t iters,
-                                                       uint32_t *sink, uint32_t salt)
-{
-    uint32_t s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + salt;
-    uint32_t acc = 0;
-    for (uint32_t i = 0; i < iters; i += 4)
-    {
-        uint32_t idx[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-        {
-            s = s * 1664525u + 1013904223u;
-            idx[u] = (s >> 4) & line_mask;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            acc ^= buf[(size_t)idx[u] * 4u].x;  // one 16-byte word of a random 64-byte line
-    }
-    if (acc == 0x12345u)
-        sink[0] = acc;
-}
-
-static void burn_resources(lpx_ctx *ctx)
-{
-    static const uint32_t alu = LPX_KNOB("LPX_BURN_ALU") ? (uint32_t)atoi(LPX_KNOB("LPX_BURN_ALU")) : 0u;
-    static const uint32_t mem = LPX_KNOB("LPX_BURN_MEM") ? (uint32_t)atoi(LPX_KNOB("LPX_BURN_MEM")) : 0u;
-    static const uint32_t blocks = LPX_KNOB("LPX_BURN_BLOCKS") ? (uint32_t)atoi(LPX_KNOB("LPX_BURN_BLOCKS")) : 1024u;
-    if (!alu && !mem)
-        return;
-    static void *buf = nullptr;
-    static uint32_t salt = 0;
-    constexpr size_t BYTES = 4ull << 30;  // far beyond L2 and the 256 MB of last-level cache
-    if (!buf)
-    {
-        static std::mutex mu;
-        std::lock_guard<std::mutex> lk(mu);
-        if (!buf)
-        {
-            void *p = nullptr;
-            if (hipMalloc(&p, BYTES) != hipSuccess)
-                return;
-            hipMemset(p, 1, BYTES);
-            hipDeviceSynchronize();
-            buf = p;
-        }
-    }
-    if (alu)
-        hipLaunchKernelGGL(burn_alu_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (float *)buf, alu);
-    // LPX_BURN_SPAN_MB: the lines come from the first so many MB of the buffer (a power of two): 4096 = memory,
-    // 64 = what the 256 MB last-level cache holds, 2 = what one L2 holds
-    static const uint32_t span_mb = LPX_KNOB("LPX_BURN_SPAN_MB") ? (uint32_t)atoi(LPX_KNOB("LPX_BURN_SPAN_MB")) : 4096u;
-    const size_t span = ((size_t)(span_mb < 1u ? 1u : (span_mb > 4096u ? 4096u : span_mb))) << 20;
-    if (mem)
-        hipLaunchKernelGGL(burn_mem_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)buf,
-                           (uint32_t)(span / 64 - 1), mem, (uint32_t *)buf, ++salt);
-}
+#include "../../experiments/burners.inc"  // resource burners (measurement only)
 #endif
 
 static uint32_t bits_for_count(uint32_t n)  // bits to hold values 0..n-1

@@ -234,7 +234,15 @@ struct lpx_ctx
     hipStream_t copy_stream = nullptr;  // downloads of the segmentation beside the look-ahead clustering
     hipEvent_t ev_seg = nullptr;        // the segmentation's kernels (and the snapshot of its frame state) are done
     void *h_frame = nullptr;            // pinned: that snapshot
-    Buf pts4;                  // the cloud in original order, float4 {x, y, z, 0} per point
+    Buf pts4;                  // the cloud in original order, float4 {x, y, z, 0} per point (only when rec_direct is off)
+    // where the records of the last segmentation call lie (device memory: the caller's array or the staging buffer of a
+    // host call) and how (stride, field offsets, records between the frames of a batch): with rec_direct the last pass
+    // of the x sort and lpx_coloured_clouds* read the coordinates from there and no copy is made
+    const void *rec_ptr = nullptr;
+    size_t rec_stride = 0;
+    uint32_t rec_off[3] = {0, 4, 8};
+    uint32_t rec_pitch = 0;
+    bool rec_direct = false;
     Buf key_a, key_b;          // u32 keys ping-pong
     Buf val_a, val_b;          // u32 values ping-pong
     Buf key64_a, key64_b;      // u64 keys ping-pong
@@ -350,11 +358,60 @@ struct StageTimer
 // (function copies if the pass count is odd).  n is a host upper bound; d_n (optional) the device count.
 // gather (optional): the sorted values index a table of 16-byte records {x, y, z, .}; the LAST pass writes x / y / z of
 // the records in sorted order itself (and leaves the sorted keys unwritten: *keys_out is then not to be read)
+// records: either the arena's table of 16-byte records {x, y, z, .} in input order (stride 0: one table per frame slot) or
+// the CALLER's records themselves (stride > 0: float32 x / y / z at byte offsets off[] of every stride-byte record, frame
+// b of the call `pitch` records behind frame 0) -- then nobody has to write a copy of the cloud first
 struct LpxSortGather
 {
     const void *records;
     float *x, *y, *z;
+    size_t stride = 0;
+    uint32_t off[3] = {0, 4, 8};
+    uint32_t pitch = 0;
 };
+// how a kernel reads x, y, z of record i (LpxSortGather / lpx_ctx::rec_*): mode 0 = 16-byte table entries, 1 = records
+// whose x, y, z are the first three floats and which are 16-byte aligned (every PCL point type: ONE 16-byte load),
+// 2 = 4-byte aligned fields, 3 = bytes (a PointCloud2 buffer with odd offsets)
+struct LpxRecLayout
+{
+    size_t stride = 0;
+    uint32_t ox = 0, oy = 4, oz = 8, pitch = 0, mode = 0;
+};
+static inline LpxRecLayout lpx_rec_layout(const void *records, size_t stride, const uint32_t *off, uint32_t pitch)
+{
+    LpxRecLayout l;
+    l.stride = stride;
+    l.ox = off[0], l.oy = off[1], l.oz = off[2];
+    l.pitch = pitch;
+    if (stride == 0)
+        l.mode = 0;
+    else if (off[0] == 0 && off[1] == 4 && off[2] == 8 && (((uintptr_t)records | stride) & 15u) == 0)
+        l.mode = 1;
+    else if ((((uintptr_t)records | stride | off[0] | off[1] | off[2]) & 3u) == 0)
+        l.mode = 2;
+    else
+        l.mode = 3;
+    return l;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ float lpx_ld_bytes_f32(const char *p)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    return __uint_as_float((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24));
+}
+__device__ __forceinline__ float4 lpx_rec_xyz(const float4 *rec, uint32_t i, const LpxRecLayout &lay)
+{
+    if (lay.mode == 0)
+        return rec[i];
+    const char *p = (const char *)rec + (size_t)i * lay.stride;
+    if (lay.mode == 1)
+        return *(const float4 *)p;
+    if (lay.mode == 2)
+        return make_float4(*(const float *)(p + lay.ox), *(const float *)(p + lay.oy), *(const float *)(p + lay.oz), 0.0f);
+    return make_float4(lpx_ld_bytes_f32(p + lay.ox), lpx_ld_bytes_f32(p + lay.oy), lpx_ld_bytes_f32(p + lay.oz), 0.0f);
+}
+#endif
+
 // first_hist_ready: the producer of keys_a has left the tile histograms of the lowest key byte in lpx_sort_first_hist()
 // iota_vals: vals_a[i] == i is MEANT, the array is never read (nobody has to write it)
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,

@@ -2600,14 +2600,37 @@ __global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long 
     thead[s] = 0;  // points of the cell
 }
 
-#ifndef LPX_GRID_INSERT_ITEMS
-#define LPX_GRID_INSERT_ITEMS 1  // (4 and 8 measured: no gain -- the kernel waits for its atomics, not for its loads)
-#endif
-__global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *__restrict__ OX,
-                                   const float *__restrict__ OY, const float *__restrict__ OZ, float d,
-                                   unsigned long long *tkey, uint32_t *thead, uint32_t *__restrict__ next,
-                                   uint32_t *__restrict__ cells, uint32_t *__restrict__ cell_of,
-                                   float4 *__restrict__ trep, uint32_t cap_max, size_t fs)
+// Insert, aggregated per tile in LDS.  The obstacle cloud arrives in x order (the segmentation emits it slab by slab,
+// every slab x-sorted), so the GI_TILE consecutive points of a workgroup lie in a thin x slice and share their cells:
+// a KITTI frame holds 3.3 points per cell and a cell's points almost always sit in ONE tile.  Rounds 2-4 sent every
+// POINT to the table in memory -- an agent-scope load of the key, one atomicAdd on the cell's counter, and on this part
+// an agent-scope atomic is executed on the memory side whatever the L2 holds (5 300 cycles of latency each, one fabric
+// request each: 4.0 M atomics + 5.9 M reads and writes per 64-frame chain, the largest single consumer of the chain's
+// requests).  Now the tile's points are first counted per cell in an LDS table (LDS atomics), and only every DISTINCT
+// (tile, cell) goes to the global table: one probe, one atomicAdd of the tile's whole count (its old value is where
+// the tile's points begin inside the cell's run), and the workgroup's newly claimed cells are listed with ONE bump of
+// the frame's cell counter -- so that cells claimed by one tile are neighbours in the cell list, take neighbouring
+// runs in grid_alloc_kernel, and the scatter of a tile writes one compact region.  Nothing depends on the order of the
+// input: an unsorted cloud (lpx_cluster of any cloud) just aggregates less.  The order of a cell's points inside its
+// run and which point represents a cell differ from run to run, like before; the components do not.
+constexpr int GI_THREADS = 256;
+constexpr int GI_PER = 4;                      // points per thread
+constexpr int GI_TILE = GI_THREADS * GI_PER;   // 1024 points per workgroup
+constexpr int GI_SLOTS = 2048;                 // LDS table: load factor <= 1/2
+__device__ __forceinline__ uint32_t gi_lds_hash(unsigned long long key)
+{
+    unsigned long long k = key * 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(k >> 40);
+}
+
+__global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__restrict__ frame,
+                                                                 const float *__restrict__ OX,
+                                                                 const float *__restrict__ OY,
+                                                                 const float *__restrict__ OZ, float d,
+                                                                 unsigned long long *tkey, uint32_t *thead,
+                                                                 uint32_t *__restrict__ next, uint32_t *__restrict__ cells,
+                                                                 uint32_t *__restrict__ cell_of, float4 *__restrict__ trep,
+                                                                 uint32_t cap_max, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<6>(fs);
     trep = lpx_slot(trep, fs);
@@ -2620,75 +2643,122 @@ __global__ void grid_insert_kernel(FrameState *__restrict__ frame, const float *
     next = lpx_slot(next, fs);
     cells = lpx_slot(cells, fs);
     cell_of = lpx_slot(cell_of, fs);
+    __shared__ unsigned long long lkey[GI_SLOTS];  // the tile's cells
+    __shared__ uint32_t lcnt[GI_SLOTS];            // points of the tile in the cell; after phase 2: where they begin in the cell's run
+    __shared__ uint32_t lslot[GI_SLOTS];           // first: a point of the tile in that cell (the representative); then: the cell's table slot
+    __shared__ uint32_t lclaim[GI_TILE];           // table slots this workgroup claimed
+    __shared__ uint32_t llist[GI_TILE];            // the occupied LDS slots (phase 2 walks them with every lane busy)
+    __shared__ uint32_t nclaim, claim_base, nlist;
     const uint32_t M = frame->n_obstacle;
+    const uint32_t tile0 = lpx_blk.x * GI_TILE;
+    if (tile0 >= M)
+        return;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t s = tid; s < GI_SLOTS; s += GI_THREADS)
+    {
+        lkey[s] = CELL_EMPTY;
+        lcnt[s] = 0;
+    }
+    if (tid == 0)
+        nclaim = nlist = 0;
+    __syncthreads();
     const uint32_t mask = cell_cap_for(M, cap_max) - 1;
     const double inv_c = cell_inv_edge(d);
-    // GI points per lane (consecutive lanes on consecutive points): the coordinate loads, the first probes and the
-    // position counters of the GI points are in flight together; only a probe that has to move on and the rare claim
-    // of a new cell run one point at a time
-    constexpr int GI = LPX_GRID_INSERT_ITEMS;
-    uint32_t idx[GI], h[GI];
-    float px[GI], py[GI], pz[GI];
-    unsigned long long key[GI], old[GI];
-    bool in[GI];
+    // phase 1: every point into the LDS table (consecutive lanes on consecutive points, the GI_PER loads together)
+    uint32_t ls[GI_PER], lrank[GI_PER];
+    float px[GI_PER], py[GI_PER], pz[GI_PER];
+    bool in[GI_PER];
 #pragma unroll
-    for (int u = 0; u < GI; ++u)
+    for (int u = 0; u < GI_PER; ++u)
     {
-        idx[u] = (lpx_blk.x * GI + u) * blockDim.x + threadIdx.x;
-        in[u] = idx[u] < M;
-        px[u] = in[u] ? OX[idx[u]] : 0.0f;
-        py[u] = in[u] ? OY[idx[u]] : 0.0f;
-        pz[u] = in[u] ? OZ[idx[u]] : 0.0f;
+        const uint32_t i = tile0 + u * GI_THREADS + tid;
+        in[u] = i < M;
+        px[u] = in[u] ? OX[i] : 0.0f;
+        py[u] = in[u] ? OY[i] : 0.0f;
+        pz[u] = in[u] ? OZ[i] : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < GI; ++u)
+    for (int u = 0; u < GI_PER; ++u)
     {
-        key[u] = ((unsigned long long)cell_coord(px[u], inv_c) << 42) | ((unsigned long long)cell_coord(py[u], inv_c) << 21) |
-                 (unsigned long long)cell_coord(pz[u], inv_c);
-        h[u] = cell_hash(key[u]) & mask;
-        old[u] = in[u] ? __hip_atomic_load(tkey + h[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : key[u];
-    }
-#pragma unroll
-    for (int u = 0; u < GI; ++u)
-    {
+        ls[u] = 0;
+        lrank[u] = 0;
         if (!in[u])
             continue;
-        unsigned long long o = old[u];
+        const unsigned long long key = ((unsigned long long)cell_coord(px[u], inv_c) << 42) |
+                                       ((unsigned long long)cell_coord(py[u], inv_c) << 21) |
+                                       (unsigned long long)cell_coord(pz[u], inv_c);
+        uint32_t s = gi_lds_hash(key) & (GI_SLOTS - 1);
         for (;;)
         {
-            // look before the compare-and-swap: all but the first points of a cell find its key with a plain (L2) load,
-            // and atomics on one address serialise -- a dense cell near the sensor holds hundreds of points
+            unsigned long long o = lkey[s];
             if (o == CELL_EMPTY)
-                o = atomicCAS(tkey + h[u], CELL_EMPTY, key[u]);
+                o = atomicCAS(&lkey[s], CELL_EMPTY, key);
             if (o == CELL_EMPTY)
             {
-                cells[atomicAdd(&frame->n_cells, 1u)] = h[u];           // this point claimed the cell: list it ...
-                trep[h[u]] = make_float4(px[u], py[u], pz[u], 0.0f);    // ... and represents it in the quick test of the linking
+                lslot[s] = tile0 + u * GI_THREADS + tid;  // this point stands for the cell if the tile claims it
+                llist[atomicAdd(&nlist, 1u)] = s;
                 break;
             }
-            if (o == key[u])
+            if (o == key)
                 break;
-            h[u] = (h[u] + 1) & mask;
-            o = __hip_atomic_load(tkey + h[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s = (s + 1) & (GI_SLOTS - 1);
         }
+        ls[u] = s;
+        lrank[u] = atomicAdd(&lcnt[s], 1u);
     }
-    uint32_t pos[GI];
+    __syncthreads();
+    // phase 2: every distinct cell of the tile to the table in memory (a thread per cell: the dependent round trips of
+    // all cells of the tile -- probe, claim, position -- are in flight together)
+    const uint32_t ncell = nlist;
+    for (uint32_t c = tid; c < ncell; c += GI_THREADS)
+    {
+        const uint32_t s = llist[c];
+        const unsigned long long key = lkey[s];
+        uint32_t h = cell_hash(key) & mask;
+        unsigned long long o = __hip_atomic_load(tkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;)
+        {
+            if (o == CELL_EMPTY)
+                o = atomicCAS(tkey + h, CELL_EMPTY, key);
+            if (o == CELL_EMPTY)
+            {
+                const uint32_t rep = lslot[s];
+                trep[h] = make_float4(OX[rep], OY[rep], OZ[rep], 0.0f);  // represents the cell in the quick test of the linking
+                lclaim[atomicAdd(&nclaim, 1u)] = h;
+                break;
+            }
+            if (o == key)
+                break;
+            h = (h + 1) & mask;
+            o = __hip_atomic_load(tkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lcnt[s] = atomicAdd(thead + h, lcnt[s]);  // the tile's points take consecutive positions among the cell's points
+        lslot[s] = h;
+    }
+    __syncthreads();
+    if (tid == 0 && nclaim)
+        claim_base = atomicAdd(&frame->n_cells, nclaim);
+    __syncthreads();
+    for (uint32_t c = tid; c < nclaim; c += GI_THREADS)
+        cells[claim_base + c] = lclaim[c];
+    // phase 3: what the scatter needs per point
 #pragma unroll
-    for (int u = 0; u < GI; ++u)
-        pos[u] = in[u] ? atomicAdd(thead + h[u], 1u) : 0u;  // the point's position among the points of its cell
-#pragma unroll
-    for (int u = 0; u < GI; ++u)
+    for (int u = 0; u < GI_PER; ++u)
         if (in[u])
         {
-            cell_of[idx[u]] = h[u];
-            next[idx[u]] = pos[u];
+            const uint32_t i = tile0 + u * GI_THREADS + tid;
+            cell_of[i] = lslot[ls[u]];
+            next[i] = lcnt[ls[u]] + lrank[u];
         }
 }
 
 // The points of every cell as ONE contiguous run of {x, y, z, index} records (the linking then reads a cell's points
-// with independent loads instead of walking a list): a cell takes its run from a running cursor ...
-__global__ void grid_alloc_kernel(FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
-                                  const uint32_t *__restrict__ tcount, uint32_t *__restrict__ tstart, size_t fs)
+// with independent loads instead of walking a list): the cells take their runs in the order of the cell list, a
+// wavefront's 64 cells with ONE bump of the frame's cursor (an exclusive scan of their counts: 64 x fewer atomics on
+// that word, and the cells a tile claimed together get neighbouring runs) ...
+__global__ __launch_bounds__(256) void grid_alloc_kernel(FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
+                                                         const uint32_t *__restrict__ tcount, uint32_t *__restrict__ tstart,
+                                                         size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<6>(fs);
     frame = lpx_slot(frame, fs);
@@ -2696,10 +2766,20 @@ __global__ void grid_alloc_kernel(FrameState *__restrict__ frame, const uint32_t
     tcount = lpx_slot(tcount, fs);
     tstart = lpx_slot(tstart, fs);
     const uint32_t c = lpx_blk.x * blockDim.x + threadIdx.x;
-    if (c >= frame->n_cells)
-        return;
-    const uint32_t h = cells[c];
-    tstart[h] = atomicAdd(&frame->cell_cursor, tcount[h]);
+    const uint32_t nc = frame->n_cells;
+    if ((c & ~(uint32_t)(WAVE - 1)) >= nc)
+        return;  // (whole wavefronts leave together)
+    const bool on = c < nc;
+    const uint32_t h = on ? cells[c] : 0u;
+    const uint32_t cnt = on ? tcount[h] : 0u;
+    const uint32_t incl = lpx_wave_incl_scan_u32(cnt);
+    const uint32_t total = __shfl(incl, WAVE - 1, WAVE);
+    uint32_t base = 0;
+    if ((threadIdx.x & (WAVE - 1)) == 0)
+        base = atomicAdd(&frame->cell_cursor, total);
+    base = __shfl(base, 0, WAVE);
+    if (on)
+        tstart[h] = base + incl - cnt;
 }
 
 // ... and every point goes to its position in the run of its cell
@@ -3008,604 +3088,6 @@ __global__ __launch_bounds__(256) void grid_flatten_kernel(const FrameState *__r
     }
 }
 
-#ifdef LPX_DEV_KNOBS  // (development build only: measured, not adopted -- see the header below and DESIGN.md section 4)
-// ------------------------------------------------------------------------------------------------
-// Expansion-driven search, part 2b: the same connected components from a SWEEP over the cloud's own order -- no hash
-// table, no scattered global access.
-//
-// Why: with sixteen chains in flight the device is short of memory transactions, not of arithmetic (tools/r4_probe14.sh:
-// scattered 64-byte line requests added to every chain cost their whole stand-alone time in throughput, vector-ALU work
-// added the same way costs a third of it; the vector ALUs are ~43 % busy).  The clique-cell grid above is the opposite
-// trade: almost no arithmetic, ~24 MB of scattered traffic per KITTI frame (inserts, probes, runs, roots).
-//
-// How: the obstacle cloud the segmentation leaves is in x order (the partitions are x slabs of the x-sorted cloud,
-// src/segmentation.cpp:104-149, and the obstacles are emitted slab by slab in that order), so a PIECE of 1024 consecutive
-// points is a thin x slab.  sweep_pieces_kernel sorts every piece by y in LDS and writes it out as {x, y, z, index}
-// records with its bounding box; sweep_link_kernel gives a workgroup one piece: it stages, one after the other, the
-// pieces up to its own whose boxes (widened by the radius) meet its box -- in an x-sorted cloud its own and the one or
-// two before it; ANY order of the input is handled, an unordered cloud just meets more pieces -- and every wavefront
-// tests its tiles of 64 y-consecutive queries, one query per lane, against the candidates of the staged piece inside
-// the tile's y window (found by a two-step search over the sorted y), one candidate per step read from LDS by all lanes.
-// The test is the reference's float expression (src/kdtree.hpp:145-157, inclusive :315).  A pair is looked at once, by
-// the point that comes later in the piece-major, y-sorted order; a query unites with a neighbour only if that neighbour
-// is farther than d from the one it linked last (induction on the later point's position, as in kd_link_queries).
-// Global traffic: the cloud read once and written once, every piece read ~2.3 times (coalesced), the union-find words.
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t SW_PIECE = 1024;
-constexpr uint32_t SW_THREADS = 256;
-struct SweepBox
-{
-    float lo[3], hi[3];
-    uint32_t count, pad;
-};
-
-__device__ __forceinline__ uint32_t sw_key(float v)  // ascending unsigned order == ascending float order
-{
-    const uint32_t u = __float_as_uint(v);
-    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
-}
-__device__ __forceinline__ float sw_unkey(uint32_t k)
-{
-    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
-}
-
-__global__ __launch_bounds__(SW_THREADS) void sweep_pieces_kernel(const FrameState *__restrict__ frame,
-                                                                  const float *__restrict__ OX,
-                                                                  const float *__restrict__ OY,
-                                                                  const float *__restrict__ OZ, float4 *__restrict__ Q,
-                                                                  SweepBox *__restrict__ box, float *__restrict__ ysamp,
-                                                                  uint32_t *__restrict__ parent, size_t fs)
-{
-    const LpxBlock lpx_blk = lpx_block<6>(fs);
-    __shared__ unsigned long long s_key[SW_PIECE];
-    __shared__ float s_x[SW_PIECE], s_z[SW_PIECE];
-    __shared__ float s_red[4][SW_THREADS / WAVE];
-    frame = lpx_slot(frame, fs);
-    OX = lpx_slot(OX, fs);
-    OY = lpx_slot(OY, fs);
-    OZ = lpx_slot(OZ, fs);
-    Q = lpx_slot(Q, fs);
-    box = lpx_slot(box, fs);
-    ysamp = lpx_slot(ysamp, fs);
-    parent = lpx_slot(parent, fs);
-    const uint32_t M = frame->n_obstacle, p0 = lpx_blk.x * SW_PIECE, tid = threadIdx.x;
-    if (p0 >= M)
-        return;
-    const uint32_t cnt = min(SW_PIECE, M - p0);
-    float xlo = 3.0e38f, xhi = -3.0e38f, zlo = 3.0e38f, zhi = -3.0e38f;
-#pragma unroll
-    for (uint32_t r = 0; r < SW_PIECE / SW_THREADS; ++r)
-    {
-        const uint32_t k = tid + SW_THREADS * r;
-        if (k < cnt)
-        {
-            const float x = OX[p0 + k], y = OY[p0 + k], z = OZ[p0 + k];
-            uf_st(parent + p0 + k, p0 + k);  // every point its own set
-            s_x[k] = x;
-            s_z[k] = z;
-            s_key[k] = ((unsigned long long)sw_key(y) << 32) | k;
-            xlo = fminf(xlo, x), xhi = fmaxf(xhi, x), zlo = fminf(zlo, z), zhi = fmaxf(zhi, z);
-        }
-        else
-            s_key[k] = ~0ull;  // behind every point
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-    {
-        xlo = fminf(xlo, __shfl_xor(xlo, o, 64));
-        xhi = fmaxf(xhi, __shfl_xor(xhi, o, 64));
-        zlo = fminf(zlo, __shfl_xor(zlo, o, 64));
-        zhi = fmaxf(zhi, __shfl_xor(zhi, o, 64));
-    }
-    if (tid % WAVE == 0)
-    {
-        s_red[0][tid / WAVE] = xlo;
-        s_red[1][tid / WAVE] = xhi;
-        s_red[2][tid / WAVE] = zlo;
-        s_red[3][tid / WAVE] = zhi;
-    }
-    __syncthreads();
-    // bitonic sort of the (y key, position) words
-    for (uint32_t k2 = 2; k2 <= SW_PIECE; k2 <<= 1)
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1)
-        {
-#pragma unroll
-            for (uint32_t r = 0; r < SW_PIECE / 2 / SW_THREADS; ++r)
-            {
-                const uint32_t t = tid + SW_THREADS * r;
-                const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
-                const unsigned long long a = s_key[i], b = s_key[l];
-                if ((a > b) == ((i & k2) == 0u))
-                {
-                    s_key[i] = b;
-                    s_key[l] = a;
-                }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-    for (uint32_t r = 0; r < SW_PIECE / SW_THREADS; ++r)
-    {
-        const uint32_t k = tid + SW_THREADS * r;
-        if (k < cnt)
-        {
-            const unsigned long long c = s_key[k];
-            const uint32_t li = (uint32_t)c & (SW_PIECE - 1u);
-            Q[p0 + k] = make_float4(s_x[li], sw_unkey((uint32_t)(c >> 32)), s_z[li], __uint_as_float(p0 + li));
-        }
-    }
-    if (tid < 64u)  // the y of the last entry of every 16-entry bucket: step 1 of the searches for a y window
-        ysamp[lpx_blk.x * 64u + tid] = 16u * tid + 15u < cnt ? sw_unkey((uint32_t)(s_key[16u * tid + 15u] >> 32)) : 3.0e38f;
-    if (tid == 0)
-    {
-        SweepBox b;
-        b.lo[0] = fminf(fminf(s_red[0][0], s_red[0][1]), fminf(s_red[0][2], s_red[0][3]));
-        b.hi[0] = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
-        b.lo[2] = fminf(fminf(s_red[2][0], s_red[2][1]), fminf(s_red[2][2], s_red[2][3]));
-        b.hi[2] = fmaxf(fmaxf(s_red[3][0], s_red[3][1]), fmaxf(s_red[3][2], s_red[3][3]));
-        b.lo[1] = sw_unkey((uint32_t)(s_key[0] >> 32));
-        b.hi[1] = sw_unkey((uint32_t)(s_key[cnt - 1] >> 32));
-        b.count = cnt;
-        b.pad = 0;
-        box[lpx_blk.x] = b;
-    }
-}
-
-// One workgroup per tile of SC_TILE y-consecutive queries of a piece.  Its WINDOW -- of every piece up to its own whose
-// box meets the tile's box (widened by the radius) the run of entries inside the tile's y range, the tile itself last --
-// goes to LDS; the window's points are binned into clique cells (edge 0.99 d / sqrt 3, as the grid above) in an LDS hash
-// table; every cell that holds a query probes its 124 partners IN LDS, and a pair of cells with a point pair within d
-// (first the two lowest window positions, then every pair) is united in a union-find over the table slots, in LDS.
-// Only the outcome leaves the workgroup: a slot that is not its own local root unites the lowest point of its cell
-// with the lowest point of the root's cell, and a query that is not the lowest point of its cell unites with it
-// (global union-find over points, a frame's words live in one L2).  Why that is complete: for a pair (i, j) within d, j
-// earlier than i in the piece-major, y-sorted order, the workgroup of i's tile holds both (j lies inside the widened
-// box, inside the y window, in a piece whose box meets, at a lower position) and therefore unites a point of cell(i)
-// with a point of cell(j); and the points of one cell are all within d of each other, so each finds the cell's globally
-// lowest point in its own window and unites with it.  A window that does not fit (more than SC_WMAX points, more than
-// 2^10 x 2^11 x 2^10 cells -- dense or unordered clouds) is swept by plain tests instead, chunk by chunk: same result.
-constexpr uint32_t SC_TILE = 128;
-constexpr uint32_t SC_THREADS = 256;
-constexpr uint32_t SC_WMAX = 1536;
-constexpr uint32_t SC_SLOTS = 2048;
-constexpr uint32_t SC_NONE = 0xffffffffu;
-
-__device__ __forceinline__ uint32_t sc_hash(uint32_t key)
-{
-    return (key * 2654435761u) >> 21;  // 11 bits: SC_SLOTS
-}
-
-struct ScRun  // the entries of piece c inside a tile's y window
-{
-    uint32_t src, len;
-};
-
-// (all lanes of a wavefront, uniform arguments and result)
-__device__ __forceinline__ ScRun sc_run(const float4 *__restrict__ Q, const float *__restrict__ ysamp, uint32_t c,
-                                        uint32_t cntc, float ylo, float yhi, uint32_t lane)
-{
-    const float sv = ysamp[c * 64u + lane];  // y of the last entry of every 16-entry bucket (3e38 beyond the end)
-    const uint32_t nbl = (uint32_t)__popcll(__ballot(sv < ylo));
-    const uint32_t nbh = (uint32_t)__popcll(__ballot(sv <= yhi));
-    const uint32_t half = lane >> 4, l16 = lane & 15u;
-    const uint32_t ei = 16u * (half ? nbh : nbl) + l16;
-    const float ev = (half < 2u && ei < cntc) ? Q[c * SW_PIECE + ei].y : 3.0e38f;
-    const unsigned long long em = __ballot(half == 0u ? ev < ylo : (half == 1u ? ev <= yhi : false));
-    uint32_t jlo = 16u * nbl + (uint32_t)__popcll(em & 0xffffull);
-    uint32_t jhi = 16u * nbh + (uint32_t)__popcll(em & 0xffff0000ull);
-    jlo = min(jlo, cntc);
-    jhi = min(jhi, cntc);
-    ScRun r;
-    r.src = c * SW_PIECE + jlo;
-    r.len = jhi > jlo ? jhi - jlo : 0u;
-    return r;
-}
-
-constexpr uint32_t SC_RUNS = 8;  // candidate pieces of a tile in the cell path (an x-sorted cloud: 2-4)
-
-__global__ __launch_bounds__(SC_THREADS) void sweep_link_kernel(const FrameState *__restrict__ frame,
-                                                                const float4 *__restrict__ Q,
-                                                                const SweepBox *__restrict__ box,
-                                                                const float *__restrict__ ysamp, uint32_t *parent,
-                                                                float r2, float rr, float d, int force_plain, int stop, size_t fs)
-{
-    const LpxBlock lpx_blk = lpx_block<5>(fs);
-    __shared__ float4 s_pt[SC_WMAX];
-    __shared__ uint16_t s_next[SC_WMAX];
-    // key / head double as the list of unions that leave the workgroup (s_un) once the linking is over
-    __shared__ __attribute__((aligned(16))) uint32_t s_tab[4][SC_SLOTS];
-    uint32_t *const s_key = s_tab[0], *const s_head = s_tab[1], *const s_min = s_tab[2], *const s_par = s_tab[3];
-    uint2 *const s_un = (uint2 *)&s_tab[0][0];  // SC_SLOTS entries
-    __shared__ uint32_t s_qcell[SC_TILE];
-    __shared__ float s_red[4][SC_THREADS / WAVE];
-    __shared__ uint32_t s_run_src[SC_RUNS], s_run_len[SC_RUNS];
-    __shared__ uint32_t s_nqc, s_nun;
-    frame = lpx_slot(frame, fs);
-    Q = lpx_slot(Q, fs);
-    box = lpx_slot(box, fs);
-    ysamp = lpx_slot(ysamp, fs);
-    parent = lpx_slot(parent, fs);
-    const uint32_t M = frame->n_obstacle, q0 = lpx_blk.x * SC_TILE, tid = threadIdx.x;
-    if (q0 >= M)
-        return;
-    const uint32_t nq = min(SC_TILE, M - q0), p = q0 / SW_PIECE, pl_end = q0 - p * SW_PIECE + nq;
-    const uint32_t w = tid / WAVE, lane = tid % WAVE;
-    // the boxes of the (first 64) pieces up to the tile's own: requested before anything waits
-    const uint32_t pbase = p >= WAVE ? p - (WAVE - 1u) : 0u;
-    const uint32_t cl0 = pbase + lane;  // the 64 pieces that end with p
-    const SweepBox bc0 = box[cl0 <= p ? cl0 : p];
-    // ---- the tile's box, widened ----
-    float tlo[3], thi[3];
-    {
-        const float4 q = Q[q0 + min(tid & (SC_TILE - 1u), nq - 1u)];
-        const float yfirst = Q[q0].y, ylast = Q[q0 + nq - 1u].y;  // (the piece is sorted by y)
-        float xlo = q.x, xhi = q.x, zlo = q.z, zhi = q.z;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-        {
-            xlo = fminf(xlo, __shfl_xor(xlo, o, 64));
-            xhi = fmaxf(xhi, __shfl_xor(xhi, o, 64));
-            zlo = fminf(zlo, __shfl_xor(zlo, o, 64));
-            zhi = fmaxf(zhi, __shfl_xor(zhi, o, 64));
-        }
-        if (lane == 0)
-        {
-            s_red[0][w] = xlo;
-            s_red[1][w] = xhi;
-            s_red[2][w] = zlo;
-            s_red[3][w] = zhi;
-        }
-        if (tid == 0)
-        {
-            s_nqc = 0;
-            s_nun = 0;
-        }
-        __syncthreads();
-        tlo[0] = fminf(fminf(s_red[0][0], s_red[0][1]), fminf(s_red[0][2], s_red[0][3]));
-        thi[0] = fmaxf(fmaxf(s_red[1][0], s_red[1][1]), fmaxf(s_red[1][2], s_red[1][3]));
-        tlo[2] = fminf(fminf(s_red[2][0], s_red[2][1]), fminf(s_red[2][2], s_red[2][3]));
-        thi[2] = fmaxf(fmaxf(s_red[3][0], s_red[3][1]), fmaxf(s_red[3][2], s_red[3][3]));
-        tlo[1] = yfirst;
-        thi[1] = ylast;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-        {
-            tlo[a] -= rr;
-            thi[a] += rr;
-            tlo[a] -= fabsf(tlo[a]) * 2.4e-7f;  // two ulps: far from the origin the rounding beats any fixed margin
-            thi[a] += fabsf(thi[a]) * 2.4e-7f;
-        }
-    }
-    // ---- the candidate pieces and their runs.  Cell path: at most SC_RUNS pieces, all among the 64 that end with the
-    // tile's own, the runs found by the wavefronts side by side (every wavefront computes the same mask) ----
-    const bool meets0 = cl0 <= p && bc0.lo[0] <= thi[0] && bc0.hi[0] >= tlo[0] && bc0.lo[1] <= thi[1] &&
-                        bc0.hi[1] >= tlo[1] && bc0.lo[2] <= thi[2] && bc0.hi[2] >= tlo[2];
-    const unsigned long long cm0 = __ballot(meets0);
-    const uint32_t ncand = (uint32_t)__popcll(cm0);
-    const double inv_c = cell_inv_edge(d);
-    uint32_t org[3], ext[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-    {
-        org[a] = cell_coord(tlo[a], inv_c);
-        ext[a] = cell_coord(thi[a], inv_c) - org[a] + 1u;
-    }
-    bool cells = !force_plain && ncand <= SC_RUNS && ext[0] <= 1024u && ext[1] <= 2048u && ext[2] <= 1024u;
-    // (pieces before the 64 looked at may meet the box too -- an unordered cloud: the plain sweep looks at all of them)
-    for (uint32_t cbase = 0; cells && cbase < pbase; cbase += WAVE)
-    {
-        const uint32_t cl = cbase + lane;
-        const SweepBox bc = box[cl < pbase ? cl : 0u];
-        const bool meets = cl < pbase && bc.lo[0] <= thi[0] && bc.hi[0] >= tlo[0] && bc.lo[1] <= thi[1] &&
-                           bc.hi[1] >= tlo[1] && bc.lo[2] <= thi[2] && bc.hi[2] >= tlo[2];
-        cells = __ballot(meets) == 0ull;
-    }
-    uint32_t W = 0;
-    if (cells)
-    {
-        unsigned long long cm = cm0;
-        for (uint32_t k = 0; cm; ++k)
-        {
-            const int ci = __ffsll((long long)cm) - 1;
-            cm &= cm - 1;
-            if ((k & (SC_THREADS / WAVE - 1u)) != w)
-                continue;
-            const uint32_t c = pbase + (uint32_t)ci;
-            const uint32_t cntc = (uint32_t)__builtin_amdgcn_readlane((int)bc0.count, ci);
-            ScRun r = sc_run(Q, ysamp, c, cntc, tlo[1], thi[1], lane);
-            if (c == p)
-                r.len = pl_end - (r.src - p * SW_PIECE);  // the own piece: up to the tile's last query
-            if (lane == 0)
-            {
-                s_run_src[k] = r.src;
-                s_run_len[k] = r.len;
-            }
-        }
-        for (uint32_t sl = tid; sl < SC_SLOTS; sl += SC_THREADS)
-        {
-            s_key[sl] = SC_NONE;
-            s_head[sl] = SC_NONE;
-            s_min[sl] = SC_NONE;
-            s_par[sl] = sl;
-        }
-        __syncthreads();
-        for (uint32_t k = 0; k < ncand; ++k)
-            W += s_run_len[k];
-        cells = W <= SC_WMAX;
-    }
-    if (stop == 1)
-        return;
-    if (cells)
-    {
-        // ---- the window ----
-        uint32_t off = 0;
-        for (uint32_t k = 0; k < ncand; ++k)
-        {
-            const uint32_t src = s_run_src[k], len = s_run_len[k];
-            for (uint32_t i = tid; i < len; i += SC_THREADS)
-                s_pt[off + i] = Q[src + i];
-            off += len;
-        }
-        __syncthreads();
-        if (stop == 2)
-            return;
-        // every window point inside the widened box goes into its cell (the others cannot be within d of a query);
-        // the queries -- the last nq points of the window -- after all others, so that the head of a cell's list is a
-        // query whenever the cell holds one
-        constexpr uint32_t PER = (SC_WMAX + SC_THREADS - 1) / SC_THREADS;
-        const uint32_t wq = W - nq;
-        uint32_t slot_q = SC_NONE;  // a thread inserts at most one query (nq <= SC_TILE <= SC_THREADS)
-#pragma unroll 1
-        for (int phase = 0; phase < 2; ++phase)
-        {
-#pragma unroll
-            for (uint32_t u = 0; u < PER; ++u)
-            {
-                const uint32_t wi = phase ? wq + tid : tid + SC_THREADS * u;
-                if (phase ? (u > 0 || tid >= nq) : wi >= wq)
-                    continue;
-                const float4 pt = s_pt[wi];
-                s_next[wi] = 0xffffu;
-                if (!(pt.x >= tlo[0] && pt.x <= thi[0] && pt.y >= tlo[1] && pt.y <= thi[1] && pt.z >= tlo[2] &&
-                      pt.z <= thi[2]))
-                    continue;
-                const uint32_t key = ((cell_coord(pt.x, inv_c) - org[0]) << 21) |
-                                     ((cell_coord(pt.y, inv_c) - org[1]) << 10) | (cell_coord(pt.z, inv_c) - org[2]);
-                uint32_t h = sc_hash(key);
-                for (;;)
-                {
-                    const uint32_t o = atomicCAS(&s_key[h], SC_NONE, key);
-                    if (o == SC_NONE || o == key)
-                        break;
-                    h = (h + 1u) & (SC_SLOTS - 1u);
-                }
-                atomicMin(&s_min[h], wi);
-                s_next[wi] = (uint16_t)atomicExch(&s_head[h], wi);  // (SC_NONE -> 0xffff)
-                if (phase)
-                    slot_q = h;
-            }
-            __syncthreads();
-        }
-        // the cells that hold a query, listed by the query at the head of their list
-        if (slot_q != SC_NONE && s_head[slot_q] == wq + tid)
-            s_qcell[atomicAdd(&s_nqc, 1u)] = slot_q;
-        __syncthreads();
-        if (stop == 3)
-            return;
-        // the 26 partners that touch a cell first -- almost all of them are connected and the quick test settles them --
-        // then the 98 one cell further away, most of which already share a (local) set through the cells in between
-        // and are skipped before any point pair is looked at
-        const uint32_t nqc = s_nqc;
-#pragma unroll 1
-        for (int far = 0; far < 2; ++far)
-        {
-        const uint32_t per = far ? 98u : 26u, total = nqc * per;
-        for (uint32_t it = tid; it < total; it += SC_THREADS)
-        {
-            const uint32_t A = s_qcell[it / per];
-            uint32_t t = it % per;
-            if (far)
-                t = t < 49u ? FAR_T[t] : 124u - FAR_T[t - 49u];
-            else
-            {
-                t += t >= 13u ? 1u : 0u;  // [-1, 1]^3 without (0, 0, 0) ...
-                t = (t / 9u + 1u) * 25u + ((t / 3u) % 3u + 1u) * 5u + (t % 3u + 1u);  // ... as an offset of [-2, 2]^3
-            }
-            const uint32_t ka = s_key[A];
-            const uint32_t bx = (ka >> 21) + t / 25u - 2u, by = ((ka >> 10) & 2047u) + (t / 5u) % 5u - 2u,
-                           bz = (ka & 1023u) + t % 5u - 2u;
-            if (bx >= ext[0] || by >= ext[1] || bz >= ext[2])
-                continue;  // (unsigned: below 0 or beyond the widened box -- no point there)
-            const uint32_t kb = (bx << 21) | (by << 10) | bz;
-            uint32_t B = sc_hash(kb);
-            for (;;)
-            {
-                const uint32_t k = s_key[B];
-                if (k == kb)
-                    break;
-                if (k == SC_NONE)
-                {
-                    B = SC_NONE;
-                    break;
-                }
-                B = (B + 1u) & (SC_SLOTS - 1u);
-            }
-            if (B == SC_NONE)
-                continue;
-            if (s_head[B] >= wq && B < A)
-                continue;  // both hold queries: the pair is B's as well, once is enough
-            // local union-find over the slots (hook the larger slot under the smaller; a stale read costs a retry)
-            uint32_t ra = A, rb = B;
-            for (uint32_t pa = s_par[ra]; pa != ra; pa = s_par[ra])
-                ra = pa;
-            for (uint32_t pb = s_par[rb]; pb != rb; pb = s_par[rb])
-                rb = pb;
-            if (ra == rb)
-                continue;
-            bool joined;
-            {
-                const float4 a = s_pt[s_min[A]], b = s_pt[s_min[B]];
-                const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z;
-                joined = d0 * d0 + (d1 * d1 + d2 * d2) <= r2;
-            }
-            for (uint32_t ia = s_head[A]; ia != SC_NONE && !joined; ia = s_next[ia] == 0xffffu ? SC_NONE : s_next[ia])
-            {
-                const float4 a = s_pt[ia];
-                for (uint32_t ib = s_head[B]; ib != SC_NONE && !joined;
-                     ib = s_next[ib] == 0xffffu ? SC_NONE : s_next[ib])
-                {
-                    const float4 b = s_pt[ib];
-                    const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z;
-                    // dist_sqr, src/kdtree.hpp:145-157, inclusive :315
-                    joined = d0 * d0 + (d1 * d1 + d2 * d2) <= r2;
-                }
-            }
-            if (!joined)
-                continue;
-            for (;;)
-            {
-                for (uint32_t pa = s_par[ra]; pa != ra; pa = s_par[ra])
-                    ra = pa;
-                for (uint32_t pb = s_par[rb]; pb != rb; pb = s_par[rb])
-                    rb = pb;
-                if (ra == rb)
-                    break;
-                if (ra < rb)
-                {
-                    const uint32_t x = ra;
-                    ra = rb;
-                    rb = x;
-                }
-                if (atomicCAS(&s_par[ra], ra, rb) == ra)
-                    break;
-            }
-        }
-        __syncthreads();
-        }
-        __syncthreads();
-        if (stop == 4)
-            return;
-        // ---- what leaves the workgroup: first into registers (the list overwrites key / head), then one dense list ----
-        constexpr uint32_t SPER = SC_SLOTS / SC_THREADS;
-        uint2 un[SPER + 1];
-#pragma unroll
-        for (uint32_t u = 0; u < SPER; ++u)
-        {
-            const uint32_t sl = tid + SC_THREADS * u;
-            un[u] = make_uint2(SC_NONE, SC_NONE);
-            if (s_key[sl] == SC_NONE)
-                continue;
-            uint32_t r = sl;
-            for (uint32_t pr = s_par[r]; pr != r; pr = s_par[r])
-                r = pr;
-            if (r != sl)
-                un[u] = make_uint2(__float_as_uint(s_pt[s_min[sl]].w), __float_as_uint(s_pt[s_min[r]].w));
-        }
-        un[SPER] = make_uint2(SC_NONE, SC_NONE);
-        if (slot_q != SC_NONE)
-        {
-            const uint32_t m = s_min[slot_q];
-            if (m != wq + tid)
-                un[SPER] = make_uint2(__float_as_uint(s_pt[wq + tid].w), __float_as_uint(s_pt[m].w));
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t u = 0; u <= SPER; ++u)
-            if (un[u].x != SC_NONE)
-                s_un[atomicAdd(&s_nun, 1u)] = un[u];  // (at most one entry per occupied slot and per query: <= SC_SLOTS)
-        __syncthreads();
-        const uint32_t nun = s_nun;
-        for (uint32_t i = tid; i < nun; i += SC_THREADS)
-            uf_unite(parent, s_un[i].x, s_un[i].y);
-        return;
-    }
-    // ---- plain sweep (the window does not fit): every wavefront holds 64 of the queries, one per lane -- the four
-    // wavefronts are two halves of the tile x the even / odd groups of four entries; the runs pass through LDS in
-    // chunks of SC_WMAX entries and every query is tested against every entry before it ----
-    __syncthreads();
-    const uint32_t my = q0 + (w & 1u) * WAVE + lane;  // position of the lane's query in Q
-    const bool act = my < q0 + nq;
-    const float4 q = Q[act ? my : q0];
-    const uint32_t qi = __float_as_uint(q.w);
-    for (uint32_t cbase = 0; cbase <= p; cbase += WAVE)
-    {
-        const uint32_t cl = cbase + lane;
-        const SweepBox bc = box[cl <= p ? cl : p];
-        const bool meets = cl <= p && bc.lo[0] <= thi[0] && bc.hi[0] >= tlo[0] && bc.lo[1] <= thi[1] &&
-                           bc.hi[1] >= tlo[1] && bc.lo[2] <= thi[2] && bc.hi[2] >= tlo[2];
-        unsigned long long cm = __ballot(meets);
-        while (cm)
-        {
-            const int ci = __ffsll((long long)cm) - 1;
-            cm &= cm - 1;
-            const uint32_t c = cbase + (uint32_t)ci;
-            const uint32_t cntc = (uint32_t)__builtin_amdgcn_readlane((int)bc.count, ci);
-            ScRun r = sc_run(Q, ysamp, c, cntc, tlo[1], thi[1], lane);
-            if (c == p)
-                r.len = pl_end - (r.src - p * SW_PIECE);
-            for (uint32_t c0 = 0; c0 < r.len; c0 += SC_WMAX)
-            {
-                const uint32_t cn = min(SC_WMAX, r.len - c0);
-                __syncthreads();  // (the scans of the chunk before this one are over)
-                for (uint32_t k = tid; k < cn; k += SC_THREADS)
-                    s_pt[k] = Q[r.src + c0 + k];
-                __syncthreads();
-                float lx = 0.0f, ly = 0.0f, lz = 0.0f;
-                bool have_last = false;
-                uint32_t l0 = SC_NONE, l1 = SC_NONE, l2 = SC_NONE, l3 = SC_NONE;  // pending unions, newest first
-                const uint32_t base = r.src + c0;                                    // position in Q of s_pt[0]
-                for (uint32_t j = 4u * (w >> 1); j < cn; j += 8)
-                {
-                    float4 cd[4];
-                    bool hit[4];
-                    bool any = false;
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k)
-                        cd[k] = s_pt[min(j + k, cn - 1u)];
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k)
-                    {
-                        const float a0 = q.x - cd[k].x, a1 = q.y - cd[k].y, a2 = q.z - cd[k].z;
-                        const float da = a0 * a0 + (a1 * a1 + a2 * a2);
-                        hit[k] = act && j + k < cn && base + j + k < my && da <= r2;
-                        any = any || hit[k];
-                    }
-                    if (__ballot(any) == 0ull)
-                        continue;
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k)
-                    {
-                        if (!hit[k])
-                            continue;
-                        const float b0 = lx - cd[k].x, b1 = ly - cd[k].y, b2 = lz - cd[k].z;
-                        if (have_last && b0 * b0 + (b1 * b1 + b2 * b2) <= r2)
-                            continue;  // within d of the neighbour linked last: that pair is somebody's own
-                        if (l3 != SC_NONE)
-                            uf_unite(parent, qi, l3);
-                        l3 = l2;
-                        l2 = l1;
-                        l1 = l0;
-                        l0 = __float_as_uint(cd[k].w);
-                        lx = cd[k].x;
-                        ly = cd[k].y;
-                        lz = cd[k].z;
-                        have_last = true;
-                    }
-                }
-                if (l0 != SC_NONE)
-                    uf_unite(parent, qi, l0);
-                if (l1 != SC_NONE)
-                    uf_unite(parent, qi, l1);
-                if (l2 != SC_NONE)
-                    uf_unite(parent, qi, l2);
-                if (l3 != SC_NONE)
-                    uf_unite(parent, qi, l3);
-            }
-        }
-    }
-}
-
-#endif  // LPX_DEV_KNOBS
 
 __global__ void layout_idx_kernel(const Node *__restrict__ nodes, uint32_t m, uint32_t *__restrict__ out)
 {
@@ -3806,14 +3288,9 @@ bool lpx_cc_from_chunks(uint32_t m_max)
 }
 
 #ifdef LPX_DEV_KNOBS
-// ... or from the sweep over the cloud's own order (lpx_sweep_components)
-bool lpx_cc_from_sweep(uint32_t m_max)
-{
-    static const char *e = LPX_KNOB("LPX_CC");
-    if (e)
-        return strcmp(e, "sweep") == 0;
-    return false;
-}
+// development build only: the components from a sweep over the cloud's own order (measured, not adopted) live outside
+// the product sources
+#include "../../experiments/sweep_components.inc"
 #endif
 
 int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2, bool clear_grid)
@@ -3878,8 +3355,8 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     if (!cleared)  // (nb_index_kernel has emptied the table when it ran right in front of this: one launch less)
         hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, thead, ctx->cell_cap,
                            ctx->fs_tag);
-    const dim3 gi((m_max + 256 * LPX_GRID_INSERT_ITEMS - 1) / (256 * LPX_GRID_INSERT_ITEMS), 1, ctx->cur_b);
-    hipLaunchKernelGGL(grid_insert_kernel, gi, blk, 0, ctx->stream, frame, (const float *)ctx->OX.p,
+    const dim3 gi((m_max + GI_TILE - 1) / GI_TILE, 1, ctx->cur_b);
+    hipLaunchKernelGGL(grid_insert_kernel, gi, dim3(GI_THREADS), 0, ctx->stream, frame, (const float *)ctx->OX.p,
                        (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells,
                        (uint32_t *)ctx->cell_of.p, (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fs_tag);
     uint32_t *tstart = (uint32_t *)ctx->cell_start.p;
@@ -3932,26 +3409,3 @@ int lpx_grid_flatten(lpx_ctx *ctx, uint32_t m_max, uint32_t *d_root, uint32_t *d
     return LPX_OK;
 }
 
-#ifdef LPX_DEV_KNOBS
-int lpx_sweep_components(lpx_ctx *ctx, uint32_t m_max, float r2)
-{
-    if (m_max == 0)
-        return LPX_OK;
-    StageTimer tm(ctx, ST_NB_SCAN);
-    const float rr = sqrtf(r2) * 1.0001f + 1.0e-3f;
-    const dim3 pieces((m_max + SW_PIECE - 1) / SW_PIECE, 1, ctx->cur_b), tiles((m_max + SC_TILE - 1) / SC_TILE, 1, ctx->cur_b);
-    if (sizeof(SweepBox) * (size_t)pieces.x > ctx->cell_xyz.bytes || sizeof(float) * 64u * (size_t)pieces.x > ctx->cell_list.bytes)
-        return lpx_fail(ctx, LPX_ERR_INTERNAL, "%u sweep pieces do not fit the workspace", pieces.x);
-    static const int plain = LPX_KNOB("LPX_SWEEP_PLAIN") ? atoi(LPX_KNOB("LPX_SWEEP_PLAIN")) : 0;  // tests: the fallback alone
-    static const int stop = LPX_KNOB("LPX_SWEEP_STOP") ? atoi(LPX_KNOB("LPX_SWEEP_STOP")) : 0;     // timing only (wrong results)
-    hipLaunchKernelGGL(sweep_pieces_kernel, pieces, dim3(SW_THREADS), 0, ctx->stream, (const FrameState *)ctx->frame.p,
-                       (const float *)ctx->OX.p, (const float *)ctx->OY.p, (const float *)ctx->OZ.p,
-                       (float4 *)ctx->cell_pts.p, (SweepBox *)ctx->cell_xyz.p, (float *)ctx->cell_list.p,
-                       (uint32_t *)ctx->parent.p, ctx->fs_tag);
-    hipLaunchKernelGGL(sweep_link_kernel, tiles, dim3(SC_THREADS), 0, ctx->stream, (const FrameState *)ctx->frame.p,
-                       (const float4 *)ctx->cell_pts.p, (const SweepBox *)ctx->cell_xyz.p, (const float *)ctx->cell_list.p,
-                       (uint32_t *)ctx->parent.p, r2, rr, sqrtf(r2), plain, stop, ctx->fs_tag);
-    LPX_HIP(ctx, hipGetLastError());
-    return LPX_OK;
-}
-#endif

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
                                                                       const float4 *__restrict__ rec = nullptr,
                                                                       float *__restrict__ GX = nullptr,
                                                                       float *__restrict__ GY = nullptr,
-                                                                      float *__restrict__ GZ = nullptr)
+                                                                      float *__restrict__ GZ = nullptr,
+                                                                      LpxRecLayout lay = LpxRecLayout())
 {
     const LpxBlock lpx_blk = lpx_block<1>(fs);
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];
@@ -81,7 +82,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
     offs = lpx_slot(offs, fs);
     if (GATHER)
     {
-        rec = lpx_slot(rec, fs);
+        if (lay.stride == 0)
+            rec = lpx_slot(rec, fs);  // the arena's table of this frame slot
+        else
+            rec = (const float4 *)((const char *)rec + (size_t)lpx_blk.z * lay.pitch * lay.stride);  // the caller's frame
         GX = lpx_slot(GX, fs);
         GY = lpx_slot(GY, fs);
         GZ = lpx_slot(GZ, fs);
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
             const bool in = j < tile_n;
             vv[r] = in ? stage_v[HAS_VALS ? j : 0] : 0u;
             dd[r] = in ? gofs[(uint32_t)(stage_k[j] >> shift) & (RADIX - 1)] + j : 0u;
-            q[r] = rec[vv[r]];
+            q[r] = lpx_rec_xyz(rec, vv[r], lay);
         }
 #pragma unroll
         for (int r = 0; r < SORT_ITEMS; ++r)
@@ -547,7 +551,8 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
         if (gather && shift + 8 >= bits)  // the last pass also fetches the records the sorted values name
             hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
                                ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large, fs,
-                               (const float4 *)gather->records, gather->x, gather->y, gather->z);
+                               (const float4 *)gather->records, gather->x, gather->y, gather->z,
+                               lpx_rec_layout(gather->records, gather->stride, gather->off, gather->pitch));
         else
             hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
                                ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large, fs);

@@ -28,7 +28,7 @@ constexpr int SEG_WAVES = SEG_THREADS / WAVE;
 #define LPX_PASS_CHUNK 4096
 #endif
 #ifndef LPX_PASS_MINWAVES
-#define LPX_PASS_MINWAVES 1
+#define LPX_PASS_MINWAVES 3
 #endif
 constexpr uint32_t SEG_CHUNK = LPX_PASS_CHUNK;  // points per block of the plane passes / the compaction (64 per lane of a one-wavefront
                                       // pass block; the int64 moment lanes hold 256 points: |q| < 2^27, products < 2^54)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(INGEST_THREADS) void ingest_kernel(const char *__re
         {
             if (P4)
                 P4[i] = make_float4(x, y, z, 0.0f);  // one 16-byte record per point: whoever gathers it touches one line
-            else
+            else if (X)  // (neither: the consumers read the caller's records where they lie -- lpx_ctx::rec_direct)
             {
                 X[i] = x;
                 Y[i] = y;
@@ -1225,9 +1225,19 @@ __device__ __forceinline__ void seg_block_range(const SegParams &prm, uint32_t s
 // the ~1900 blocks of a 64-frame launch are all resident at once (two per SIMD), their heads overlap one another and
 // the loads of the other blocks, and the block reduction is a DPP reduction without LDS or barriers.
 constexpr int PASS_THREADS = WAVE;
-constexpr int PASS_QUADS = 4;                                           // quads (four consecutive points) per lane and trip
+constexpr int PASS_QUADS = 4;                                           // (general form) quads per lane and trip
 constexpr uint32_t PASS_TRIP = 4u * PASS_THREADS * PASS_QUADS;          // points of a trip: 1024
-static_assert(SEG_CHUNK % (2u * PASS_TRIP) == 0, "a block is an even number of trips (two register sets alternate)");
+// The lean loop keeps a RING of PASS_RING quads (four consecutive points: three 16-byte loads) per lane: quad g of the
+// block is lane's points base + 4 (lane + 64 g) ..., a wavefront instruction reads 1 KB; as soon as a quad has been
+// processed its registers take the load of the quad PASS_RING further on, so 7/8 of the 96 staging registers are in
+// flight at any time (two alternating sets of four quads: half of them) -- 21 KB per wavefront.
+#ifndef LPX_PASS_RING
+#define LPX_PASS_RING 4
+#endif
+constexpr int PASS_RING = LPX_PASS_RING;
+constexpr uint32_t PASS_QUAD_POINTS = 4u * PASS_THREADS;                // points of one quad row of a wavefront: 256
+static_assert(SEG_CHUNK % (2u * PASS_TRIP) == 0 && (2u * PASS_TRIP) % (PASS_RING * PASS_QUAD_POINTS) == 0,
+              "a block is a whole number of rings");
 
 typedef float pass_v4f __attribute__((ext_vector_type(4)));
 
@@ -1273,130 +1283,34 @@ __device__ __forceinline__ bool plane_from_moment_lanes(long long v, uint32_t la
     return true;
 }
 
-template <bool FINAL>
-__global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_kernel(const float *__restrict__ XS,
-                                                                   const float *__restrict__ YS,
-                                                                   const float *__restrict__ ZS, SegParams prm,
-                                                                   uint32_t t, SegState *st, long long *part,
-                                                                   long long *facc, uint8_t *__restrict__ flags,
-                                                                   uint32_t *__restrict__ blk_counts,
-                                                                   const FrameState *__restrict__ frame, size_t fs)
+// ---- the general form of the loop, for frames that hold a point beyond +-2048 m (rare: a spurious far return, a cloud in
+// a map frame): member points that do not fit the int32 lanes go to the segment's far accumulator one by one.  Kept out
+// of line, loading for itself, so that its registers and its call do not shape the allocation of the lean loop.
+struct PassGeneric
 {
-    const LpxBlock lpx_blk = lpx_block<2>(fs);
-    XS = lpx_slot(XS, fs);
-    YS = lpx_slot(YS, fs);
-    ZS = lpx_slot(ZS, fs);
-    st = lpx_slot(st, fs);
-    part = lpx_slot(part, fs);
-    facc = lpx_slot(facc, fs);
-    flags = lpx_slot(flags, fs);
-    blk_counts = lpx_slot(blk_counts, fs);
-    frame = lpx_slot(frame, fs);
-    seg_bind(prm, frame);
-    const bool any_far = frame->has_far != 0;
-    const uint32_t s = lpx_blk.y, b = lpx_blk.x;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t nb = prm.P * prm.bps;
-    uint32_t base, lo, hi;
-    seg_block_range(prm, s, b, base, lo, hi);
-    const uint32_t trips = prm.chunk / PASS_TRIP;  // even (seg_geometry)
-
-    // two register sets of four quads per lane: the loads of trip k + 1 are in flight while trip k is processed
-    pass_v4f xa[PASS_QUADS], ya[PASS_QUADS], za[PASS_QUADS], xb[PASS_QUADS], yb[PASS_QUADS], zb[PASS_QUADS];
-#define LPX_PASS_LOAD(X4, Y4, Z4, TRIP)                                                                               \
-    _Pragma("unroll") for (int u = 0; u < PASS_QUADS; ++u)                                                            \
-    {                                                                                                                 \
-        const uint32_t p_ = base + 4u * (lane + PASS_THREADS * (u + PASS_QUADS * (TRIP)));                            \
-        if (p_ < hi) /* (a quad that starts before `hi` may reach past it: the arrays carry 16 spare elements) */     \
-        {                                                                                                             \
-            X4[u] = *(const pass_v4f *)(XS + p_);                                                                     \
-            Y4[u] = *(const pass_v4f *)(YS + p_);                                                                     \
-            Z4[u] = *(const pass_v4f *)(ZS + p_);                                                                     \
-        }                                                                                                             \
-    }
-    // The first trip is requested before anything else and is on its way from HBM while the head runs.  (Measured, per
-    // 64-frame pass chain / per 5M-point frame: one trip ahead 0.198 / 0.115 ms; two trips ahead with 4096-point blocks
-    // 0.302 / 0.120; 2048-point blocks, both trips ahead, 0.262 / 0.150, and 0.367 / 0.166 when held to 128 registers:
-    // every register spent on data in flight costs a resident wavefront -- 168 registers keep three per SIMD, which is
-    // all blocks of a 64-frame launch -- and resident wavefronts are what hides the heads of the others.)
-    LPX_PASS_LOAD(xa, ya, za, 0u)
-
-    // ---- head: the state this pass tests against ----
-    SegState sst;
-    if (t == 0)
-        sst = st[s];  // the seed state, set 0
-    else
-    {
-        // plane t - 1 from the rows pass t - 1 left (set (t - 1) & 1): 4 rows x 16 words per load instruction, eight
-        // independent loads in flight per lane
-        const long long *pin = part + (size_t)((t + 1u) & 1u) * prm.part_stride + (size_t)s * prm.bps * LPX_ACC_WORDS;
-        const uint32_t row = lane >> 4, word = lane & 15u;
-        long long v = 0;
-        for (uint32_t r0 = 0; r0 < prm.bps; r0 += 32)
-        {
-            long long q[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-            {
-                const uint32_t r = r0 + row + 4u * k;
-                q[k] = r < prm.bps ? pin[(size_t)r * LPX_ACC_WORDS + word] : 0ll;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                v += q[k];
-        }
-        v += __shfl_xor(v, 16, WAVE);
-        v += __shfl_xor(v, 32, WAVE);  // every lane: the segment's total of word lane & 15
-        SegState o = st[(size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS + s];
-        if (o.failed == 0)
-        {
-            float plane[4];
-            bool ok;
-            if (any_far)
-            {
-                // rare (a coordinate beyond +-2048 m): the far-point limbs join the sums; the plain evaluation
-                long long m[LPX_ACC_WORDS], fm[LPX_FAR_WORDS];
-#pragma unroll
-                for (int i = 0; i < LPX_ACC_WORDS; ++i)
-                    m[i] = __shfl(v, i, WAVE);
-                const long long *fin = facc + ((size_t)((t - 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS;
-                for (int i = 0; i < LPX_FAR_WORDS; ++i)
-                    fm[i] = fin[i];
-                ok = plane_from_moments(m, fm, plane);
-            }
-            else
-                ok = plane_from_moment_lanes(v, lane, plane);
-            // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
-            if (!ok)
-                o.failed = 1;
-            else
-            {
-                o.plane[0] = plane[0];
-                o.plane[1] = plane[1];
-                o.plane[2] = plane[2];
-                o.plane[3] = plane[3];
-                o.thr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
-                o.fitted = 1;
-            }
-        }
-        if (b == 0 && lane == 0)
-            st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s] = o;  // what the compaction hands out as planes
-        // the far set pass t + 1 accumulates into was read by pass t - 1 and is free
-        if (any_far && b == 0 && lane < LPX_FAR_WORDS)
-            facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
-        sst = o;
-    }
-    const bool skip = sst.failed == 2;       // < 3 points: nothing labelled
-    const bool dead = sst.failed != 0;       // all obstacle
+    long long m[10];        // n, sx, sy, sz, xx, xy, xz, yy, yz, zz
+    uint32_t cnt_g, cnt_o;
+};
+template <bool FINAL>
+__device__ __noinline__ void pass_block_generic(const float *XS, const float *YS, const float *ZS, uint32_t base,
+                                                uint32_t lo, uint32_t hi, uint32_t trips, uint32_t lane,
+                                                const SegState *sstp, uint32_t t, uint32_t I, long long *fa,
+                                                uint8_t *flags, PassGeneric *out)
+{
+    const SegState sst = *sstp;
+    const bool any_far = true;
+    const bool skip = sst.failed == 2;
+    const bool dead = sst.failed != 0;
     const float pa = sst.plane[0], pb = sst.plane[1], pc = sst.plane[2], pd = sst.plane[3];
     const float thr = sst.thr;
     const bool use_seed = (t == 0);
     const bool seeds_ok = sst.has_seeds != 0;
-    long long *fa = facc + ((size_t)(t % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS;
-
+    struct
+    {
+        uint32_t I;
+    } prm = {I};
     long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
     uint32_t cnt_g = 0, cnt_o = 0;
-
     auto process = [&](const pass_v4f *x4, const pass_v4f *y4, const pass_v4f *z4, uint32_t trip) {
 #pragma unroll
         for (int u = 0; u < PASS_QUADS; ++u)
@@ -1458,17 +1372,260 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
             }
         }
     };
-    for (uint32_t trip = 0; trip < trips; trip += 2)
+    for (uint32_t trip = 0; trip < trips; ++trip)
     {
-        LPX_PASS_LOAD(xb, yb, zb, trip + 1u)
-        process(xa, ya, za, trip);
-        if (trip + 2 < trips)
+        pass_v4f xa[PASS_QUADS], ya[PASS_QUADS], za[PASS_QUADS];
+#pragma unroll
+        for (int u = 0; u < PASS_QUADS; ++u)
         {
-            LPX_PASS_LOAD(xa, ya, za, trip + 2u)
+            const uint32_t p_ = base + 4u * (lane + PASS_THREADS * (u + PASS_QUADS * trip));
+            if (p_ < hi)
+            {
+                xa[u] = *(const pass_v4f *)(XS + p_);
+                ya[u] = *(const pass_v4f *)(YS + p_);
+                za[u] = *(const pass_v4f *)(ZS + p_);
+            }
         }
-        process(xb, yb, zb, trip + 1u);
+        process(xa, ya, za, trip);
     }
-#undef LPX_PASS_LOAD
+    const long long r[10] = {a_n, a_x, a_y, a_z, a_xx, a_xy, a_xz, a_yy, a_yz, a_zz};
+    for (int i = 0; i < 10; ++i)
+        out->m[i] = r[i];
+    out->cnt_g = cnt_g;
+    out->cnt_o = cnt_o;
+}
+
+// ---- the streaming loop of a pass block, lean form ----
+// A pass is issue-bound as much as memory-bound: the first form of this loop spent 63 vector and 20 scalar instructions
+// per point (per-point scalar branches on conditions that are uniform for the whole block -- the kind of pass, "the
+// frame has a far point", "the segment is dead" --, 64-bit adds for sums that fit 32 bits for eight points, bounds
+// tests on every point of blocks that lie wholly inside their segment), the vector ALUs of a compute unit were 86 %
+// busy and pass 0 (two compares per point), the plane passes (six multiply-adds) and the final pass (no moments at
+// all) took the same 29-32 us per 96 MB.  Here everything uniform is decided once per block (template parameters
+// behind scalar branches around the whole loop), members are selected instead of branched on (a non-member adds
+// zeros), the three coordinate sums and the count run in 32-bit lanes flushed every eight points (|q| < 2^27), and only
+// the first and the last block of a segment test positions against the segment's bounds: 29 vector instructions per
+// point in a plane pass, 10 in the final one.  Integer sums: the result does not depend on any of this.
+struct PassUniform
+{
+    float pa, pb, pc, pd, thr;     // plane t - 1 and its threshold
+    float lo_excl, hi_incl;        // pass 0: the seed window
+    uint32_t base, lo, span;       // first position of the block's window; the segment's points are lo <= p < lo + span
+    uint32_t fm, fn;               // FINAL: flag of a member / of a non-member (0 when the segment is not labelled)
+};
+struct PassAcc
+{
+    long long x = 0, y = 0, z = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+    uint32_t n = 0, in = 0;        // members; FINAL with EDGE: points of the segment seen
+    int sx = 0, sy = 0, sz = 0;    // 32-bit partial sums of at most eight points
+    __device__ __forceinline__ void flush()
+    {
+        x += sx;
+        y += sy;
+        z += sz;
+        sx = sy = sz = 0;
+    }
+};
+
+template <bool FINAL, bool SEED, bool EDGE>
+__device__ __forceinline__ void pass_quad_lean(const pass_v4f x4, const pass_v4f y4, const pass_v4f z4, uint32_t p0,
+                                               const PassUniform &U, PassAcc &A, uint8_t *flags)
+{
+    uint32_t fword = 0, inq = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+    {
+        const float x = x4[e], y = y4[e], z = z4[e];
+        bool member;
+        if (SEED)
+            member = (z > U.lo_excl) && (z <= U.hi_incl);
+        else
+        {
+            const float dist = ((x * U.pa + y * U.pb) + z * U.pc) - U.pd;
+            member = dist < U.thr;
+        }
+        bool in = true;
+        if (EDGE)
+        {
+            in = (p0 + (uint32_t)e - U.lo) < U.span;  // (unsigned: positions before the segment wrap around)
+            member = member && in;
+        }
+        A.n += member ? 1u : 0u;
+        if (FINAL)
+        {
+            const uint32_t f = member ? U.fm : U.fn;
+            fword |= (EDGE && !in ? 0u : f) << (8 * e);
+            if (EDGE)
+                inq |= (in ? 1u : 0u) << e;
+        }
+        else
+        {
+            const int qx = member ? __float2int_rn(x * FIX_SCALE) : 0;
+            const int qy = member ? __float2int_rn(y * FIX_SCALE) : 0;
+            const int qz = member ? __float2int_rn(z * FIX_SCALE) : 0;
+            A.sx += qx;
+            A.sy += qy;
+            A.sz += qz;
+            A.xx += (long long)qx * qx;
+            A.xy += (long long)qx * qy;
+            A.xz += (long long)qx * qz;
+            A.yy += (long long)qy * qy;
+            A.yz += (long long)qy * qz;
+            A.zz += (long long)qz * qz;
+        }
+    }
+    if (FINAL)
+    {
+        if (!EDGE || inq == 0xfu)
+            *(uint32_t *)(flags + p0) = fword;  // p0 is a multiple of four
+        else
+            for (int e = 0; e < 4; ++e)
+                if ((inq >> e) & 1u)
+                    flags[p0 + e] = (uint8_t)(fword >> (8 * e));
+        if (EDGE)
+            A.in += __popc(inq);
+    }
+}
+
+template <bool FINAL>
+__global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_kernel(const float *__restrict__ XS,
+                                                                   const float *__restrict__ YS,
+                                                                   const float *__restrict__ ZS, SegParams prm,
+                                                                   uint32_t t, SegState *st, long long *part,
+                                                                   long long *facc, uint8_t *__restrict__ flags,
+                                                                   uint32_t *__restrict__ blk_counts,
+                                                                   const FrameState *__restrict__ frame, size_t fs)
+{
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
+    XS = lpx_slot(XS, fs);
+    YS = lpx_slot(YS, fs);
+    ZS = lpx_slot(ZS, fs);
+    st = lpx_slot(st, fs);
+    part = lpx_slot(part, fs);
+    facc = lpx_slot(facc, fs);
+    flags = lpx_slot(flags, fs);
+    blk_counts = lpx_slot(blk_counts, fs);
+    frame = lpx_slot(frame, fs);
+    seg_bind(prm, frame);
+    const bool any_far = frame->has_far != 0;
+    const uint32_t s = lpx_blk.y, b = lpx_blk.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nb = prm.P * prm.bps;
+    uint32_t base, lo, hi;
+    seg_block_range(prm, s, b, base, lo, hi);
+    const uint32_t trips = prm.chunk / PASS_TRIP;  // even (seg_geometry)
+    const uint32_t G = prm.chunk / PASS_QUAD_POINTS;  // quads per lane: a multiple of PASS_RING (seg_geometry)
+
+    // The ring of the lean loop.  Buffer loads: the three descriptors live in scalar registers, a load's address is the
+    // lane's constant byte offset plus a scalar offset -- no vector address arithmetic at all -- and reads beyond the
+    // frame's points return zeros (the last block of the last segment is clipped by the descriptor, not by a branch).
+    pass_v4f X[PASS_RING], Y[PASS_RING], Z[PASS_RING];
+    const uint32_t bytes = 4u * ((prm.n + 3u) & ~3u);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)XS, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)YS, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void *)ZS, 0, bytes, 0x00020000);
+    const uint32_t voff = lane * 16u;
+    typedef unsigned int pass_v4u __attribute__((ext_vector_type(4)));
+#define LPX_RING_LOAD(i, g)                                                                                            \
+    {                                                                                                                  \
+        /* quad g of the block; past the block's last quad: an offset beyond the descriptor's range (zeros, no access) */ \
+        const uint32_t so_ = (uint32_t)(g) < G ? 4u * (base + PASS_QUAD_POINTS * (uint32_t)(g)) : bytes;               \
+        X[i] = __builtin_bit_cast(pass_v4f, (pass_v4u)__builtin_amdgcn_raw_buffer_load_b128(rx, voff, so_, 0));        \
+        Y[i] = __builtin_bit_cast(pass_v4f, (pass_v4u)__builtin_amdgcn_raw_buffer_load_b128(ry, voff, so_, 0));        \
+        Z[i] = __builtin_bit_cast(pass_v4f, (pass_v4u)__builtin_amdgcn_raw_buffer_load_b128(rz, voff, so_, 0));        \
+    }
+
+    // ---- the state this pass tests against: S_t, set t & 1 of seg_state -- the seed window (t == 0, from the seed
+    // selection) or plane t - 1, which the LAST block of pass t - 1 to finish its segment solved and published (tail below)
+    const SegState sst = st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s];
+    const bool skip = sst.failed == 2;       // < 3 points: nothing labelled
+    const bool dead = sst.failed != 0;       // all obstacle
+    const float pa = sst.plane[0], pb = sst.plane[1], pc = sst.plane[2], pd = sst.plane[3];
+    const float thr = sst.thr;
+    const bool use_seed = (t == 0);
+    const bool seeds_ok = sst.has_seeds != 0;
+    long long *fa = facc + ((size_t)(t % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS;
+
+    long long a_n = 0, a_x = 0, a_y = 0, a_z = 0, a_xx = 0, a_xy = 0, a_xz = 0, a_yy = 0, a_yz = 0, a_zz = 0;
+    uint32_t cnt_g = 0, cnt_o = 0;
+
+    if (any_far)
+    {
+        // rare (a coordinate beyond +-2048 m somewhere in the frame): the general form, out of line
+        PassGeneric g;
+        pass_block_generic<FINAL>(XS, YS, ZS, base, lo, hi, trips, lane, &sst, t, prm.I, fa, flags, &g);
+        a_n = g.m[0], a_x = g.m[1], a_y = g.m[2], a_z = g.m[3];
+        a_xx = g.m[4], a_xy = g.m[5], a_xz = g.m[6], a_yy = g.m[7], a_yz = g.m[8], a_zz = g.m[9];
+        cnt_g = g.cnt_g, cnt_o = g.cnt_o;
+    }
+    else
+    {
+        // the lean form (pass_trip_lean): what is uniform for the block is decided here, once
+        PassUniform U;
+        const bool alive = !dead && (!use_seed || seeds_ok);
+        U.pa = pa, U.pb = pb, U.pc = pc, U.pd = pd;
+        U.thr = alive ? thr : -INFINITY;            // nobody is a member of a dead segment
+        U.lo_excl = alive ? sst.lo_excl : INFINITY;
+        U.hi_incl = sst.hi_incl;
+        U.base = base, U.lo = lo, U.span = hi - lo;
+        U.fm = skip ? 0u : 1u;
+        U.fn = skip ? 0u : ((prm.I == 0 && !dead) ? 0u : 2u);  // number_of_iterations == 0: the rest stays UNKNOWN (:243-247)
+        const bool edge = lo != base || hi != base + prm.chunk;  // the block is clipped by its segment's bounds
+        PassAcc A;
+// One instance of the loop: the ring is filled, then every quad is processed and its registers take the load of the
+// quad PASS_RING further on (sched_barrier: in that order -- left to itself the compiler copies the ring aside, requests
+// all eight reloads and processes the copies: 256 registers).
+#define LPX_PASS_RUN(SEEDV, EDGEV)                                                                                    \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < PASS_RING; ++i) LPX_RING_LOAD(i, i)                                     \
+        for (uint32_t g0 = 0; g0 < G; g0 += PASS_RING)                                                                \
+        {                                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < PASS_RING; ++i)                                                     \
+            {                                                                                                         \
+                pass_quad_lean<FINAL, SEEDV, EDGEV>(X[i], Y[i], Z[i], base + 4u * lane + PASS_QUAD_POINTS * (g0 + i), \
+                                                    U, A, flags);                                                     \
+                LPX_RING_LOAD(i, g0 + i + PASS_RING)                                                                  \
+                if (!FINAL && (i & 1))                                                                                \
+                    A.flush();                                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+        if (use_seed)
+        {
+            if (edge)
+            {
+                LPX_PASS_RUN(true, true)
+            }
+            else
+            {
+                LPX_PASS_RUN(true, false)
+            }
+        }
+        else if (edge)
+        {
+            LPX_PASS_RUN(false, true)
+        }
+        else
+        {
+            LPX_PASS_RUN(false, false)
+        }
+#undef LPX_PASS_RUN
+        if (FINAL)
+        {
+            const uint32_t seen = edge ? A.in : G * 4u;  // points of the segment this lane flagged
+            cnt_g = U.fm == 1u ? A.n : 0u;
+            cnt_o = U.fn == 2u ? seen - A.n : 0u;
+        }
+        else
+        {
+            A.flush();
+            a_n = (long long)A.n;
+            a_x = A.x, a_y = A.y, a_z = A.z;
+            a_xx = A.xx, a_xy = A.xy, a_xz = A.xz, a_yy = A.yy, a_yz = A.yz, a_zz = A.zz;
+        }
+    }
+#undef LPX_RING_LOAD
 
     if (FINAL)
     {
@@ -1484,8 +1641,17 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
         return;
     }
 
-    // 16 words: n, sx, sy, sz, then (hi, lo) limbs of the six second moments; this block's row of set t & 1 -- one
-    // 128-byte line, written whole, read by every block of the segment in the head of the next launch
+    // ---- tail: this block's moments, and -- for the block that arrives last -- the segment's next plane ----
+    // 16 words: n, sx, sy, sz, then (hi, lo) limbs of the six second moments, reduced over the wavefront and left in this
+    // block's 128-byte row of set t & 1 by sixteen lanes with ONE write-through store instruction.  Then the block takes
+    // a ticket of its segment (an agent-scope atomic behind the drained stores); the block that draws the last one reads
+    // all rows of the segment past every cache, sums them (integer sums: order-independent), solves the 3x3 problem --
+    // nine lanes for the nine double-precision quotients, the bit-exact Jacobi once -- and publishes S_{t+1} (set
+    // (t + 1) & 1) for the next launch.  So the solve runs ONCE per segment and pass, while the other segments still
+    // stream, instead of at the head of every block of the next pass (rounds 3-4: ~10 us of dependent instructions that
+    // each of a launch's ~1900 blocks had to wait for before it could test its first point -- and ~100 registers of
+    // 128-bit arithmetic live beside the staging registers of the loop).  Publication follows the write-through form of
+    // the hand-off: every store of the payload sc1 and drained before the ticket, every load of it sc1.
     long long v[LPX_ACC_WORDS];
     v[0] = a_n;
     v[1] = a_x;
@@ -1498,15 +1664,83 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
         v[4 + 2 * i] = sm[i] >> 32;
         v[5 + 2 * i] = sm[i] & 0xffffffffLL;
     }
+    long long mine = 0;
 #pragma unroll
     for (int i = 0; i < LPX_ACC_WORDS; ++i)
-        v[i] = lpx_wave_sum_i64(v[i]);  // valid in lane 0
-    if (lane == 0)
     {
-        long long *row = part + (size_t)(t & 1u) * prm.part_stride + ((size_t)s * prm.bps + b) * LPX_ACC_WORDS;
+        const long long tot = lpx_wave_sum_i64(v[i]);  // valid in lane 0
+        const long long bc = __shfl(tot, 0, WAVE);
+        mine = lane == (uint32_t)i ? bc : mine;
+    }
+    long long *rows = part + (size_t)(t & 1u) * prm.part_stride + (size_t)s * prm.bps * LPX_ACC_WORDS;
+    if (lane < LPX_ACC_WORDS)
+        __hip_atomic_store(rows + (size_t)b * LPX_ACC_WORDS + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row has left for memory
+    SegState *const cur = st + (size_t)(t & 1u) * LPX_MAX_PARTITIONS + s;
+    uint32_t ticket = 0;
+    if (lane == 0)
+        ticket = __hip_atomic_fetch_add(&cur->pad[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __shfl(ticket, 0, WAVE);
+    if (ticket != prm.bps - 1u)
+        return;
+    // the last block of the segment: every row is in memory
+    {
+        const uint32_t row = lane >> 4, word = lane & 15u;
+        long long tot = 0;
+        for (uint32_t r0 = 0; r0 < prm.bps; r0 += 32)
+        {
+            long long q[8];
 #pragma unroll
-        for (int i = 0; i < LPX_ACC_WORDS; ++i)
-            row[i] = v[i];
+            for (int k = 0; k < 8; ++k)
+            {
+                const uint32_t r = r0 + row + 4u * k;
+                q[k] = r < prm.bps ? __hip_atomic_load(rows + (size_t)r * LPX_ACC_WORDS + word, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                   : 0ll;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                tot += q[k];
+        }
+        tot += __shfl_xor(tot, 16, WAVE);
+        tot += __shfl_xor(tot, 32, WAVE);  // every lane: the segment's total of word lane & 15
+        SegState o = sst;  // sticky flags carry over
+        o.pad[0] = 0;      // S_{t+1} starts with a fresh ticket counter
+        if (o.failed == 0)
+        {
+            float plane[4];
+            bool ok;
+            if (any_far)
+            {
+                // rare (a coordinate beyond +-2048 m): the far-point limbs join the sums; the plain evaluation
+                long long m[LPX_ACC_WORDS], fm[LPX_FAR_WORDS];
+#pragma unroll
+                for (int i = 0; i < LPX_ACC_WORDS; ++i)
+                    m[i] = __shfl(tot, i, WAVE);
+                for (int i = 0; i < LPX_FAR_WORDS; ++i)  // (accumulated by memory-side atomics of every block)
+                    fm[i] = __hip_atomic_load(fa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = plane_from_moments(m, fm, plane);
+            }
+            else
+                ok = plane_from_moment_lanes(tot, lane, plane);
+            // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
+            if (!ok)
+                o.failed = 1;
+            else
+            {
+                o.plane[0] = plane[0];
+                o.plane[1] = plane[1];
+                o.plane[2] = plane[2];
+                o.plane[3] = plane[3];
+                o.thr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
+                o.fitted = 1;
+            }
+        }
+        if (lane == 0)
+            st[(size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS + s] = o;  // what pass t + 1 tests against; the compaction's planes
+        // the far set pass t + 1 accumulates into was read at the end of pass t - 2 and is free
+        if (any_far && lane < LPX_FAR_WORDS)
+            facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
     }
 }
 
@@ -1706,13 +1940,16 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
 // Record = 32 bytes as pcl::PointXYZRGBL lays them out (PCL 1.12 point_types: float x, y, z, 1.0f | b, g, r, a = 255
 // | uint32 label | 8 bytes of padding, written as zero).  One thread per record, two 16-byte stores.
 // ------------------------------------------------------------------------------------------------
-__global__ void colour_kernel(const float4 *__restrict__ P4,
+__global__ void colour_kernel(const float4 *__restrict__ P4, LpxRecLayout lay,
                               const uint32_t *__restrict__ gidx, const uint32_t *__restrict__ oidx,
                               const FrameState *__restrict__ frame, float4 *__restrict__ grec,
                               float4 *__restrict__ orec, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<0>(fv.fs);
-    P4 = lpx_slot(P4, fv.fs);
+    if (lay.stride == 0)
+        P4 = lpx_slot(P4, fv.fs);  // the arena's copy of the cloud
+    else
+        P4 = (const float4 *)((const char *)P4 + (size_t)lpx_blk.z * lay.pitch * lay.stride);  // the records of the call
     frame = lpx_slot(frame, fv.fs);
     gidx = lpx_user(gidx, fv.upitch);
     oidx = lpx_user(oidx, fv.upitch);
@@ -1726,7 +1963,7 @@ __global__ void colour_kernel(const float4 *__restrict__ P4,
     const uint32_t j = g ? i : i - ng;
     const uint32_t k = g ? gidx[j] : oidx[j];
     float4 *dst = (g ? grec : orec) + 2 * (size_t)j;
-    const float4 q = P4[k];
+    const float4 q = lpx_rec_xyz(P4, k, lay);
     dst[0] = make_float4(q.x, q.y, q.z, 1.0f);
     const uint32_t rgba = g ? 0xffdcdcdcu : 0xff00ff00u;  // a r g b from the top byte down: bytes b, g, r, a in memory
     dst[1] = make_float4(__uint_as_float(rgba), __uint_as_float(g ? 0u : 1u), 0.0f, 0.0f);
@@ -1799,8 +2036,13 @@ int lpx_run_colour(lpx_ctx *ctx, uint32_t n_max, const uint32_t *d_gidx, const u
 {
     if (n_max == 0)
         return LPX_OK;
+    // the coordinates: the arena's copy of the cloud, or -- when the segmentation made none (rec_direct) -- the records
+    // of that call where they lie
+    const uint32_t table_off[3] = {0, 4, 8};
+    const LpxRecLayout lay = ctx->rec_direct ? lpx_rec_layout(ctx->rec_ptr, ctx->rec_stride, ctx->rec_off, ctx->rec_pitch)
+                                             : lpx_rec_layout(ctx->pts4.p, 0, table_off, 0);
     hipLaunchKernelGGL(colour_kernel, dim3((n_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream,
-                       (const float4 *)ctx->pts4.p, d_gidx, d_oidx,
+                       (const float4 *)(ctx->rec_direct ? ctx->rec_ptr : ctx->pts4.p), lay, d_gidx, d_oidx,
                        (const FrameState *)ctx->frame.p, (float4 *)d_grec, (float4 *)d_orec, lpx_fv(ctx));
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
@@ -1939,11 +2181,6 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     const dim3 blk(256), grd((n + 255) / 256, 1, B);
 
     uint32_t *first_hist = lpx_sort_first_hist(ctx, n);  // the ingest also counts the lowest key byte per sort tile
-    {
-        StageTimer tm(ctx, ST_INGEST);
-        launch_ingest(ctx, n, d_pts, stride, nullptr, nullptr, nullptr, P4, (uint32_t *)ctx->key_a.p,
-                      (uint32_t *)nullptr, frame, nullptr, first_hist);  // (the sort's values are the positions: iota_vals)
-    }
     // segments that fit one workgroup's registers get their seed statistics by selection; larger ones (or more
     // representatives than the LDS sort holds) by the full (segment, z) sort
     const bool select_seeds = prm.n_per <= SEL_MAX_POINTS && prm.n_lpr <= SEL_MAX_LPR;
@@ -1958,7 +2195,28 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
 #else
     const bool fused_gather = (select_seeds || select_wide) && !(B == 1 && prm.n_per == 0);
 #endif
-    const LpxSortGather sg = {P4, XS, YS, ZS};
+    // With the gather inside the last sort pass nobody needs a copy of the cloud in input order: that pass (and
+    // lpx_coloured_clouds*) read x, y, z of a point from the records of the call where they lie -- one request per
+    // point either way -- and the ingest writes 4 bytes per point (the x key) instead of 20.
+    ctx->rec_ptr = d_pts;
+    ctx->rec_stride = stride;
+    ctx->rec_off[0] = ctx->in_off[0], ctx->rec_off[1] = ctx->in_off[1], ctx->rec_off[2] = ctx->in_off[2];
+    ctx->rec_pitch = ctx->upitch;
+    ctx->rec_direct = fused_gather;
+    {
+        StageTimer tm(ctx, ST_INGEST);
+        launch_ingest(ctx, n, d_pts, stride, nullptr, nullptr, nullptr, fused_gather ? (float4 *)nullptr : P4,
+                      (uint32_t *)ctx->key_a.p, (uint32_t *)nullptr, frame, nullptr, first_hist);  // (values: iota_vals)
+    }
+    LpxSortGather sg;
+    sg.records = fused_gather ? d_pts : (const void *)P4;
+    sg.x = XS, sg.y = YS, sg.z = ZS;
+    if (fused_gather)
+    {
+        sg.stride = stride;
+        sg.off[0] = ctx->in_off[0], sg.off[1] = ctx->in_off[1], sg.off[2] = ctx->in_off[2];
+        sg.pitch = ctx->upitch;
+    }
     uint32_t *skeys = nullptr, *sidx = nullptr;
     {
         StageTimer tm(ctx, ST_XSORT);
