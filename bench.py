@@ -867,6 +867,7 @@ def latency_of(plan, host_frames, lpx):
         one.cluster(pageable[oi], ccfg)
 
     two_ms = med(two_calls)
+    ws_lists = one.workspace_bytes() if hasattr(one, "workspace_bytes") else (0, 0)
     one.set_neighbour_mode("search")
     dev_search_ms = med(dev_call)
     one.close()
@@ -878,6 +879,8 @@ def latency_of(plan, host_frames, lpx):
             "dropin_what": "lpx_segment, host copy of the obstacle cloud, lpx_cluster: the two blocking calls of "
                            "the unchanged processor node (pageable memory)",
             "device_resident_ms_search_mode": round(dev_search_ms, 4),
+            "workspace_mb": {"frame_slot_arena": round(ws_lists[0] / 1e6, 1), "neighbour_lists": round(ws_lists[1] / 1e6, 1),
+                             "what": "device memory of the single-frame context in lists mode (lpx_workspace_bytes)"},
             "note": "single-frame contexts default to LPX_NEIGHBOURS_LISTS (shortest critical path); the "
                     "throughput figure uses LPX_NEIGHBOURS_SEARCH"}
 

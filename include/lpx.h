@@ -97,6 +97,9 @@ int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_per_point);
  * lists reserved by an upper bound of their length, which saves its counting pass.  It never changes what
  * fits: a kd group that finds no room there counts first and uses the lpx_reserve workspace.  0 disables. */
 int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point);
+/* Device memory the context holds right now, in bytes: bytes2[0] = the frame-slot arenas (~400 B per reserved point and
+ * slot), bytes2[1] = the neighbour-list arena of LPX_NEIGHBOURS_LISTS (0 until a call has used that mode). */
+int lpx_workspace_bytes(const lpx_ctx *ctx, uint64_t *bytes2);
 /* How Clusterer::cluster finds neighbours.  Both modes give the reference's labels; they trade latency for work.
  *   LPX_NEIGHBOURS_LISTS : every radius list is materialised by the whole device at once, then the greedy loop
  *                          replays over them: shortest critical path for ONE frame alone on the device, but ~30x

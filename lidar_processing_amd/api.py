@@ -280,6 +280,13 @@ class Context:
                                                             _vp(n), C.byref(sc), C.byref(cc), d_labels, d_ground_idx,
                                                             d_obstacle_idx, d_planes, d_cluster_labels, d_counts))
 
+    def workspace_bytes(self):
+        """lpx_workspace_bytes: (frame-slot arenas, neighbour-list arena) in bytes"""
+        o = np.zeros(2, np.uint64)
+        self._L.lpx_workspace_bytes.argtypes = [C.c_void_p, C.c_void_p]
+        self.check(self._L.lpx_workspace_bytes(self._h, _vp(o)))
+        return int(o[0]), int(o[1])
+
     def frame_stats(self, slot=0):
         """counters of the last frame processed in frame slot `slot` of this context (synchronises)"""
         o = np.zeros(12, np.uint32)

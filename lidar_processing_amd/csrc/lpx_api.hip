@@ -503,6 +503,17 @@ extern "C" const char *lpx_build_info(void)
     return info;
 }
 
+// device memory the context holds: out[0] = the slot arenas (every per-point buffer of every frame slot), out[1] = the
+// neighbour-list arena of the list mode (0 until a call has used it)
+extern "C" int lpx_workspace_bytes(const lpx_ctx *ctx, uint64_t *out2)
+{
+    if (!ctx || !out2)
+        return LPX_ERR_ARG;
+    out2[0] = ctx->arena ? (uint64_t)ctx->fstride * ctx->batch : 0;
+    out2[1] = ctx->nb_arena ? (uint64_t)ctx->nb_fstride * ctx->batch : 0;
+    return LPX_OK;
+}
+
 extern "C" int lpx_create(int device, lpx_ctx **out)
 {
     return create_common(device, nullptr, true, 1, out);

@@ -387,12 +387,17 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
 // those <= 8192 keys in LDS (bitonic) and sums them with one lane.  Same results as seed_kernel over the
 // sorted segment; replaces five radix-sort passes over all N points.
 // ------------------------------------------------------------------------------------------------
-constexpr int SEL_THREADS = 1024;  // (the kernel is written for exactly sixteen wavefronts: 512 threads fault)
-constexpr int SEL_PTS = 24;
-constexpr uint32_t SEL_MAX_POINTS = SEL_THREADS * SEL_PTS;  // 24576 points per segment
+constexpr int SEL_THREADS = 1024;  // a frame alone on the device: sixteen wavefronts, 24 keys per thread
+// In launch chains the same kernel runs with SEL_NARROW threads and 96 keys per thread: under load a 1024-thread workgroup
+// waits until ONE compute unit has sixteen free wave slots (seed_select_kernel: 0.20 ms alone, 3.0 ms with sixteen
+// chains in flight -- fifteen times, where the 256-thread kernels of a chain wait four to ten), a 256-thread workgroup
+// fits anywhere.
+constexpr int SEL_NARROW = 256;
+constexpr uint32_t SEL_MAX_POINTS = 24576;                 // points per segment: 24 (96) keys per thread
 constexpr uint32_t SEL_MAX_LPR = 8192;                     // keys sorted in LDS
-constexpr int SEL_BINS = 512;  // per wavefront; the 16 private histograms alias the sort buffer
+constexpr int SEL_BINS = 512;  // per wavefront; the private histograms alias the sort buffer
 
+template <int THREADS>
 __device__ __forceinline__ uint32_t sel_block_sum(uint32_t v, uint32_t *red, uint32_t tid)
 {
     v = lpx_wave_sum_u32(v);
@@ -401,38 +406,57 @@ __device__ __forceinline__ uint32_t sel_block_sum(uint32_t v, uint32_t *red, uin
     __syncthreads();
     uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < SEL_THREADS / WAVE; ++i)
+    for (int i = 0; i < THREADS / WAVE; ++i)
         s += red[i];
     __syncthreads();
     return s;
 }
 
-// the <= SEL_MAX_LPR keys in s_buf (padded with 0xffffffff to n_sort, a power of two), ascending; all SEL_THREADS threads
+// compare-exchanges between registers a and a + D of one thread (a holds the lower index of the pair), all T / 2 of them
+template <int T, int D>
+__device__ __forceinline__ void sel_ce_regs(uint32_t (&e)[T], uint32_t w, uint32_t lane, uint32_t k2)
+{
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+        if ((a & D) == 0)
+        {
+            const bool up = (((w * (T * WAVE) + a * WAVE + lane) & k2) == 0);
+            const uint32_t mn = min(e[a], e[a + D]), mx = max(e[a], e[a + D]);
+            e[a] = up ? mn : mx;
+            e[a + D] = up ? mx : mn;
+        }
+}
+
+// the <= SEL_MAX_LPR keys in s_buf (padded with 0xffffffff to n_sort, a power of two), ascending; all THREADS threads
+template <int THREADS>
 __device__ __forceinline__ void sel_bitonic_sort(uint32_t *s_buf, uint32_t n_sort, uint32_t tid)
 {
-    // Bitonic sort, ascending, of the 8 keys per thread i = 512 w + 64 t + lane.  A compare-exchange at
-    // distance j2 pairs: the same lane of another register (j2 = 64, 128, 256), another lane of the same
-    // register (j2 < 64, one cross-lane read) or another wavefront's block (j2 >= 512, through LDS with
-    // workgroup barriers: 10 of the 91 stages).
+    // Bitonic sort, ascending, of the T keys per thread i = 64 T w + 64 t + lane (T = 8 with sixteen wavefronts, 32 with
+    // four).  A compare-exchange at distance j2 pairs: the same lane of another register (64 <= j2 < 64 T), another lane
+    // of the same register (j2 < 64, one cross-lane read) or another wavefront's block (j2 >= 64 T, through LDS with
+    // workgroup barriers).
+    constexpr int T = (int)SEL_MAX_LPR / THREADS;
+    constexpr uint32_t WBLK = (uint32_t)T * WAVE;  // keys of one wavefront
+    static_assert(T == 8 || T == 32, "register stages are written for 8 or 32 keys per thread");
     const uint32_t w = tid / WAVE, lane = tid % WAVE;
-    uint32_t e[8];
+    uint32_t e[T];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-        e[t] = s_buf[w * 512 + t * WAVE + lane];
+    for (int t = 0; t < T; ++t)
+        e[t] = s_buf[w * WBLK + t * WAVE + lane];
     for (uint32_t k2 = 2; k2 <= n_sort; k2 <<= 1)
         for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1)
         {
-            if (j2 >= 512)
+            if (j2 >= WBLK)
             {
                 __syncthreads();
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    s_buf[w * 512 + t * WAVE + lane] = e[t];
+                for (int t = 0; t < T; ++t)
+                    s_buf[w * WBLK + t * WAVE + lane] = e[t];
                 __syncthreads();
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
+                for (int t = 0; t < T; ++t)
                 {
-                    const uint32_t i = w * 512 + t * WAVE + lane;
+                    const uint32_t i = w * WBLK + t * WAVE + lane;
                     const uint32_t pv = s_buf[(i ^ j2) & (SEL_MAX_LPR - 1)];
                     const bool keep_min = ((i & j2) == 0) == ((i & k2) == 0);
                     e[t] = keep_min ? min(e[t], pv) : max(e[t], pv);
@@ -440,34 +464,26 @@ __device__ __forceinline__ void sel_bitonic_sort(uint32_t *s_buf, uint32_t n_sor
             }
             else if (j2 >= (uint32_t)WAVE)
             {
-                // registers (a, b = a + j2 / 64) of one thread: a holds the lower index of the pair
-#define SEL_CE(a, b)                                                              \
-{                                                                             \
-    const bool up = (((w * 512 + (a) * WAVE + lane) & k2) == 0);              \
-    const uint32_t mn = min(e[a], e[b]), mx = max(e[a], e[b]);                \
-    e[a] = up ? mn : mx;                                                      \
-    e[b] = up ? mx : mn;                                                      \
-}
                 if (j2 == 64)
-                {
-                    SEL_CE(0, 1) SEL_CE(2, 3) SEL_CE(4, 5) SEL_CE(6, 7)
-                }
+                    sel_ce_regs<T, 1>(e, w, lane, k2);
                 else if (j2 == 128)
+                    sel_ce_regs<T, 2>(e, w, lane, k2);
+                else if (j2 == 256)
+                    sel_ce_regs<T, 4>(e, w, lane, k2);
+                else if (T > 8)
                 {
-                    SEL_CE(0, 2) SEL_CE(1, 3) SEL_CE(4, 6) SEL_CE(5, 7)
+                    if (j2 == 512)
+                        sel_ce_regs<T, (T > 8 ? 8 : 1)>(e, w, lane, k2);
+                    else
+                        sel_ce_regs<T, (T > 8 ? 16 : 1)>(e, w, lane, k2);
                 }
-                else
-                {
-                    SEL_CE(0, 4) SEL_CE(1, 5) SEL_CE(2, 6) SEL_CE(3, 7)
-                }
-#undef SEL_CE
             }
             else
             {
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
+                for (int t = 0; t < T; ++t)
                 {
-                    const uint32_t i = w * 512 + t * WAVE + lane;
+                    const uint32_t i = w * WBLK + t * WAVE + lane;
                     const uint32_t pv = (uint32_t)__shfl_xor((int)e[t], (int)j2, WAVE);
                     const bool keep_min = ((i & j2) == 0) == ((i & k2) == 0);
                     e[t] = keep_min ? min(e[t], pv) : max(e[t], pv);
@@ -476,8 +492,8 @@ __device__ __forceinline__ void sel_bitonic_sort(uint32_t *s_buf, uint32_t n_sor
         }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-        s_buf[w * 512 + t * WAVE + lane] = e[t];
+    for (int t = 0; t < T; ++t)
+        s_buf[w * WBLK + t * WAVE + lane] = e[t];
     __syncthreads();
 }
 
@@ -519,16 +535,20 @@ __device__ __forceinline__ float sel_sequential_zmax(const uint32_t *s_buf, uint
 // registers, x and y of the seeds are two more loads per point.  One launch less, 0.013 ms more per 64-frame chain alone,
 // and 2 % LESS throughput with sixteen chains in flight: this is a 1024-thread workgroup, the kind that waits longest
 // for a compute unit under load, and everything added to it is added to that wait.  Taken out again.)
-__global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *__restrict__ ZS, SegParams prm,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void seed_select_kernel(const float *__restrict__ ZS, SegParams prm,
                                                                    SegState *__restrict__ st,
                                                                    long long *__restrict__ facc,
                                                                    const FrameState *__restrict__ frame, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<2>(fs);
     __shared__ __attribute__((aligned(16))) uint32_t s_buf[SEL_MAX_LPR];
-    static_assert(SEL_BINS * (SEL_THREADS / WAVE) <= (int)SEL_MAX_LPR, "private histograms alias the sort buffer");
+    constexpr int SEL_PTS = (int)SEL_MAX_POINTS / THREADS;  // keys per thread, in registers
+    constexpr int NW = THREADS / WAVE;
+    static_assert(SEL_BINS * NW <= (int)SEL_MAX_LPR, "private histograms alias the sort buffer");
+    static_assert(SEL_BINS % THREADS == 0 || THREADS % SEL_BINS == 0, "bins per thread");
     uint32_t *s_hist = s_buf;  // [wavefront][bin] during the select, before the buffer is filled
-    __shared__ uint32_t s_red[SEL_THREADS / WAVE];
+    __shared__ uint32_t s_red[NW];
     __shared__ uint32_t s_pick[2];  // bin, count before the bin
     __shared__ uint32_t s_fill;
     __shared__ float s_zmax;
@@ -542,29 +562,24 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
     seg_far_reset(facc, s, tid);
 
     uint32_t key[SEL_PTS];
-    uint32_t vmask = 0;  // bit u: slot u holds a point of the segment
+    // (slot u of a thread holds a point of the segment iff tid + u THREADS < ns: recomputed where needed -- 96 slots per
+    // thread do not fit a 32-bit mask)
+#define SEL_VALID(u) (tid + (uint32_t)(u) * THREADS < ns)
 #pragma unroll
     for (int u = 0; u < SEL_PTS; ++u)
-    {
-        const uint32_t p = tid + u * SEL_THREADS;
-        const bool in = p < ns;
-        key[u] = in ? lpx_float_key(ZS[base + p]) : 0xffffffffu;
-        vmask |= (in ? 1u : 0u) << u;
-    }
+        key[u] = SEL_VALID(u) ? lpx_float_key(ZS[base + tid + u * THREADS]) : 0xffffffffu;
     // points at or below the floor are dropped, unless that leaves nothing (:171-182)
     const uint32_t floor_key = lpx_float_key(prm.z_floor);
     uint32_t c = 0;
 #pragma unroll
     for (int u = 0; u < SEL_PTS; ++u)
-        c += ((vmask >> u) & 1u) && key[u] <= floor_key;
-    const uint32_t c_floor = sel_block_sum(c, s_red, tid);
+        c += SEL_VALID(u) && key[u] <= floor_key;
+    const uint32_t c_floor = sel_block_sum<THREADS>(c, s_red, tid);
     const uint32_t cut = (c_floor < ns) ? c_floor : 0u;
     const uint32_t nrem = ns - cut;
     const uint32_t n_rep = min(nrem, prm.n_lpr);
-    uint32_t rmask = 0;  // bit u: slot u is in the remainder
-#pragma unroll
-    for (int u = 0; u < SEL_PTS; ++u)
-        rmask |= ((((vmask >> u) & 1u) && (cut == 0 || key[u] > floor_key)) ? 1u : 0u) << u;
+    // slot u is in the remainder:
+#define SEL_REM(u) (SEL_VALID(u) && (cut == 0 || key[u] > floor_key))
 
     // key K of rank n_rep (1-based) among the remainder, `need` = how many copies of K belong to the n_rep lowest
     uint32_t prefix = 0, pmask = 0, need = n_rep;
@@ -575,21 +590,28 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
-            for (uint32_t i = tid; i < SEL_BINS * (SEL_THREADS / WAVE); i += SEL_THREADS)
+            for (uint32_t i = tid; i < SEL_BINS * NW; i += THREADS)
                 s_hist[i] = 0;
             __syncthreads();
             const uint32_t dmask = (1u << bits[r]) - 1u;
 #pragma unroll
             for (int u = 0; u < SEL_PTS; ++u)
-                if (((rmask >> u) & 1u) && (key[u] & pmask) == prefix)
+                if (SEL_REM(u) && (key[u] & pmask) == prefix)
                     atomicAdd(&s_hist[wv * SEL_BINS + ((key[u] >> shifts[r]) & dmask)], 1u);
             __syncthreads();
-            // bin totals over the wavefronts (thread t < 512 owns bin t), then the first bin whose inclusive
-            // prefix count reaches `need`
-            uint32_t h = 0;
-            if (tid < (uint32_t)SEL_BINS)
-                for (int ww = 0; ww < SEL_THREADS / WAVE; ++ww)
-                    h += s_hist[ww * SEL_BINS + tid];
+            // bin totals over the wavefronts, then the first bin whose inclusive prefix count reaches `need`: thread t owns
+            // the BPT consecutive bins BPT t .. (one with 1024 threads -- the upper half idles --, two with 256)
+            constexpr int BPT = SEL_BINS > THREADS ? SEL_BINS / THREADS : 1;
+            uint32_t hb[BPT], h = 0;
+#pragma unroll
+            for (int q = 0; q < BPT; ++q)
+            {
+                hb[q] = 0;
+                if (tid * BPT + q < (uint32_t)SEL_BINS)
+                    for (int ww = 0; ww < NW; ++ww)
+                        hb[q] += s_hist[ww * SEL_BINS + tid * BPT + q];
+                h += hb[q];
+            }
             const uint32_t incl = lpx_wave_incl_scan_u32(h);
             if ((tid % WAVE) == WAVE - 1)
                 s_red[tid / WAVE] = incl;
@@ -597,11 +619,16 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
             uint32_t wbase = 0;
             for (uint32_t i = 0; i < tid / WAVE; ++i)
                 wbase += s_red[i];
-            const uint32_t before = wbase + incl - h;  // keys in bins < tid
-            if (tid < (uint32_t)SEL_BINS && before < need && need <= before + h)
+            uint32_t before = wbase + incl - h;  // keys in bins below this thread's first
+#pragma unroll
+            for (int q = 0; q < BPT; ++q)
             {
-                s_pick[0] = tid;
-                s_pick[1] = before;
+                if (tid * BPT + q < (uint32_t)SEL_BINS && before < need && need <= before + hb[q])
+                {
+                    s_pick[0] = tid * BPT + q;
+                    s_pick[1] = before;
+                }
+                before += hb[q];
             }
             __syncthreads();
             prefix |= s_pick[0] << shifts[r];
@@ -617,7 +644,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
         n_sort <<= 1;
     if (tid == 0)
         s_fill = 0;
-    for (uint32_t i = tid; i < SEL_MAX_LPR; i += SEL_THREADS)
+    for (uint32_t i = tid; i < SEL_MAX_LPR; i += THREADS)
         s_buf[i] = 0xffffffffu;
     __syncthreads();
     if (n_rep)
@@ -627,7 +654,7 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
 #pragma unroll
         for (int u = 0; u < SEL_PTS; ++u)
         {
-            const bool take = ((rmask >> u) & 1u) && key[u] < K;
+            const bool take = SEL_REM(u) && key[u] < K;
             const unsigned long long tm = __ballot(take);
             if (tm)
             {
@@ -641,12 +668,12 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
         }
         __syncthreads();
         const uint32_t below = s_fill;  // == n_rep - need
-        for (uint32_t i = tid; i < need; i += SEL_THREADS)
+        for (uint32_t i = tid; i < need; i += THREADS)
             s_buf[below + i] = K;
         __syncthreads();
-        sel_bitonic_sort(s_buf, n_sort, tid);
+        sel_bitonic_sort<THREADS>(s_buf, n_sort, tid);
         // keys -> float bits in place, so that the summing lane reads floats
-        for (uint32_t i = tid; i < n_sort; i += SEL_THREADS)
+        for (uint32_t i = tid; i < n_sort; i += THREADS)
             s_buf[i] = __float_as_uint(lpx_key_float(s_buf[i]));
     }
     __syncthreads();
@@ -658,8 +685,8 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
     c = 0;
 #pragma unroll
     for (int u = 0; u < SEL_PTS; ++u)
-        c += ((rmask >> u) & 1u) && !(lpx_key_float(key[u]) > z_max);
-    const uint32_t cnt_le = sel_block_sum(c, s_red, tid);
+        c += SEL_REM(u) && !(lpx_key_float(key[u]) > z_max);
+    const uint32_t cnt_le = sel_block_sum<THREADS>(c, s_red, tid);
     if (tid == 0)
     {
         const uint32_t n_seed = (cnt_le < nrem) ? cnt_le : 0u;
@@ -675,6 +702,8 @@ __global__ __launch_bounds__(SEL_THREADS) void seed_select_kernel(const float *_
         st[s] = o;
     }
 }
+#undef SEL_REM
+#undef SEL_VALID
 
 // ------------------------------------------------------------------------------------------------
 // The same selection for segments that do not fit one workgroup's registers (BASELINE's 1M- and 5M-point clouds hold
@@ -904,7 +933,7 @@ __global__ __launch_bounds__(SEL_THREADS) void selw_final_kernel(SegParams prm, 
     for (uint32_t i = tid; i < SEL_MAX_LPR; i += SEL_THREADS)
         s_buf[i] = i < below ? w->keys[i] : (i < n_rep ? K : 0xffffffffu);
     __syncthreads();
-    sel_bitonic_sort(s_buf, n_sort, tid);
+    sel_bitonic_sort<SEL_THREADS>(s_buf, n_sort, tid);
     // keys -> float bits in place, so that the summing lane reads floats
     for (uint32_t i = tid; i < n_sort; i += SEL_THREADS)
         s_buf[i] = __float_as_uint(lpx_key_float(s_buf[i]));
@@ -1427,6 +1456,9 @@ struct PassAcc
     }
 };
 
+// (Packed float32 arithmetic -- v_pk_mul_f32 / v_pk_add_f32 on pairs of points, bit-identical -- was built and measured:
+// 0.338 -> 0.376 ms per 32-frame 1M-point chain and -1.3 % under load; the packed forms are no faster per point here and
+// cost the moves that pair the operands.  Scalar it stays.)
 template <bool FINAL, bool SEED, bool EDGE>
 __device__ __forceinline__ void pass_quad_lean(const pass_v4f x4, const pass_v4f y4, const pass_v4f z4, uint32_t p0,
                                                const PassUniform &U, PassAcc &A, uint8_t *flags)
@@ -2076,6 +2108,10 @@ static void seg_geometry(SegParams &prm, uint32_t cap_n)
 {
     uint32_t chunk = SEG_CHUNK;
     const uint32_t quantum = 2u * PASS_TRIP;  // an even number of trips per block
+    // long segments (BASELINE's 1M- and 5M-point clouds: 83k / 208k points each): 8192-point blocks -- the plane passes
+    // run at the same rate, the compaction (same geometry: fewer per-block offset sums, longer runs per lane) 16 % faster
+    if (prm.n_per >= 65536u && chunk < 2u * SEG_CHUNK)
+        chunk = 2u * SEG_CHUNK;
     if (prm.n_per / 256u > chunk)
     {
         chunk = ((prm.n_per / 256u + quantum - 1) / quantum) * quantum;
@@ -2247,8 +2283,14 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     if (select_seeds)
     {
         StageTimer tm(ctx, ST_SEEDS);
-        hipLaunchKernelGGL(seed_select_kernel, dim3(P, 1, B), dim3(SEL_THREADS), 0, st, ZS, prm, sst, facc,
-                           (const FrameState *)frame, fv.fs);
+#ifndef LPX_SEED_WIDE_IN_CHAINS  // (A/B switch of tools/build_variant.sh)
+        if (B > 1)  // launch chains: the narrow form (a 1024-thread workgroup waits longest for a compute unit under load)
+            hipLaunchKernelGGL(seed_select_kernel<SEL_NARROW>, dim3(P, 1, B), dim3(SEL_NARROW), 0, st, ZS, prm, sst, facc,
+                               (const FrameState *)frame, fv.fs);
+        else
+#endif
+            hipLaunchKernelGGL(seed_select_kernel<SEL_THREADS>, dim3(P, 1, B), dim3(SEL_THREADS), 0, st, ZS, prm, sst, facc,
+                               (const FrameState *)frame, fv.fs);
     }
     else if (select_wide)
     {
