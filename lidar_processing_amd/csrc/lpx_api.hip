@@ -134,10 +134,10 @@ int lpx_ensure_capacity(lpx_ctx *ctx, uint32_t n, uint64_t nb)
             // expansion-driven search only (with_search)
             {&ctx->grp_of, with_search ? 4 * n4 : 0},   {&ctx->cell_of, with_search ? n4 : 0},
             {&ctx->chunks, with_search ? chunk_bytes : 0},
-            {&ctx->cell_key, with_search ? sizeof(uint64_t) * cell_cap : 0},
+            {&ctx->cell_key, with_search ? sizeof(uint64_t) * cell_cap + LPX_CELL_BITS_BYTES : 0},  // + the occupancy bitmap
             {&ctx->cell_rep, with_search ? sizeof(uint32_t) * cell_cap : 0},
             {&ctx->cell_parent, with_search ? sizeof(uint32_t) * cell_cap : 0},
-            {&ctx->cell_xyz, with_search ? sizeof(float4) * cell_cap : 0},
+            {&ctx->cell_xyz, with_search ? 3 * sizeof(float4) * cell_cap : 0},  // representative, box low, box high
             {&ctx->cell_start, with_search ? sizeof(uint32_t) * cell_cap : 0},
             {&ctx->cell_pts, with_search ? 4 * n4 : 0},
             {&ctx->cell_list, with_search ? n4 : 0},

@@ -109,6 +109,23 @@ static inline uint64_t lpx_entries_written(const FrameState &f)
     return s;
 }
 
+// Occupancy bitmap of the component grid: one bit per cell position modulo 2^XB x 2^YB x 32 (x, y, z) -- 8 KiB with 64 x 32 x 32, small
+// enough to sit in the LDS of every linking workgroup.  A set bit says "a cell with these low coordinate bits exists"
+// (cells that many positions apart alias: a false positive costs one probe of the table, nothing else); a clear bit
+// says the partner cell does not exist, without touching the table.  Word = (x mod 2^XB) << YB | (y mod 2^YB), bit = z & 31.
+#ifndef LPX_CELL_BITS_XB
+#define LPX_CELL_BITS_XB 6  // x positions modulo 2^XB
+#endif
+#ifndef LPX_CELL_BITS_YB
+#define LPX_CELL_BITS_YB 5  // y positions modulo 2^YB (z modulo 32: the bits of a word)
+#endif
+#define LPX_CELL_BITS_WORDS (1u << (LPX_CELL_BITS_XB + LPX_CELL_BITS_YB))
+#define LPX_CELL_BITS_BYTES (4u * LPX_CELL_BITS_WORDS)
+__host__ __device__ static inline uint32_t lpx_cell_bit_word(uint32_t cx, uint32_t cy)
+{
+    return ((cx & ((1u << LPX_CELL_BITS_XB) - 1u)) << LPX_CELL_BITS_YB) | (cy & ((1u << LPX_CELL_BITS_YB) - 1u));
+}
+
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)
 // blocks of a plane pass (and rows of seg_part / blk_counts) a cloud of n points can need at most: a segment's blocks
 // start on a multiple of four points (16-byte loads), which can add one block per segment
@@ -278,11 +295,12 @@ struct lpx_ctx
     Buf grp_of;                // float4 per point {x, y, z, kd group (bucket or upper node) the point is a query of}: what a
                                // queue window of the replay gathers per point, in ONE 16-byte record
     Buf chunks;                // ChunkRec [groups][LPX_GROUP_CHUNKS]: candidate chunks (pre-order rank, count, box) of a group
-    Buf cell_key;              // u64 [cell_cap]: occupied cells of the component grid (open addressing)
+    Buf cell_key;              // u64 [cell_cap]: occupied cells of the component grid (open addressing), then the
+                               // occupancy bitmap of the cells (LPX_CELL_BITS_BYTES, lpx_cell_bit)
     Buf cell_rep, cell_parent; // u32 [cell_cap]: points of the cell / union-find over cells
     Buf cell_start;            // u32 [cell_cap]: where the cell's points begin in the cell-ordered copy
     Buf cell_of;               // u32 per point: its cell slot
-    Buf cell_xyz;              // float4 [cell_cap]: the point that claimed the cell
+    Buf cell_xyz;              // float4 [3][cell_cap]: the point that claimed the cell; low / high corner of the box of its points
     Buf cell_pts;              // float4 per point: the cell-ordered copy of the cloud ({x, y, z, index} runs per cell)
     Buf cell_list;             // u32 per point: the occupied cells' table slots
     uint32_t cell_cap = 0;     // slots per frame slot (power of two >= 2 * cap_n)

@@ -2246,6 +2246,9 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
             tparent[sl] = sl;
             thead[sl] = 0;
         }
+        uint32_t *const bits = (uint32_t *)(tkey + cap_max);  // the occupancy bitmap behind the table
+        for (uint32_t i = lpx_blk.x * NB_THREADS + threadIdx.x; i < LPX_CELL_BITS_WORDS; i += gridDim.x * NB_THREADS)
+            bits[i] = 0;
         if (lpx_blk.x == 0 && threadIdx.x == 0)
         {
             wframe->n_cells = 0;
@@ -2593,6 +2596,8 @@ __global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long 
         frame->n_cells = 0;
         frame->cell_cursor = 0;
     }
+    if (s < LPX_CELL_BITS_WORDS)
+        ((uint32_t *)(tkey + cap_max))[s] = 0;  // the occupancy bitmap behind the table
     if (s >= cell_cap_for(frame->n_obstacle, cap_max) || frame->n_obstacle == 0)
         return;
     tkey[s] = CELL_EMPTY;
@@ -2725,6 +2730,9 @@ __global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__r
                 const uint32_t rep = lslot[s];
                 trep[h] = make_float4(OX[rep], OY[rep], OZ[rep], 0.0f);  // represents the cell in the quick test of the linking
                 lclaim[atomicAdd(&nclaim, 1u)] = h;
+                // ... and shows in the occupancy bitmap (one no-return atomic per CELL: lpx_cell_bit_word)
+                atomicOr((uint32_t *)(tkey + cap_max) + lpx_cell_bit_word((uint32_t)(key >> 42), (uint32_t)(key >> 21) & 0x1fffffu),
+                         1u << ((uint32_t)key & 31u));
                 break;
             }
             if (o == key)
@@ -2845,51 +2853,99 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
     const uint32_t mask = cell_cap_for(M, cap_max) - 1;
     constexpr uint32_t P = FAR ? 49u : 13u;
     const unsigned long long total = (unsigned long long)frame->n_cells * P;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    // U items per lane and trip.  An item is a chain of dependent loads (cell -> its key -> the partner's home slot ->
-    // representatives / roots), and at full occupancy this kernel's time scaled 1 : 1 with the wavefronts resident
-    // (measured with occupancy caps): it is bound by the latency of those chains, not by any throughput.  So every
-    // lane walks the first three links of U chains side by side -- U independent loads in flight per link -- and the
-    // representatives of the U partners likewise; only the rare tail (more probes, the union, a point-pair scan) stays
-    // one item at a time.
+    // Phase A / phase B.  Of a cell's 62 possible partners about ten exist, and finding that out used to cost every
+    // (cell, partner) item a hash and a scattered probe of the table -- 47 M probes per 64-frame chain, a quarter of the
+    // texture-addresser cycles and a seventh of the vector-ALU cycles a chain spends (profiles/r05_stream_cu_resources.json:
+    // the compute units, not the memory system, are what sixteen chains in flight saturate).  Now the workgroup holds the
+    // frame's occupancy bitmap in LDS (lpx_cell_bit_word: cell positions modulo 64 x 32 x 32, 8 KiB): phase A walks the
+    // items, asks the bitmap, and queues the few survivors -- (cell slot, partner key) -- densely in LDS; phase B hashes,
+    // probes and links only those, U per lane side by side as before.  A false positive of the bitmap (an aliased
+    // position) costs one probe that finds nothing; there are no false negatives (every claimed cell set its bit in
+    // grid_insert_kernel).  Which pairs are linked, and with them the components, do not change.
     constexpr int U = 4;
-    for (unsigned long long item0 = (unsigned long long)lpx_blk.x * blockDim.x + threadIdx.x; item0 < total;
-         item0 += U * stride)
+#ifndef LPX_PAIRS_QCAP
+#define LPX_PAIRS_QCAP 1024
+#endif
+    constexpr uint32_t QCAP = LPX_PAIRS_QCAP;  // survivors queued per round (12 bytes each)
+    __shared__ uint32_t s_bits[LPX_CELL_BITS_WORDS];
+    __shared__ unsigned long long q_key[QCAP];
+    __shared__ uint32_t q_slot[QCAP];
+    __shared__ uint32_t q_n;
     {
+        const uint4 *src = (const uint4 *)(tkey + cap_max);  // behind the table (16-byte aligned: cap_max is a power of two)
+        uint4 *dst = (uint4 *)s_bits;
+        for (uint32_t i = threadIdx.x; i < LPX_CELL_BITS_WORDS / 4; i += blockDim.x)
+            dst[i] = src[i];
+        if (threadIdx.x == 0)
+            q_n = 0;
+    }
+    __syncthreads();
+    const unsigned long long lt = lpx_lanemask_lt();
+    const uint32_t lane = threadIdx.x % WAVE;
+    const unsigned long long per_round = (unsigned long long)blockDim.x * (QCAP / 256u);  // items one round may queue at most
+    for (unsigned long long round0 = (unsigned long long)lpx_blk.x * per_round; round0 < total;
+         round0 += (unsigned long long)gridDim.x * per_round)
+    {
+        // ---- phase A: QCAP / 256 items per thread, consecutive lanes on consecutive items (49 / 13 items share a cell) ----
+#pragma unroll
+        for (uint32_t r = 0; r < QCAP / 256u; ++r)
+        {
+            const unsigned long long item = round0 + (unsigned long long)r * blockDim.x + threadIdx.x;
+            bool keep = item < total;
+            uint32_t slq = 0;
+            unsigned long long nkq = 0;
+            if (keep)
+            {
+                slq = cells[(uint32_t)(item / P)];
+                const unsigned long long key = tkey[slq];
+                const uint32_t j = (uint32_t)(item % P);
+                int dx, dy, dz;
+                if (FAR)
+                {
+                    const int t = FAR_T[j];
+                    dx = t / 25 - 2, dy = (t / 5) % 5 - 2, dz = t % 5 - 2;
+                }
+                else
+                {
+                    const int t = 14 + (int)j;  // the offsets of [-1, 1]^3 that follow (0, 0, 0) lexicographically
+                    dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
+                }
+                const int nx = (int)(key >> 42) + dx, ny = (int)((key >> 21) & 0x1fffffu) + dy,
+                          nz = (int)(key & 0x1fffffu) + dz;
+                keep = !((unsigned)nx > 0x1fffffu || (unsigned)ny > 0x1fffffu || (unsigned)nz > 0x1fffffu);
+                keep = keep && ((s_bits[lpx_cell_bit_word((uint32_t)nx, (uint32_t)ny)] >> ((uint32_t)nz & 31u)) & 1u);
+                nkq = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) | (unsigned long long)nz;
+            }
+            const unsigned long long km = __ballot(keep);
+            if (km)
+            {
+                uint32_t pos = 0;
+                if (lane == 0)
+                    pos = atomicAdd(&q_n, (uint32_t)__popcll(km));
+                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                if (keep)
+                {
+                    const uint32_t at = pos + __popcll(km & lt);
+                    q_slot[at] = slq;
+                    q_key[at] = nkq;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nq = q_n;
+        // ---- phase B: the survivors, U per lane side by side ----
+        for (uint32_t e0 = threadIdx.x; e0 < nq; e0 += U * blockDim.x)
+        {
         uint32_t sl[U], hh[U];
         unsigned long long nk[U], k2[U];
         bool live[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
         {
-            const unsigned long long item = item0 + u * stride;
-            live[u] = item < total;
-            sl[u] = live[u] ? cells[(uint32_t)(item / P)] : 0u;
-        }
-        unsigned long long key[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            key[u] = live[u] ? tkey[sl[u]] : 0ull;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-            const uint32_t j = (uint32_t)((item0 + u * stride) % P);
-            int dx, dy, dz;
-            if (FAR)
-            {
-                const int t = FAR_T[live[u] ? j : 0u];
-                dx = t / 25 - 2, dy = (t / 5) % 5 - 2, dz = t % 5 - 2;
-            }
-            else
-            {
-                const int t = 14 + (int)j;  // the offsets of [-1, 1]^3 that follow (0, 0, 0) lexicographically
-                dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
-            }
-            const int nx = (int)(key[u] >> 42) + dx, ny = (int)((key[u] >> 21) & 0x1fffffu) + dy,
-                      nz = (int)(key[u] & 0x1fffffu) + dz;
-            if ((unsigned)nx > 0x1fffffu || (unsigned)ny > 0x1fffffu || (unsigned)nz > 0x1fffffu)
-                live[u] = false;
-            nk[u] = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) | (unsigned long long)nz;
+            const uint32_t e = e0 + u * blockDim.x;
+            live[u] = e < nq;
+            sl[u] = live[u] ? q_slot[e] : 0u;
+            nk[u] = live[u] ? q_key[e] : 0ull;
             hh[u] = cell_hash(nk[u]) & mask;
         }
 #pragma unroll
@@ -2962,6 +3018,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
                 continue;
             if (!FAR && uf_find(tparent, sc) == uf_find(tparent, pc))
                 continue;  // united meanwhile through other pairs
+            if (FAR)
+            {
+                // the boxes of the two cells' points (grid_compress_kernel): when even the boxes are farther apart than d
+                // no pair can be within d -- the gaps are differences of coordinates that occur, float subtraction, squares
+                // of non-negative values and the sums below are monotonic, so the expression of EVERY pair is at least this
+                // one -- and the scan, all na x nb pairs with no hit to stop it, is skipped
+                const float4 la = trep[(size_t)cap_max + sc], ha = trep[2 * (size_t)cap_max + sc];
+                const float4 lb = trep[(size_t)cap_max + pc], hb = trep[2 * (size_t)cap_max + pc];
+                const float g0 = fmaxf(fmaxf(la.x - hb.x, lb.x - ha.x), 0.0f);
+                const float g1 = fmaxf(fmaxf(la.y - hb.y, lb.y - ha.y), 0.0f);
+                const float g2 = fmaxf(fmaxf(la.z - hb.z, lb.z - ha.z), 0.0f);
+                if (g0 * g0 + (g1 * g1 + g2 * g2) > r2)
+                    continue;
+            }
             // every point of the partner against every point of the cell, until the first pair within d.  Cells hold
             // 2.6 points on average: PS points of either run are requested TOGETHER and the pairs are tested from
             // registers, longer runs go on in steps of PS -- the plain double loop (PS = 1) is a chain of na x nb
@@ -3001,22 +3071,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
             if (joined)
                 uf_unite(tparent, sc, pc);
         }
+        }  // phase B
+        __syncthreads();  // everybody is through with the queue
+        if (threadIdx.x == 0)
+            q_n = 0;
+        __syncthreads();
     }
 }
 
 // between the two linking passes: every cell points straight at its root, so that the far pass recognises pairs of
 // one set with one load per side
 __global__ void grid_compress_kernel(const FrameState *__restrict__ frame, const uint32_t *__restrict__ cells,
-                                     uint32_t *tparent, size_t fs)
+                                     uint32_t *tparent, const uint32_t *__restrict__ tcount,
+                                     const uint32_t *__restrict__ tstart, const float4 *__restrict__ cpts,
+                                     float4 *__restrict__ trep, uint32_t cap_max, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<6>(fs);
     frame = lpx_slot(frame, fs);
     cells = lpx_slot(cells, fs);
     tparent = lpx_slot(tparent, fs);
+    tcount = lpx_slot(tcount, fs);
+    tstart = lpx_slot(tstart, fs);
+    cpts = lpx_slot(cpts, fs);
+    trep = lpx_slot(trep, fs);
     const uint32_t c = lpx_blk.x * blockDim.x + threadIdx.x;
     if (c >= frame->n_cells)
         return;
     const uint32_t s = cells[c];
+    // The bounding box of the cell's points (behind the representatives: trep[cap_max + slot], trep[2 cap_max + slot]):
+    // the far pass scans the points of two cells only when their boxes are within d.  A cell with many points (a dense
+    // surface near the sensor) gets an unbounded box -- it is never skipped -- instead of a long loop in one lane.
+    {
+        const uint32_t n = tcount[s];
+        const float4 *P = cpts + tstart[s];
+        float4 lo = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f), hi = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+        if (n <= 16u)
+        {
+            lo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                const float4 p = P[i];
+                lo.x = fminf(lo.x, p.x), lo.y = fminf(lo.y, p.y), lo.z = fminf(lo.z, p.z);
+                hi.x = fmaxf(hi.x, p.x), hi.y = fmaxf(hi.y, p.y), hi.z = fmaxf(hi.z, p.z);
+            }
+        }
+        trep[(size_t)cap_max + s] = lo;
+        trep[2 * (size_t)cap_max + s] = hi;
+    }
     uint32_t x = s, p = uf_ld(tparent + x);
     while (p != x)
     {
@@ -3347,7 +3448,8 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     uint32_t cap = 64;
     while (cap < 2 * m_max && cap < ctx->cell_cap)
         cap <<= 1;
-    const dim3 blk(256), gc((cap + 255) / 256, 1, ctx->cur_b), gm((m_max + 255) / 256, 1, ctx->cur_b);
+    const dim3 blk(256), gc(((cap > LPX_CELL_BITS_WORDS ? cap : LPX_CELL_BITS_WORDS) + 255) / 256, 1, ctx->cur_b),
+        gm((m_max + 255) / 256, 1, ctx->cur_b);
     unsigned long long *tkey = (unsigned long long *)ctx->cell_key.p;
     uint32_t *tparent = (uint32_t *)ctx->cell_parent.p, *thead = (uint32_t *)ctx->cell_rep.p;
     // (nothing here touches a buffer of the kd build or of the chunk tables: a forked front end runs them side by side)
@@ -3388,7 +3490,8 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
         static const int gp_dbg = LPX_KNOB("LPX_GP_DBG") ? atoi(LPX_KNOB("LPX_GP_DBG")) : 0;  // timing experiments only
         hipLaunchKernelGGL(grid_pairs_kernel<false>, dim3(pg0, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
         hipLaunchKernelGGL(grid_compress_kernel, gm, blk, 0, ctx->stream, (const FrameState *)frame, (const uint32_t *)cells,
-                           tparent, ctx->fs_tag);
+                           tparent, (const uint32_t *)thead, (const uint32_t *)tstart, (const float4 *)cpts,
+                           (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fs_tag);
         hipLaunchKernelGGL(grid_pairs_kernel<true>, dim3(pg1, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
 #undef GP_ARGS
     }
