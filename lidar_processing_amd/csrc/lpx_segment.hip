@@ -49,6 +49,8 @@ struct SegParams
     float odt;         // orthogonal_distance_threshold
     uint32_t n_lpr;
     uint32_t part_stride;  // int64 words between the two sets of moment partials (seg_part)
+    uint32_t head_solve;   // plane passes: every block solves at its head (launches that are resident all at once) instead
+                           // of the last block of a segment at its tail (plane_pass_kernel)
 };
 
 // per-frame sizes: the launch geometry (bps) comes from the largest frame of the call, the ranges
@@ -1519,6 +1521,69 @@ __device__ __forceinline__ void pass_quad_lean(const pass_v4f x4, const pass_v4f
     }
 }
 
+// S_{t+1} from S_t and the rows of pass t (one wavefront, every lane the same result): the rows of the segment summed
+// (integer sums: order-independent), the 3x3 problem solved -- nine lanes for the nine double-precision quotients, the
+// bit-exact Jacobi once.  Out of line: called at the tail of a pass by the block that arrives last, or at the head of
+// the next pass by every block (PassParams::head_solve); its ~100 registers of 128-bit arithmetic stay out of the
+// allocation of the streaming loop.  Rows are read past the caches (agent scope): in the tail form other blocks of the
+// same launch have just written them.
+__device__ __noinline__ void pass_solve(const long long *rows, uint32_t bps, const SegState *prev, const long long *fa,
+                                        uint32_t any_far, float odt, uint32_t lane, SegState *out)
+{
+    const uint32_t row = lane >> 4, word = lane & 15u;
+    long long tot = 0;
+    for (uint32_t r0 = 0; r0 < bps; r0 += 32)
+    {
+        long long q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+        {
+            const uint32_t r = r0 + row + 4u * k;
+            q[k] = r < bps ? __hip_atomic_load(rows + (size_t)r * LPX_ACC_WORDS + word, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)
+                           : 0ll;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            tot += q[k];
+    }
+    tot += __shfl_xor(tot, 16, WAVE);
+    tot += __shfl_xor(tot, 32, WAVE);  // every lane: the segment's total of word lane & 15
+    SegState o = *prev;  // sticky flags carry over
+    o.pad[0] = 0;        // a fresh ticket counter
+    if (o.failed == 0)
+    {
+        float plane[4];
+        bool ok;
+        if (any_far)
+        {
+            // rare (a coordinate beyond +-2048 m): the far-point limbs join the sums; the plain evaluation
+            long long m[LPX_ACC_WORDS], fm[LPX_FAR_WORDS];
+#pragma unroll
+            for (int i = 0; i < LPX_ACC_WORDS; ++i)
+                m[i] = __shfl(tot, i, WAVE);
+            for (int i = 0; i < LPX_FAR_WORDS; ++i)  // (accumulated by memory-side atomics of every block)
+                fm[i] = __hip_atomic_load(fa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = plane_from_moments(m, fm, plane);
+        }
+        else
+            ok = plane_from_moment_lanes(tot, lane, plane);
+        // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
+        if (!ok)
+            o.failed = 1;
+        else
+        {
+            o.plane[0] = plane[0];
+            o.plane[1] = plane[1];
+            o.plane[2] = plane[2];
+            o.plane[3] = plane[3];
+            o.thr = odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
+            o.fitted = 1;
+        }
+    }
+    *out = o;
+}
+
 template <bool FINAL>
 __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_kernel(const float *__restrict__ XS,
                                                                    const float *__restrict__ YS,
@@ -1569,7 +1634,25 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
 
     // ---- the state this pass tests against: S_t, set t & 1 of seg_state -- the seed window (t == 0, from the seed
     // selection) or plane t - 1, which the LAST block of pass t - 1 to finish its segment solved and published (tail below)
-    const SegState sst = st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s];
+    // Tail form (launches of more blocks than the device holds at once: early segments solve while later ones stream):
+    // read it.  Head form (launches that are resident all at once -- a frame alone, a chain of 120k-point frames: there
+    // every segment finishes together and a solve at the tail is ~10 us that nothing overlaps): every block computes S_t
+    // itself from S_{t-1} and the rows of pass t - 1, identically, and block 0 publishes it for the compaction's planes.
+    SegState sst;
+    if (prm.head_solve && t > 0)
+    {
+        const SegState prev = st[(size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS + s];
+        pass_solve(part + (size_t)((t + 1u) & 1u) * prm.part_stride + (size_t)s * prm.bps * LPX_ACC_WORDS, prm.bps, &prev,
+                   facc + ((size_t)((t - 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS, any_far ? 1u : 0u, prm.odt,
+                   lane, &sst);
+        if (b == 0 && lane == 0)
+            st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s] = sst;
+        // the far set pass t + 1 accumulates into was read by pass t - 1 and is free
+        if (any_far && b == 0 && lane < LPX_FAR_WORDS)
+            facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
+    }
+    else
+        sst = st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s];
     const bool skip = sst.failed == 2;       // < 3 points: nothing labelled
     const bool dead = sst.failed != 0;       // all obstacle
     const float pa = sst.plane[0], pb = sst.plane[1], pc = sst.plane[2], pd = sst.plane[3];
@@ -1707,6 +1790,8 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
     long long *rows = part + (size_t)(t & 1u) * prm.part_stride + (size_t)s * prm.bps * LPX_ACC_WORDS;
     if (lane < LPX_ACC_WORDS)
         __hip_atomic_store(rows + (size_t)b * LPX_ACC_WORDS + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prm.head_solve)
+        return;  // (the next launch reads the rows: every block of it solves at its head)
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row has left for memory
     SegState *const cur = st + (size_t)(t & 1u) * LPX_MAX_PARTITIONS + s;
     uint32_t ticket = 0;
@@ -1716,64 +1801,13 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
     if (ticket != prm.bps - 1u)
         return;
     // the last block of the segment: every row is in memory
-    {
-        const uint32_t row = lane >> 4, word = lane & 15u;
-        long long tot = 0;
-        for (uint32_t r0 = 0; r0 < prm.bps; r0 += 32)
-        {
-            long long q[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-            {
-                const uint32_t r = r0 + row + 4u * k;
-                q[k] = r < prm.bps ? __hip_atomic_load(rows + (size_t)r * LPX_ACC_WORDS + word, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT)
-                                   : 0ll;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                tot += q[k];
-        }
-        tot += __shfl_xor(tot, 16, WAVE);
-        tot += __shfl_xor(tot, 32, WAVE);  // every lane: the segment's total of word lane & 15
-        SegState o = sst;  // sticky flags carry over
-        o.pad[0] = 0;      // S_{t+1} starts with a fresh ticket counter
-        if (o.failed == 0)
-        {
-            float plane[4];
-            bool ok;
-            if (any_far)
-            {
-                // rare (a coordinate beyond +-2048 m): the far-point limbs join the sums; the plain evaluation
-                long long m[LPX_ACC_WORDS], fm[LPX_FAR_WORDS];
-#pragma unroll
-                for (int i = 0; i < LPX_ACC_WORDS; ++i)
-                    m[i] = __shfl(tot, i, WAVE);
-                for (int i = 0; i < LPX_FAR_WORDS; ++i)  // (accumulated by memory-side atomics of every block)
-                    fm[i] = __hip_atomic_load(fa + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = plane_from_moments(m, fm, plane);
-            }
-            else
-                ok = plane_from_moment_lanes(tot, lane, plane);
-            // fewer than 3 ground points or a failed solve: everything is an obstacle (:251-259, :275-283)
-            if (!ok)
-                o.failed = 1;
-            else
-            {
-                o.plane[0] = plane[0];
-                o.plane[1] = plane[1];
-                o.plane[2] = plane[2];
-                o.plane[3] = plane[3];
-                o.thr = prm.odt * sqrtf((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
-                o.fitted = 1;
-            }
-        }
-        if (lane == 0)
-            st[(size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS + s] = o;  // what pass t + 1 tests against; the compaction's planes
-        // the far set pass t + 1 accumulates into was read at the end of pass t - 2 and is free
-        if (any_far && lane < LPX_FAR_WORDS)
-            facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
-    }
+    SegState o;
+    pass_solve(rows, prm.bps, &sst, fa, any_far ? 1u : 0u, prm.odt, lane, &o);
+    if (lane == 0)
+        st[(size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS + s] = o;  // what pass t + 1 tests against; the compaction's planes
+    // the far set pass t + 1 accumulates into was read at the end of pass t - 2 and is free
+    if (any_far && lane < LPX_FAR_WORDS)
+        facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2121,6 +2155,18 @@ static void seg_geometry(SegParams &prm, uint32_t cap_n)
     prm.chunk = chunk;
     prm.bps = prm.n_per ? (prm.n_per + 3u + chunk - 1) / chunk : 1;
     prm.part_stride = (uint32_t)(LPX_SEG_MAX_BLOCKS(cap_n) * LPX_ACC_WORDS);
+    prm.head_solve = 1;  // (lpx_pass_form decides per launch)
+}
+
+// Where the 3x3 solve of a plane pass runs (plane_pass_kernel): at the head of every block when the blocks of a launch
+// are resident all at once (three one-wavefront blocks per SIMD: 3072), at the tail of the last block of a segment
+// otherwise.  LPX_PASS_SOLVE=head|tail (development build) forces one form: the tests run both against the oracle.
+static uint32_t lpx_pass_form(uint32_t blocks_of_a_launch)
+{
+    static const char *e = LPX_KNOB("LPX_PASS_SOLVE");
+    if (e)
+        return strcmp(e, "tail") == 0 ? 0u : 1u;
+    return blocks_of_a_launch <= 3072u ? 1u : 0u;
 }
 
 int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
@@ -2132,6 +2178,7 @@ int lpx_dbg_plane_run(lpx_ctx *ctx, const void *d_pts, uint32_t n, float *d_out)
     prm.P = 1;
     prm.I = 1;
     seg_geometry(prm, ctx->cap_n);
+    prm.head_solve = lpx_pass_form(prm.bps);
     prm.z_floor = 0.0f;
     prm.seed_thr = 0.0f;
     prm.odt = 0.0f;
@@ -2333,6 +2380,7 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         // against 0.095 ms for the six launches of a 123k-point frame.  Removed.)
         {
             const dim3 g2(prm.bps, P, B);
+            prm.head_solve = lpx_pass_form(prm.bps * P * B);
             for (uint32_t t = 0; t < I; ++t)
                 hipLaunchKernelGGL((plane_pass_kernel<false>), g2, dim3(PASS_THREADS), 0, st, XS, YS, ZS, prm, t, sst, part,
                                    facc, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fv.fs);

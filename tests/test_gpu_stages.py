@@ -164,3 +164,22 @@ def test_plane_bit_exact(ctx, n):
     assert rc == rc2 == 0
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (got, want)
     assert got[2] > 0.99
+
+
+@pytest.mark.parametrize("form", ["head", "tail"])
+def test_plane_solve_at_the_head_and_at_the_tail_agree_with_the_oracle(form):
+    """plane_pass_kernel solves the 3x3 problem of a pass either at the head of every block (launches resident all at
+    once) or once per segment at the tail of the block that draws the segment's last ticket (larger launches); the
+    development library's LPX_PASS_SOLVE forces one form for every launch, and either must give the oracle's labels,
+    index lists and plane words bit for bit -- frames alone, ragged batches in both neighbour modes, far points, 0 to 5
+    iterations, 200 segments (tests/solve_form_check.py, its own process: the knob is read once)"""
+    import os
+    import subprocess
+    import sys
+    from lidar_processing_amd import _lib
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, LPX_PASS_SOLVE=form, LPX_LIB=_lib.DEV_LIB_PATH,
+               PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(here, "solve_form_check.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and f"solve form check ok: {form}" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
