@@ -2871,15 +2871,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
     __shared__ unsigned long long q_key[QCAP];
     __shared__ uint32_t q_slot[QCAP];
     __shared__ uint32_t q_n;
+    constexpr uint32_t CCAP = 256;  // pairs queued for the slow tail (phase C)
+    __shared__ uint32_t c_a[CCAP], c_b[CCAP];
+    __shared__ uint32_t c_n;
     {
         const uint4 *src = (const uint4 *)(tkey + cap_max);  // behind the table (16-byte aligned: cap_max is a power of two)
         uint4 *dst = (uint4 *)s_bits;
         for (uint32_t i = threadIdx.x; i < LPX_CELL_BITS_WORDS / 4; i += blockDim.x)
             dst[i] = src[i];
         if (threadIdx.x == 0)
-            q_n = 0;
+            q_n = c_n = 0;
     }
     __syncthreads();
+    // The slow tail of an item -- the pair's representatives are farther apart than d: (far pass) the boxes of the two
+    // cells, then every point of one against every point of the other -- is needed by about one existing pair in forty,
+    // but a wavefront that holds ONE such item walks its dependent loads (boxes, run bounds, points) while the other 63
+    // lanes wait, and nearly every wavefront of every round held one: the far pass spent more time there than on all
+    // its probes.  Phase B now only QUEUES such pairs (c_a / c_b, a few hundred per workgroup); phase C, once after the
+    // last round, walks them with every lane busy -- and finds many of them united meanwhile.
+    auto slow_pair = [&](uint32_t sc, uint32_t pc) {
+        if (dbg == 3)
+            return;
+        if (uf_find(tparent, sc) == uf_find(tparent, pc))
+            return;  // united meanwhile through other pairs
+        if (FAR)
+        {
+            // the boxes of the two cells' points (grid_compress_kernel): when even the boxes are farther apart than d
+            // no pair can be within d -- the gaps are differences of coordinates that occur, float subtraction, squares
+            // of non-negative values and the sums below are monotonic, so the expression of EVERY pair is at least this
+            // one -- and the scan, all na x nb pairs with no hit to stop it, is skipped
+            const float4 la = trep[(size_t)cap_max + sc], ha = trep[2 * (size_t)cap_max + sc];
+            const float4 lb = trep[(size_t)cap_max + pc], hb = trep[2 * (size_t)cap_max + pc];
+            const float g0 = fmaxf(fmaxf(la.x - hb.x, lb.x - ha.x), 0.0f);
+            const float g1 = fmaxf(fmaxf(la.y - hb.y, lb.y - ha.y), 0.0f);
+            const float g2 = fmaxf(fmaxf(la.z - hb.z, lb.z - ha.z), 0.0f);
+            if (g0 * g0 + (g1 * g1 + g2 * g2) > r2)
+                return;
+        }
+        // every point of the partner against every point of the cell, until the first pair within d.  Cells hold
+        // 2.6 points on average: PS points of either run are requested TOGETHER and the pairs are tested from
+        // registers, longer runs go on in steps of PS -- the plain double loop (PS = 1) is a chain of na x nb
+        // dependent 16-byte loads in one lane while the other 63 lanes of the wavefront wait.  Measured on one box,
+        // 16 x 64 KITTI frames in flight / the two linking kernels of a chain alone: PS 1 2000-2014 Mpts/s / 1.65 ms;
+        // PS 2 1996-2012 / 1.53; PS 3 1978 / 1.47; PS 6 1879-1899 / 1.62 -- the wider scans are faster alone and
+        // SLOWER under load (every scanning lane requests 2 PS records whatever its runs hold, and with twenty chains
+        // in flight the memory pipeline is what the kernels queue for), so: two.
+#ifdef LPX_PAIR_SCAN_PS
+        constexpr uint32_t PS = LPX_PAIR_SCAN_PS;
+#else
+        constexpr uint32_t PS = 2;
+#endif
+        bool joined = false;
+        const float4 *A = cpts + tstart[sc], *B = cpts + tstart[pc];
+        const uint32_t na = tcount[sc], nb = tcount[pc];
+        for (uint32_t b0 = 0; b0 < nb && !joined; b0 += PS)
+            for (uint32_t a0 = 0; a0 < na && !joined; a0 += PS)
+            {
+                float4 pa[PS], pb[PS];
+#pragma unroll
+                for (uint32_t i = 0; i < PS; ++i)
+                {
+                    pa[i] = A[min(a0 + i, na - 1)];
+                    pb[i] = B[min(b0 + i, nb - 1)];
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < PS; ++j)
+#pragma unroll
+                    for (uint32_t i = 0; i < PS; ++i)
+                    {
+                        const float d0 = pa[i].x - pb[j].x, d1 = pa[i].y - pb[j].y, d2 = pa[i].z - pb[j].z;
+                        // dist_sqr, src/kdtree.hpp:145-157, inclusive :315 (a clamped index repeats a point of the run)
+                        joined = joined || (d0 * d0 + (d1 * d1 + d2 * d2) <= r2);
+                    }
+            }
+        if (joined)
+            uf_unite(tparent, sc, pc);
+    };
     const unsigned long long lt = lpx_lanemask_lt();
     const uint32_t lane = threadIdx.x % WAVE;
     const unsigned long long per_round = (unsigned long long)blockDim.x * (QCAP / 256u);  // items one round may queue at most
@@ -3016,66 +3083,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
             }
             if (dbg == 3)
                 continue;
-            if (!FAR && uf_find(tparent, sc) == uf_find(tparent, pc))
-                continue;  // united meanwhile through other pairs
-            if (FAR)
             {
-                // the boxes of the two cells' points (grid_compress_kernel): when even the boxes are farther apart than d
-                // no pair can be within d -- the gaps are differences of coordinates that occur, float subtraction, squares
-                // of non-negative values and the sums below are monotonic, so the expression of EVERY pair is at least this
-                // one -- and the scan, all na x nb pairs with no hit to stop it, is skipped
-                const float4 la = trep[(size_t)cap_max + sc], ha = trep[2 * (size_t)cap_max + sc];
-                const float4 lb = trep[(size_t)cap_max + pc], hb = trep[2 * (size_t)cap_max + pc];
-                const float g0 = fmaxf(fmaxf(la.x - hb.x, lb.x - ha.x), 0.0f);
-                const float g1 = fmaxf(fmaxf(la.y - hb.y, lb.y - ha.y), 0.0f);
-                const float g2 = fmaxf(fmaxf(la.z - hb.z, lb.z - ha.z), 0.0f);
-                if (g0 * g0 + (g1 * g1 + g2 * g2) > r2)
-                    continue;
-            }
-            // every point of the partner against every point of the cell, until the first pair within d.  Cells hold
-            // 2.6 points on average: PS points of either run are requested TOGETHER and the pairs are tested from
-            // registers, longer runs go on in steps of PS -- the plain double loop (PS = 1) is a chain of na x nb
-            // dependent 16-byte loads in one lane while the other 63 lanes of the wavefront wait.  Measured on one box,
-            // 16 x 64 KITTI frames in flight / the two linking kernels of a chain alone: PS 1 2000-2014 Mpts/s / 1.65 ms;
-            // PS 2 1996-2012 / 1.53; PS 3 1978 / 1.47; PS 6 1879-1899 / 1.62 -- the wider scans are faster alone and
-            // SLOWER under load (every scanning lane requests 2 PS records whatever its runs hold, and with twenty chains
-            // in flight the memory pipeline is what the kernels queue for), so: two.
-#ifdef LPX_PAIR_SCAN_PS
-            constexpr uint32_t PS = LPX_PAIR_SCAN_PS;
-#else
-            constexpr uint32_t PS = 2;
-#endif
-            bool joined = false;
-            const float4 *A = cpts + tstart[sc], *B = cpts + tstart[pc];
-            const uint32_t na = tcount[sc], nb = tcount[pc];
-            for (uint32_t b0 = 0; b0 < nb && !joined; b0 += PS)
-                for (uint32_t a0 = 0; a0 < na && !joined; a0 += PS)
+                const uint32_t at = atomicAdd(&c_n, 1u);
+                if (at < CCAP)
                 {
-                    float4 pa[PS], pb[PS];
-#pragma unroll
-                    for (uint32_t i = 0; i < PS; ++i)
-                    {
-                        pa[i] = A[min(a0 + i, na - 1)];
-                        pb[i] = B[min(b0 + i, nb - 1)];
-                    }
-#pragma unroll
-                    for (uint32_t j = 0; j < PS; ++j)
-#pragma unroll
-                        for (uint32_t i = 0; i < PS; ++i)
-                        {
-                            const float d0 = pa[i].x - pb[j].x, d1 = pa[i].y - pb[j].y, d2 = pa[i].z - pb[j].z;
-                            // dist_sqr, src/kdtree.hpp:145-157, inclusive :315 (a clamped index repeats a point of the run)
-                            joined = joined || (d0 * d0 + (d1 * d1 + d2 * d2) <= r2);
-                        }
+                    c_a[at] = sc;
+                    c_b[at] = pc;
                 }
-            if (joined)
-                uf_unite(tparent, sc, pc);
+                else
+                    slow_pair(sc, pc);  // (the queue is full: rare, done on the spot)
+            }
         }
         }  // phase B
         __syncthreads();  // everybody is through with the queue
         if (threadIdx.x == 0)
             q_n = 0;
         __syncthreads();
+    }
+    // ---- phase C: the queued slow pairs ----
+    __syncthreads();
+    {
+        const uint32_t nc = c_n < CCAP ? c_n : CCAP;
+        for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x)
+            slow_pair(c_a[i], c_b[i]);
     }
 }
 
