@@ -2852,7 +2852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
         return;
     const uint32_t mask = cell_cap_for(M, cap_max) - 1;
     constexpr uint32_t P = FAR ? 49u : 13u;
-    const unsigned long long total = (unsigned long long)frame->n_cells * P;
+    const uint32_t total = frame->n_cells * P;  // (fewer than 2^30 obstacle points: 32-bit item arithmetic)
     // Phase A / phase B.  Of a cell's 62 possible partners about ten exist, and finding that out used to cost every
     // (cell, partner) item a hash and a scattered probe of the table -- 47 M probes per 64-frame chain, a quarter of the
     // texture-addresser cycles and a seventh of the vector-ALU cycles a chain spends (profiles/r05_stream_cu_resources.json:
@@ -2949,23 +2949,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
     };
     const unsigned long long lt = lpx_lanemask_lt();
     const uint32_t lane = threadIdx.x % WAVE;
-    const unsigned long long per_round = (unsigned long long)blockDim.x * (QCAP / 256u);  // items one round may queue at most
-    for (unsigned long long round0 = (unsigned long long)lpx_blk.x * per_round; round0 < total;
-         round0 += (unsigned long long)gridDim.x * per_round)
+    const uint32_t per_round = blockDim.x * (QCAP / 256u);  // items one round may queue at most
+    for (unsigned long long round64 = (unsigned long long)lpx_blk.x * per_round; round64 < total;
+         round64 += (unsigned long long)gridDim.x * per_round)
     {
+        const uint32_t round0 = (uint32_t)round64;
         // ---- phase A: QCAP / 256 items per thread, consecutive lanes on consecutive items (49 / 13 items share a cell) ----
 #pragma unroll
         for (uint32_t r = 0; r < QCAP / 256u; ++r)
         {
-            const unsigned long long item = round0 + (unsigned long long)r * blockDim.x + threadIdx.x;
+            const uint32_t item = round0 + r * blockDim.x + threadIdx.x;  // (below total + per_round: no wrap)
             bool keep = item < total;
             uint32_t slq = 0;
             unsigned long long nkq = 0;
             if (keep)
             {
-                slq = cells[(uint32_t)(item / P)];
+                const uint32_t ci = item / P;
+                slq = cells[ci];
                 const unsigned long long key = tkey[slq];
-                const uint32_t j = (uint32_t)(item % P);
+                const uint32_t j = item - ci * P;
                 int dx, dy, dz;
                 if (FAR)
                 {
