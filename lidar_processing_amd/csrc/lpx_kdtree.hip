@@ -2896,6 +2896,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
             return;  // united meanwhile through other pairs
         if (FAR)
         {
+            // (the far pass queues a pair as soon as its two cells have different roots: the quick test is made here)
+            const float4 qa = trep[sc], qb = trep[pc];
+            const float e0 = qa.x - qb.x, e1 = qa.y - qb.y, e2 = qa.z - qb.z;
+            if (e0 * e0 + (e1 * e1 + e2 * e2) <= r2)
+            {
+                if (dbg != 2)
+                    uf_unite(tparent, sc, pc);
+                return;
+            }
+        }
+        if (FAR)
+        {
             // the boxes of the two cells' points (grid_compress_kernel): when even the boxes are farther apart than d
             // no pair can be within d -- the gaps are differences of coordinates that occur, float subtraction, squares
             // of non-negative values and the sums below are monotonic, so the expression of EVERY pair is at least this
@@ -3052,10 +3064,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
                 pa[u] = partner[u] != CELL_NONE ? uf_ld(tparent + sl[u]) : 0u;
                 pb[u] = partner[u] != CELL_NONE ? uf_ld(tparent + partner[u]) : 0u;
             }
+            // ... and everything else of such a pair -- one existing partner in forty -- belongs to phase C: queued
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (partner[u] != CELL_NONE && pa[u] == pb[u])
-                    partner[u] = CELL_NONE;
+                if (partner[u] != CELL_NONE && pa[u] != pb[u])
+                {
+                    const uint32_t at = atomicAdd(&c_n, 1u);
+                    if (at < CCAP)
+                    {
+                        c_a[at] = sl[u];
+                        c_b[at] = partner[u];
+                    }
+                    else
+                        slow_pair(sl[u], partner[u]);  // (the queue is full: rare, done on the spot)
+                }
+            continue;
         }
         // quick test: the point that claimed the cell against the one that claimed the partner
         float4 ra[U], rb[U];
