@@ -2619,9 +2619,14 @@ __global__ void grid_clear_kernel(FrameState *__restrict__ frame, unsigned long 
 // input: an unsorted cloud (lpx_cluster of any cloud) just aggregates less.  The order of a cell's points inside its
 // run and which point represents a cell differ from run to run, like before; the components do not.
 constexpr int GI_THREADS = 256;
-constexpr int GI_PER = 4;                      // points per thread
-constexpr int GI_TILE = GI_THREADS * GI_PER;   // 1024 points per workgroup
-constexpr int GI_SLOTS = 2048;                 // LDS table: load factor <= 1/2
+#ifndef LPX_GI_PER
+#define LPX_GI_PER 1
+#endif
+constexpr int GI_PER = LPX_GI_PER;             // points per thread
+constexpr int GI_TILE = GI_THREADS * GI_PER;   // 256 points per workgroup: 10 KiB of LDS.  (1024 / 512 / 256 points per
+                                               // tile: 2 076 / 2 109 / 2 115 Mpts/s on one box -- the larger tiles aggregate better
+                                               // but their 41 / 20 KiB workgroups wait for room under load)
+constexpr int GI_SLOTS = 2 * GI_TILE;          // LDS table: load factor <= 1/2
 __device__ __forceinline__ uint32_t gi_lds_hash(unsigned long long key)
 {
     unsigned long long k = key * 0x9E3779B97F4A7C15ull;
