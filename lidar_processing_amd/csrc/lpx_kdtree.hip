@@ -602,7 +602,10 @@ constexpr int TOP_EXTRA = 1;
 constexpr uint32_t TOP_MIN = 131072;  // levels whose ranges can exceed this take the multi-workgroup rounds
 
 constexpr int BLK_G_MAX = 1024;
-constexpr int BLK_CAP_BATCH = 1984;  // batches: kd_lds_kernel needs 20 B x 1984 + 256 B = 39 936 B, four workgroups per CU
+#ifndef LPX_BLK_CAP_BATCH
+#define LPX_BLK_CAP_BATCH 1984
+#endif
+constexpr int BLK_CAP_BATCH = LPX_BLK_CAP_BATCH;  // batches: kd_lds_kernel needs 20 B x 1984 + 256 B = 39 936 B, four workgroups per CU
                                      // (2032 nodes = 40 896 B measured as three per CU: 402 against 273 us per chain)
 constexpr int BLK_CAP_MAX = 4096;  // most nodes staged in LDS: 64 KiB + 2 x 16 KiB scratch (blk_cap is a launch argument)
 constexpr int BLK_TAIL = 1024;  // batches, upper levels: the active range is staged in LDS once it is this small
