@@ -3311,7 +3311,11 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     {
         // a batch stages nothing while the ranges are far above the LDS capacity (most rounds run in global memory
         // anyway): those workgroups need 256 bytes of LDS instead of 48 KiB
+#ifdef LPX_KD_NO_FULL_STAGE  // (A/B: batches stage only the tail of every nth_element on every level)
+        const bool stage = ctx->cur_b == 1;
+#else
         const bool stage = ctx->cur_b == 1 || size <= 4u * (uint32_t)blk_cap;
+#endif
         const KdTopState *top = nullptr;
         // LPX_KD_TOP_MIN overrides the size from which a level takes the multi-workgroup rounds (tests)
         static const uint32_t top_min = LPX_KNOB("LPX_KD_TOP_MIN") ? (uint32_t)atoi(LPX_KNOB("LPX_KD_TOP_MIN")) : TOP_MIN;
@@ -3369,10 +3373,10 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
             hipLaunchKernelGGL(kd_block_kernel<1024>, dim3(1u << level, 1, ctx->cur_b), dim3(1024), stage_lds + key_lds,
                                ctx->stream, nodes, lpos, rasc, frame, level, blk_cap, stage_cap, top, ctx->fs_tag);
         else if (size > mid_env)
-            hipLaunchKernelGGL(kd_block_kernel<256>, dim3(1u << level, 1, ctx->cur_b), dim3(256), stage_lds + key_lds,
+            hipLaunchKernelGGL(kd_block_kernel<256>, dim3(1u << level, 1, ctx->cur_b), dim3(256), stage_lds + key_lds / 4,  // (4 keys x 256 threads)
                                ctx->stream, nodes, lpos, rasc, frame, level, blk_cap, stage_cap, top, ctx->fs_tag);
         else
-            hipLaunchKernelGGL(kd_block_kernel<64>, dim3(1u << level, 1, ctx->cur_b), dim3(64), stage_lds + key_lds,
+            hipLaunchKernelGGL(kd_block_kernel<64>, dim3(1u << level, 1, ctx->cur_b), dim3(64), stage_lds + key_lds / 16,
                                ctx->stream, nodes, lpos, rasc, frame, level, blk_cap, stage_cap, top, ctx->fs_tag);
         size = size / 2;  // larger child holds at most size / 2 nodes
         ++level;
