@@ -566,8 +566,13 @@ __device__ __forceinline__ void rs_consume(const RsBatch &b, const KdNode *__res
 #define RS_LAP(acc, t) ((void)0)
 #endif
 
+#ifdef LPX_RS_MINWAVES
+#define RS_BOUNDS __launch_bounds__(RS_THREADS, LPX_RS_MINWAVES)
+#else
+#define RS_BOUNDS __launch_bounds__(RS_THREADS)
+#endif
 template <bool STATE_LDS>
-__global__ __launch_bounds__(RS_THREADS) void replay_search_kernel(
+__global__ RS_BOUNDS void replay_search_kernel(
     const FrameState *__restrict__ frame, const uint32_t *__restrict__ cc_lo, const uint32_t *__restrict__ cc_hi,
     const uint32_t *__restrict__ members, const KdNode *__restrict__ PR, const ChunkRec *__restrict__ chunks,
     const float4 *__restrict__ grp_of, const float *__restrict__ OX, const float *__restrict__ OY,
@@ -1294,7 +1299,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         else
             rc = lpx_sort_pairs(ctx, root, (uint32_t *)ctx->key_b.p, iota, (uint32_t *)ctx->val_b.p, m_max,
                                 &frame->n_obstacle, bits_for_count(m_max), &sroot, &members, first_hist != nullptr, nullptr,
-                                true);
+                                true, true);  // (every root is a position of the obstacle cloud: below its count)
         if (rc)
             return rc;
         hipLaunchKernelGGL(cc_ranges_kernel, grd, blk, 0, st, (const uint32_t *)sroot, (const uint32_t *)members, frame,

@@ -433,9 +433,11 @@ __device__ __forceinline__ float4 lpx_rec_xyz(const float4 *rec, uint32_t i, con
 
 // first_hist_ready: the producer of keys_a has left the tile histograms of the lowest key byte in lpx_sort_first_hist()
 // iota_vals: vals_a[i] == i is MEANT, the array is never read (nobody has to write it)
+// keys_below_n: every key of a frame is below that frame's element count *d_n (passes above log2 of it only copy)
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
                    const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out,
-                   bool first_hist_ready = false, const LpxSortGather *gather = nullptr, bool iota_vals = false);
+                   bool first_hist_ready = false, const LpxSortGather *gather = nullptr, bool iota_vals = false,
+                   bool keys_below_n = false);
 // where a kernel that produces the keys of an n-element sort may leave the first pass's tile histograms (block-major,
 // 256 words per LPX_SORT_TILE keys), or null when the sort would not use them (tables beyond the fused-scan limit)
 uint32_t *lpx_sort_first_hist(lpx_ctx *ctx, uint32_t n);

@@ -2728,11 +2728,11 @@ __global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__r
         const uint32_t s = llist[c];
         const unsigned long long key = lkey[s];
         uint32_t h = cell_hash(key) & mask;
-        unsigned long long o = __hip_atomic_load(tkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (straight to the CAS: most (tile, cell) pairs are new cells, and a look first -- an agent-scope load is a trip
+        // to the memory side like the CAS itself -- made their chain three dependent trips instead of two)
         for (;;)
         {
-            if (o == CELL_EMPTY)
-                o = atomicCAS(tkey + h, CELL_EMPTY, key);
+            const unsigned long long o = atomicCAS(tkey + h, CELL_EMPTY, key);
             if (o == CELL_EMPTY)
             {
                 const uint32_t rep = lslot[s];
@@ -2746,7 +2746,6 @@ __global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__r
             if (o == key)
                 break;
             h = (h + 1) & mask;
-            o = __hip_atomic_load(tkey + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lcnt[s] = atomicAdd(thead + h, lcnt[s]);  // the tile's points take consecutive positions among the cell's points
         lslot[s] = h;
@@ -3459,10 +3458,27 @@ bool lpx_cc_from_chunks(uint32_t m_max)
 #include "../../experiments/sweep_components.inc"
 #endif
 
+#ifdef LPX_DEV_KNOBS
+// LPX_DUMMY_LAUNCHES=N (development build): N empty launches of one wavefront per frame in every chain -- what a launch
+// costs a loaded device apart from its work (docs/experiments.md, round 5)
+__global__ void noop_kernel(uint32_t *sink)
+{
+    if (sink && threadIdx.x == 0xffffffffu)
+        *sink = 0;
+}
+#endif
+
 int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2, bool clear_grid)
 {
     if (m_max == 0)
         return LPX_OK;
+#ifdef LPX_DEV_KNOBS
+    {
+        static const int dummies = LPX_KNOB("LPX_DUMMY_LAUNCHES") ? atoi(LPX_KNOB("LPX_DUMMY_LAUNCHES")) : 0;
+        for (int i = 0; i < dummies; ++i)
+            hipLaunchKernelGGL(noop_kernel, dim3(1, 1, ctx->cur_b), dim3(64), 0, ctx->stream, (uint32_t *)nullptr);
+    }
+#endif
     StageTimer tm(ctx, ST_NB_FILL);
     const float rr = sqrtf(r2) * 1.0001f + 1.0e-3f;
     // Group size: 64 nodes, or 32 when the searches of the previous call on this context tested many candidates per

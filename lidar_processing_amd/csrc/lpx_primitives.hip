@@ -17,6 +17,12 @@ constexpr int SORT_ITEMS = 8;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 static_assert(SORT_TILE == (int)LPX_SORT_TILE, "the arena sizes the histogram table with LPX_SORT_TILE");
 constexpr int RADIX = 256;
+// Flag in the `block_major` / `large` word of the two kernels below: every key is BELOW the frame's element count n (the
+// component sort: the keys are positions of the obstacle cloud).  The host sizes the passes for its BOUND of n -- 17 bits
+// for a 123k-point frame -- while the frame holds ~50k obstacle points: in a pass whose digit starts at or above
+// log2(n) every key has digit 0 and the stable pass is the identity, so the scatter only copies its tile (coalesced, no
+// ranking, no table) and the histogram pass does nothing: the third pass of every KITTI frame.
+constexpr int SORT_KEYS_BELOW_N = 2;
 
 // Histogram of one digit per tile.  Small tables (frame-sized inputs, <= FUSED_SCAN_MAX_BLOCKS tiles) are stored
 // block-major [nblocks][256] and never scanned: every scatter block sums the few rows it needs itself.  Large
@@ -33,6 +39,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__
     d_n = lpx_slot(d_n, fs);
     hist = lpx_slot(hist, fs);
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
+    if ((block_major & SORT_KEYS_BELOW_N) && shift < 32u && n <= (1u << shift))
+        return;  // the pass is the identity (radix_scatter_kernel): nobody reads this table
+    block_major &= 1;
     const uint32_t tid = threadIdx.x;
     h[tid] = 0;
     __syncthreads();
@@ -93,6 +102,23 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     const uint32_t tid = threadIdx.x;
     const uint32_t w = tid / WAVE, lane = tid % WAVE;
+    if (!GATHER && (large & SORT_KEYS_BELOW_N) && shift < 32u && n <= (1u << shift))
+    {
+        // identity pass (SORT_KEYS_BELOW_N above): the tile is copied as it is
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r)
+        {
+            const uint32_t e = lpx_blk.x * SORT_TILE + r * SORT_THREADS + tid;
+            if (e < n)
+            {
+                keys_out[e] = keys_in[e];
+                if (HAS_VALS)
+                    vals_out[e] = vals_in ? vals_in[e] : e;
+            }
+        }
+        return;
+    }
+    large &= 1;
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS)
         (&wcnt[0][0])[i] = 0;
     __syncthreads();
@@ -527,7 +553,7 @@ uint32_t *lpx_sort_first_hist(lpx_ctx *ctx, uint32_t n)
 
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
                    const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out, bool first_hist_ready,
-                   const LpxSortGather *gather, bool iota_vals)
+                   const LpxSortGather *gather, bool iota_vals, bool keys_below_n)
 {
     const uint32_t nblocks = sort_blocks(n);
     int rc = ensure_hist(ctx, nblocks);
@@ -535,6 +561,9 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
         return rc;
     uint32_t *hist = (uint32_t *)((char *)ctx->hist.p + 64);
     const int large = nblocks > FUSED_SCAN_MAX_BLOCKS;
+    // (the identity shortcut needs the per-frame count on the device and the small-table form: hist_rows_kernel would
+    // scan a table nobody filled)
+    const int below = (keys_below_n && d_n && !large) ? SORT_KEYS_BELOW_N : 0;
     uint32_t *ka = keys_a, *kb = keys_b, *va = vals_a, *vb = vals_b;
     const uint32_t B = ctx->cur_b;
     const size_t fs = ctx->fs_tag;
@@ -542,7 +571,7 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     {
         if (!(shift == 0 && first_hist_ready && !large))
             hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka,
-                               n, d_n, shift, hist, nblocks, !large, fs);
+                               n, d_n, shift, hist, nblocks, (large ? 0 : 1) | below, fs);
         if (large)
             hipLaunchKernelGGL(hist_rows_kernel, dim3(RADIX, 1, B), dim3(SORT_THREADS), 0, ctx->stream, hist, nblocks, fs);
         // iota_vals: the values going in are the positions themselves -- the first pass makes them up instead of
@@ -555,7 +584,7 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
                                lpx_rec_layout(gather->records, gather->stride, gather->off, gather->pitch));
         else
             hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
-                               ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large, fs);
+                               ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large | below, fs);
         uint32_t *t = ka;
         ka = kb;
         kb = t;
