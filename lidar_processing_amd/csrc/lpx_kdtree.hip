@@ -2968,6 +2968,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
     };
     const unsigned long long lt = lpx_lanemask_lt();
     const uint32_t lane = threadIdx.x % WAVE;
+    // LPX_GP_PROF (a variant build: tools/build_variant.sh gpprof -DLPX_GP_PROF): cycles of two workgroups of frame 0 by phase
+#ifdef LPX_GP_PROF
+    unsigned long long gp_t = clock64(), gp_a = 0, gp_b = 0, gp_c = 0, gp_nq = 0;
+    const unsigned long long gp_t0 = gp_t;
+    uint32_t gp_rounds = 0;
+#define GP_LAP(acc) do { const unsigned long long n_ = clock64(); (acc) += n_ - gp_t; gp_t = n_; } while (0)
+#else
+#define GP_LAP(acc) ((void)0)
+#endif
     const uint32_t per_round = blockDim.x * (QCAP / 256u);  // items one round may queue at most
     for (unsigned long long round64 = (unsigned long long)lpx_blk.x * per_round; round64 < total;
          round64 += (unsigned long long)gridDim.x * per_round)
@@ -3021,6 +3030,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
         }
         __syncthreads();
         const uint32_t nq = q_n;
+        GP_LAP(gp_a);
+#ifdef LPX_GP_PROF
+        gp_nq += nq;
+        ++gp_rounds;
+#endif
         // ---- phase B: the survivors, U per lane side by side ----
         for (uint32_t e0 = threadIdx.x; e0 < nq; e0 += U * blockDim.x)
         {
@@ -3131,6 +3145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
         if (threadIdx.x == 0)
             q_n = 0;
         __syncthreads();
+        GP_LAP(gp_b);
     }
     // ---- phase C: the queued slow pairs ----
     __syncthreads();
@@ -3139,6 +3154,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
         for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x)
             slow_pair(c_a[i], c_b[i]);
     }
+#ifdef LPX_GP_PROF
+    __syncthreads();
+    GP_LAP(gp_c);
+    if (threadIdx.x == 0 && blockIdx.z == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))
+        printf("grid_pairs<%d> block %u of %u: cells %u rounds %u survivors %llu slow pairs %u | cycles total %llu A %llu B %llu C %llu\n",
+               (int)FAR, blockIdx.x, gridDim.x, frame->n_cells, gp_rounds, gp_nq, c_n, clock64() - gp_t0, gp_a, gp_b, gp_c);
+#endif
+#undef GP_LAP
 }
 
 // between the two linking passes: every cell points straight at its root, so that the far pass recognises pairs of
