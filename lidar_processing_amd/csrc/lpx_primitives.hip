@@ -23,6 +23,12 @@ constexpr int RADIX = 256;
 // log2(n) every key has digit 0 and the stable pass is the identity, so the scatter only copies its tile (coalesced, no
 // ranking, no table) and the histogram pass does nothing: the third pass of every KITTI frame.
 constexpr int SORT_KEYS_BELOW_N = 2;
+// Flag in the `large` word of radix_scatter_kernel: the small (block-major) table holds exclusive prefixes over the tiles
+// and, in row nblocks, the digit totals (hist_cols_kernel).  Launch chains: every scatter workgroup summing the rows of
+// all tiles itself is 61 x 61 KiB of L2 reads per pass and frame -- seven times the keys -- and a workgroup that waits for
+// two trips of 32 rows holds its wave slots for them; one 256-thread workgroup per frame sums them once.  A single frame
+// keeps the fused form: one launch less per pass is worth more there.
+constexpr int SORT_PREFIXED = 4;
 
 // Histogram of one digit per tile.  Small tables (frame-sized inputs, <= FUSED_SCAN_MAX_BLOCKS tiles) are stored
 // block-major [nblocks][256] and never scanned: every scatter block sums the few rows it needs itself.  Large
@@ -41,8 +47,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const KeyT *__
     const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
     if ((block_major & SORT_KEYS_BELOW_N) && shift < 32u && n <= (1u << shift))
         return;  // the pass is the identity (radix_scatter_kernel): nobody reads this table
-    block_major &= 1;
     const uint32_t tid = threadIdx.x;
+    if ((block_major & SORT_PREFIXED) && lpx_blk.x * SORT_TILE >= n)
+        return;  // (hist_cols_kernel reads the rows of the frame's own tiles only)
+    block_major &= 1;
     h[tid] = 0;
     __syncthreads();
     const uint32_t base = lpx_blk.x * SORT_TILE;
@@ -118,6 +126,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
         }
         return;
     }
+    const bool prefixed = (large & SORT_PREFIXED) != 0;
+    if (prefixed && lpx_blk.x * SORT_TILE >= n)
+        return;  // an empty tile (the host launches for its bound of n)
     large &= 1;
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_THREADS)
         (&wcnt[0][0])[i] = 0;
@@ -148,6 +159,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(const KeyT 
     {
         below = offs[tid * nblocks + lpx_blk.x];
         t = offs[RADIX * nblocks + tid];
+    }
+    else if (prefixed)
+    {
+        below = offs[lpx_blk.x * RADIX + tid];
+        t = offs[nblocks * RADIX + tid];
     }
     else
     {
@@ -369,6 +385,40 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(const uint32_t *in, uint3
         *d_total = carry;
 }
 
+// Small radix tables of a launch chain (SORT_PREFIXED): one workgroup per frame, thread d walks column d of the block-major
+// counts -- coalesced rows, sixteen in flight -- and leaves the exclusive prefix over the tiles in their place and the
+// digit's total in row nblocks.
+__global__ __launch_bounds__(RADIX) void hist_cols_kernel(uint32_t *hist, uint32_t nblocks, uint32_t n_max,
+                                                           const uint32_t *__restrict__ d_n, uint32_t shift, int flags,
+                                                           size_t fs)
+{
+    const LpxBlock lpx_blk = lpx_block<1>(fs);
+    hist = lpx_slot(hist, fs);
+    d_n = lpx_slot(d_n, fs);
+    const uint32_t n = d_n ? min(*d_n, n_max) : n_max;
+    if ((flags & SORT_KEYS_BELOW_N) && shift < 32u && n <= (1u << shift))
+        return;  // identity pass: nobody reads the table
+    const uint32_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t nb = tiles < nblocks ? tiles : nblocks;
+    const uint32_t tid = threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 16)
+    {
+        uint32_t c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            c[u] = (b0 + u < nb) ? hist[(b0 + u) * RADIX + tid] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (b0 + u < nb)
+            {
+                hist[(b0 + u) * RADIX + tid] = run;
+                run += c[u];
+            }
+    }
+    hist[nblocks * RADIX + tid] = run;
+}
+
 // Large radix tables (more than FUSED_SCAN_MAX_BLOCKS tiles): one workgroup per digit row turns its nblocks
 // counts into exclusive prefixes in place and leaves the row total behind the table; the scatter kernel adds the
 // prefix over the 256 totals.  (A single workgroup scanning the whole 256 x nblocks table took 0.32 ms per pass
@@ -564,6 +614,7 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     // (the identity shortcut needs the per-frame count on the device and the small-table form: hist_rows_kernel would
     // scan a table nobody filled)
     const int below = (keys_below_n && d_n && !large) ? SORT_KEYS_BELOW_N : 0;
+    const int prefixed = (!large && ctx->cur_b > 1) ? SORT_PREFIXED : 0;
     uint32_t *ka = keys_a, *kb = keys_b, *va = vals_a, *vb = vals_b;
     const uint32_t B = ctx->cur_b;
     const size_t fs = ctx->fs_tag;
@@ -571,20 +622,23 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     {
         if (!(shift == 0 && first_hist_ready && !large))
             hipLaunchKernelGGL((radix_hist_kernel<uint32_t>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0, ctx->stream, ka,
-                               n, d_n, shift, hist, nblocks, (large ? 0 : 1) | below, fs);
+                               n, d_n, shift, hist, nblocks, (large ? 0 : 1) | below | prefixed, fs);
         if (large)
             hipLaunchKernelGGL(hist_rows_kernel, dim3(RADIX, 1, B), dim3(SORT_THREADS), 0, ctx->stream, hist, nblocks, fs);
+        else if (prefixed)
+            hipLaunchKernelGGL(hist_cols_kernel, dim3(1, 1, B), dim3(RADIX), 0, ctx->stream, hist, nblocks, n, d_n, shift,
+                               below, fs);
         // iota_vals: the values going in are the positions themselves -- the first pass makes them up instead of
         // reading an array somebody had to write first (4 bytes per element written and read back, for nothing)
         const uint32_t *vin = (shift == 0 && iota_vals) ? (const uint32_t *)nullptr : va;
         if (gather && shift + 8 >= bits)  // the last pass also fetches the records the sorted values name
             hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
-                               ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large, fs,
+                               ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large | prefixed, fs,
                                (const float4 *)gather->records, gather->x, gather->y, gather->z,
                                lpx_rec_layout(gather->records, gather->stride, gather->off, gather->pitch));
         else
             hipLaunchKernelGGL((radix_scatter_kernel<uint32_t, true>), dim3(nblocks, 1, B), dim3(SORT_THREADS), 0,
-                               ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large | below, fs);
+                               ctx->stream, ka, kb, vin, vb, n, d_n, shift, hist, nblocks, large | below | prefixed, fs);
         uint32_t *t = ka;
         ka = kb;
         kb = t;
