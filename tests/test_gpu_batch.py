@@ -122,6 +122,30 @@ def test_batch_large_segments_take_the_pass_per_launch_path(ctx):
         check_frame(r, single(ctx, c, seg_kw, CLU))
 
 
+@pytest.mark.parametrize("mode", ["search", "lists"])
+def test_component_sort_passes_above_the_obstacle_count_are_per_frame(ctx, mode):
+    """The host sizes the component sort for its bound of the obstacle count (here 17-18 bits); a frame with at most
+    2^16 obstacle points takes the identity form of the third pass, a frame with more the real one -- side by side in one
+    launch (csrc/lpx_primitives.hip: SORT_KEYS_BELOW_N, SORT_PREFIXED), and a frame far below the bound leaves most of
+    the launch's tiles empty."""
+    clouds = [synthetic_scene(40_000, 300, 300, seed=31),     # ~90k obstacle points: above 2^16
+              synthetic_scene(90_000, 100, 300, seed=32),     # ~30k: identity third pass
+              synthetic_scene(3_000, 10, 100, seed=33),       # ~1k: one tile of sixty
+              synthetic_scene(50_000, 220, 300, seed=34)]     # ~66k: around the boundary
+    seg_kw = dict(number_of_planar_partitions=4, number_of_iterations=3)
+    clu_kw = dict(distance_squared=0.16, cluster_quality=0.5)
+    bctx = Context(0, batch=4)
+    try:
+        bctx.set_neighbour_mode(mode)
+        res = run_batch(bctx, clouds, seg_kw, clu_kw)
+    finally:
+        bctx.close()
+    counts = [len(r["obstacle_idx"]) for r in res]
+    assert max(counts) > 65536 > min(counts), counts
+    for c, r in zip(clouds, res):
+        check_frame(r, single(ctx, c, seg_kw, clu_kw))
+
+
 def test_batch_stride_and_far_returns_are_per_frame(ctx):
     good = load_frame(FRAMES[1])[:20_000]
     far = good.copy()
