@@ -2216,6 +2216,42 @@ __device__ __forceinline__ uint32_t cell_cap_for(uint32_t M, uint32_t cap_max)
     return cap;
 }
 
+// Bounding boxes of the pre-order layout in aligned blocks of IX_SUB ranks: {lo, hi} as two float4 per block.  The chunk
+// tables need the box of every candidate chunk of every group, and a node is a candidate of many groups (a KITTI frame:
+// ~20, BASELINE's dense box clouds: ~64): folding the chunk's 64 nodes for every table read every node that many times
+// (64 KiB of L2 reads and sixteen dependent trips per group).  The blocks are folded ONCE per frame here; a chunk's box
+// is then the union of the at most IX_SUB_SPAN blocks it overlaps -- a superset of its exact box by what the two end
+// blocks hold beyond the chunk (up to IX_SUB - 1 ranks each), which only makes the replay's cull a little more
+// permissive, never wrong.
+constexpr uint32_t IX_SUB = 16;
+constexpr uint32_t IX_SUB_SPAN = 64 / IX_SUB + 1;
+__global__ __launch_bounds__(256) void sub_box_kernel(const Node *__restrict__ PR, const FrameState *__restrict__ frame,
+                                                      float4 *__restrict__ SB, size_t fs)
+{
+    const LpxBlock lpx_blk = lpx_block<4>(fs);
+    PR = lpx_slot(PR, fs);
+    frame = lpx_slot(frame, fs);
+    SB = lpx_slot(SB, fs);
+    const uint32_t M = frame->n_obstacle;
+    const uint32_t j = lpx_blk.x * blockDim.x + threadIdx.x;
+    if (j * IX_SUB >= M)
+        return;
+    const uint32_t last = M - 1 - j * IX_SUB;  // (a clamped index repeats the block's last node: no minimum changes)
+    Node nd[IX_SUB];
+#pragma unroll
+    for (uint32_t i = 0; i < IX_SUB; ++i)
+        nd[i] = PR[j * IX_SUB + (i < last ? i : last)];
+    float4 lo = make_float4(nd[0].x, nd[0].y, nd[0].z, 0.0f), hi = lo;
+#pragma unroll
+    for (uint32_t i = 1; i < IX_SUB; ++i)
+    {
+        lo.x = fminf(lo.x, nd[i].x), lo.y = fminf(lo.y, nd[i].y), lo.z = fminf(lo.z, nd[i].z);
+        hi.x = fmaxf(hi.x, nd[i].x), hi.y = fmaxf(hi.y, nd[i].y), hi.z = fmaxf(hi.z, nd[i].z);
+    }
+    SB[2 * j] = lo;
+    SB[2 * j + 1] = hi;
+}
+
 constexpr int IX_CAPS = 160;  // traversal items per wavefront (2 x 160 x 12 B + prefix = 4.6 KiB)
 #ifndef LPX_IX_BOX_UNROLL
 #define LPX_IX_BOX_UNROLL 4
@@ -2230,10 +2266,12 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
                                                                uint32_t bucket, uint32_t *parent, float r2,
                                                                unsigned long long *__restrict__ tkey,
                                                                uint32_t *__restrict__ tparent, uint32_t *__restrict__ thead,
-                                                               uint32_t cap_max, FrameState *wframe, FV fv)
+                                                               uint32_t cap_max, FrameState *wframe,
+                                                               const float4 *__restrict__ SB, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
     parent = lpx_slot(parent, fv.fs);
+    SB = lpx_slot(SB, fv.fs);
     if (tkey)
     {
         // The cell table of the component grid, which runs right behind this kernel, is emptied here (what
@@ -2422,79 +2460,32 @@ __global__ __launch_bounds__(NB_THREADS) void nb_index_kernel(const Node *__rest
             s_out[w][LPX_GROUP_CHUNKS - 1] = make_uint2(0u, 0u);
     }
     Coop<WAVE>::sync();
-    // Exact bounding box of every chunk (a search culls chunks against its query ball before it loads a candidate).
-    // Four chunks at a time, one per row of 16 lanes: a lane folds its 4 nodes of the chunk, the row reduces with
-    // DPP row shifts (the result sits in lane 15 of the row), and lane 4 i + row of the output keeps it.
+    // Bounding box of every chunk (a search culls chunks against its query ball before it loads a candidate): lane c
+    // answers for chunk c and unites the boxes of the aligned blocks of IX_SUB ranks the chunk overlaps (sub_box_kernel) --
+    // ten 16-byte loads per lane, all in flight together.
     const uint2 mine = s_out[w][lane];
     const uint32_t stored = min(n_chunks, (uint32_t)LPX_GROUP_CHUNKS);
-    const uint32_t row = lane / 16, col = lane % 16;
     float lo0 = 0.0f, lo1 = 0.0f, lo2 = 0.0f, hi0 = 0.0f, hi1 = 0.0f, hi2 = 0.0f;
-    // (BX groups of four chunks per trip: the 4 BX node loads of a lane go out before any is folded -- the trips of
-    // this loop are independent, but one trip at a time made sixteen dependent round trips of it)
-    constexpr int BX = LPX_IX_BOX_UNROLL;
-    for (uint32_t c16 = 0; c16 < stored; c16 += 4 * BX)
     {
-        Node nd[BX][4];
-        uint32_t span[BX];
+        const uint32_t span = mine.y > 64u ? 64u : mine.y;
+        const bool has = lane < stored && span != 0u;
+        const uint32_t j0 = mine.x / IX_SUB, j1 = has ? (mine.x + span - 1u) / IX_SUB : j0;
+        float4 bl[IX_SUB_SPAN], bh[IX_SUB_SPAN];
 #pragma unroll
-        for (int g = 0; g < BX; ++g)
+        for (uint32_t u = 0; u < IX_SUB_SPAN; ++u)
         {
-            const uint32_t c = c16 + 4 * g + row;
-            const uint2 cc = c < stored ? s_out[w][c] : make_uint2(0u, 0u);
-            span[g] = cc.y > 64u ? 64u : cc.y;  // the long tail chunk gets an unbounded box below
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-            {
-                const uint32_t o = col + 16 * u;
-                nd[g][u] = PR[o < span[g] ? cc.x + o : 0u];  // unconditional: the loads go out together
-            }
+            const uint32_t j = has ? (j0 + u < j1 ? j0 + u : j1) : 0u;
+            bl[u] = SB[2 * j];
+            bh[u] = SB[2 * j + 1];
         }
-#pragma unroll
-        for (int g = 0; g < BX; ++g)
+        if (has)
         {
-            const uint32_t c4 = c16 + 4 * g;
-            if (c4 >= stored)
-                break;
-            float a0 = 3.0e38f, a1 = 3.0e38f, a2 = 3.0e38f, b0 = -3.0e38f, b1 = -3.0e38f, b2 = -3.0e38f;
+            lo0 = bl[0].x, lo1 = bl[0].y, lo2 = bl[0].z, hi0 = bh[0].x, hi1 = bh[0].y, hi2 = bh[0].z;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (uint32_t u = 1; u < IX_SUB_SPAN; ++u)
             {
-                const uint32_t o = col + 16 * u;
-                if (o < span[g])
-                {
-                    a0 = fminf(a0, nd[g][u].x);
-                    a1 = fminf(a1, nd[g][u].y);
-                    a2 = fminf(a2, nd[g][u].z);
-                    b0 = fmaxf(b0, nd[g][u].x);
-                    b1 = fmaxf(b1, nd[g][u].y);
-                    b2 = fmaxf(b2, nd[g][u].z);
-                }
-            }
-            a0 = lpx_row_min15_f32(a0);
-            a1 = lpx_row_min15_f32(a1);
-            a2 = lpx_row_min15_f32(a2);
-            b0 = lpx_row_max15_f32(b0);
-            b1 = lpx_row_max15_f32(b1);
-            b2 = lpx_row_max15_f32(b2);
-            // row r's result (its lane 15) belongs to output lane c4 + r
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-                const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0), 16 * r + 15));
-                const float v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), 16 * r + 15));
-                const float v2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), 16 * r + 15));
-                const float v3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b0), 16 * r + 15));
-                const float v4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b1), 16 * r + 15));
-                const float v5 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b2), 16 * r + 15));
-                if (lane == c4 + r)
-                {
-                    lo0 = v0;
-                    lo1 = v1;
-                    lo2 = v2;
-                    hi0 = v3;
-                    hi1 = v4;
-                    hi2 = v5;
-                }
+                lo0 = fminf(lo0, bl[u].x), lo1 = fminf(lo1, bl[u].y), lo2 = fminf(lo2, bl[u].z);
+                hi0 = fmaxf(hi0, bh[u].x), hi1 = fmaxf(hi1, bh[u].y), hi2 = fmaxf(hi2, bh[u].z);
             }
         }
     }
@@ -3532,13 +3523,19 @@ int lpx_group_index(lpx_ctx *ctx, uint32_t m_max, float r2, bool clear_grid)
     if (sizeof(ChunkRec) * LPX_GROUP_CHUNKS * (size_t)groups > ctx->chunks.bytes)
         return lpx_fail(ctx, LPX_ERR_INTERNAL, "chunk table of %u groups does not fit the workspace", groups);
     static const uint32_t ix_spine = LPX_KNOB("LPX_IX_SPINE") ? (uint32_t)atoi(LPX_KNOB("LPX_IX_SPINE")) : 2u;
+    // (the block boxes live in the kd build's stop-list scratch, which is free from here to the next build of this slot)
+    float4 *const sub_boxes = (float4 *)ctx->lpos.p;
+    if (2 * sizeof(float4) * ((size_t)m_max / IX_SUB + 1) > ctx->lpos.bytes)
+        return lpx_fail(ctx, LPX_ERR_INTERNAL, "block boxes of %u nodes do not fit their scratch", m_max);
+    hipLaunchKernelGGL(sub_box_kernel, dim3((m_max / IX_SUB + 256) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream,
+                       (const Node *)ctx->nodes_pre.p, (const FrameState *)ctx->frame.p, sub_boxes, ctx->fs_tag);
     hipLaunchKernelGGL(nb_index_kernel, dim3((groups + NB_WAVES - 1) / NB_WAVES, 1, ctx->cur_b), dim3(NB_THREADS), 0,
                        ctx->stream, (const Node *)ctx->nodes_pre.p, (const FrameState *)ctx->frame.p, rr,
                        (ChunkRec *)ctx->chunks.p, (float4 *)ctx->grp_of.p, ix_spine, bucket,
                        lpx_cc_from_chunks(m_max) ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr, r2,
                        clear_grid ? (unsigned long long *)ctx->cell_key.p : (unsigned long long *)nullptr,
                        (uint32_t *)ctx->cell_parent.p, (uint32_t *)ctx->cell_rep.p, ctx->cell_cap,
-                       (FrameState *)ctx->frame.p, lpx_fv(ctx));
+                       (FrameState *)ctx->frame.p, (const float4 *)sub_boxes, lpx_fv(ctx));
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
 }
