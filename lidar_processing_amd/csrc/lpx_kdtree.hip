@@ -2223,7 +2223,10 @@ __device__ __forceinline__ uint32_t cell_cap_for(uint32_t M, uint32_t cap_max)
 // is then the union of the at most IX_SUB_SPAN blocks it overlaps -- a superset of its exact box by what the two end
 // blocks hold beyond the chunk (up to IX_SUB - 1 ranks each), which only makes the replay's cull a little more
 // permissive, never wrong.
-constexpr uint32_t IX_SUB = 16;
+#ifndef LPX_IX_SUB
+#define LPX_IX_SUB 16
+#endif
+constexpr uint32_t IX_SUB = LPX_IX_SUB;
 constexpr uint32_t IX_SUB_SPAN = 64 / IX_SUB + 1;
 __global__ __launch_bounds__(256) void sub_box_kernel(const Node *__restrict__ PR, const FrameState *__restrict__ frame,
                                                       float4 *__restrict__ SB, size_t fs)
