@@ -109,21 +109,21 @@ static inline uint64_t lpx_entries_written(const FrameState &f)
     return s;
 }
 
-// Occupancy bitmap of the component grid: one bit per cell position modulo 2^XB x 2^YB x 32 (x, y, z) -- 8 KiB with 64 x 32 x 32, small
-// enough to sit in the LDS of every linking workgroup.  A set bit says "a cell with these low coordinate bits exists"
-// (cells that many positions apart alias: a false positive costs one probe of the table, nothing else); a clear bit
-// says the partner cell does not exist, without touching the table.  Word = (x mod 2^XB) << YB | (y mod 2^YB), bit = z & 31.
-#ifndef LPX_CELL_BITS_XB
-#define LPX_CELL_BITS_XB 6  // x positions modulo 2^XB
-#endif
-#ifndef LPX_CELL_BITS_YB
-#define LPX_CELL_BITS_YB 5  // y positions modulo 2^YB (z modulo 32: the bits of a word)
-#endif
-#define LPX_CELL_BITS_WORDS (1u << (LPX_CELL_BITS_XB + LPX_CELL_BITS_YB))
+// Occupancy bitmap of the component grid: 2^16 bits (8 KiB: small enough to sit in the LDS of every linking workgroup)
+// addressed by the low bits of a cell's position -- 64 x 64 x 16 positions (x, y, z) -- with the bit inside the word
+// permuted by a hash of the 64 x 64 tile the cell lies in.  A set bit says "some cell maps here" (a false positive costs
+// one probe of the table, nothing else); a clear bit says the partner cell does not exist, without touching the table.
+// (Rounds 4-5 used 64 x 32 x 32 with bit = z & 31: the obstacle cells of a street scene span ~10 levels of z, so two
+// thirds of every word stayed empty and aliases from different tiles met in the same few bits -- 55 % of the far pass's
+// partner tests passed where 20 % of the partners exist.)
+#define LPX_CELL_BITS_WORDS 2048u
 #define LPX_CELL_BITS_BYTES (4u * LPX_CELL_BITS_WORDS)
-__host__ __device__ static inline uint32_t lpx_cell_bit_word(uint32_t cx, uint32_t cy)
+__host__ __device__ static inline uint32_t lpx_cell_bit_index(uint32_t cx, uint32_t cy, uint32_t cz)
 {
-    return ((cx & ((1u << LPX_CELL_BITS_XB) - 1u)) << LPX_CELL_BITS_YB) | (cy & ((1u << LPX_CELL_BITS_YB) - 1u));
+    const uint32_t tile = (cx >> 6) * 0x9E3779B1u + (cy >> 6) * 0x85EBCA77u;
+    const uint32_t word = ((cx & 63u) << 5) | ((cy >> 1) & 31u);
+    const uint32_t bit = ((((cy & 1u) << 4) | (cz & 15u)) ^ (tile >> 27)) & 31u;
+    return (word << 5) | bit;  // word index in the high bits, bit inside the word in the low five
 }
 
 #define LPX_ACC_WORDS 16  // n, sx, sy, sz, 6 x (hi, lo)

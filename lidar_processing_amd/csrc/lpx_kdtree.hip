@@ -2732,9 +2732,10 @@ __global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__r
                 const uint32_t rep = lslot[s];
                 trep[h] = make_float4(OX[rep], OY[rep], OZ[rep], 0.0f);  // represents the cell in the quick test of the linking
                 lclaim[atomicAdd(&nclaim, 1u)] = h;
-                // ... and shows in the occupancy bitmap (one no-return atomic per CELL: lpx_cell_bit_word)
-                atomicOr((uint32_t *)(tkey + cap_max) + lpx_cell_bit_word((uint32_t)(key >> 42), (uint32_t)(key >> 21) & 0x1fffffu),
-                         1u << ((uint32_t)key & 31u));
+                // ... and shows in the occupancy bitmap (one no-return atomic per CELL: lpx_cell_bit_index)
+                const uint32_t bi = lpx_cell_bit_index((uint32_t)(key >> 42), (uint32_t)(key >> 21) & 0x1fffffu,
+                                                       (uint32_t)key & 0x1fffffu);
+                atomicOr((uint32_t *)(tkey + cap_max) + (bi >> 5), 1u << (bi & 31u));
                 break;
             }
             if (o == key)
@@ -2858,7 +2859,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
     // (cell, partner) item a hash and a scattered probe of the table -- 47 M probes per 64-frame chain, a quarter of the
     // texture-addresser cycles and a seventh of the vector-ALU cycles a chain spends (profiles/r05_stream_cu_resources.json:
     // the compute units, not the memory system, are what sixteen chains in flight saturate).  Now the workgroup holds the
-    // frame's occupancy bitmap in LDS (lpx_cell_bit_word: cell positions modulo 64 x 32 x 32, 8 KiB): phase A walks the
+    // frame's occupancy bitmap in LDS (lpx_cell_bit_index: 8 KiB): phase A walks the
     // items, asks the bitmap, and queues the few survivors -- (cell slot, partner key) -- densely in LDS; phase B hashes,
     // probes and links only those, U per lane side by side as before.  A false positive of the bitmap (an aliased
     // position) costs one probe that finds nothing; there are no false negatives (every claimed cell set its bit in
@@ -3004,7 +3005,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
                 const int nx = (int)(key >> 42) + dx, ny = (int)((key >> 21) & 0x1fffffu) + dy,
                           nz = (int)(key & 0x1fffffu) + dz;
                 keep = !((unsigned)nx > 0x1fffffu || (unsigned)ny > 0x1fffffu || (unsigned)nz > 0x1fffffu);
-                keep = keep && ((s_bits[lpx_cell_bit_word((uint32_t)nx, (uint32_t)ny)] >> ((uint32_t)nz & 31u)) & 1u);
+                const uint32_t bi = lpx_cell_bit_index((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
+                keep = keep && ((s_bits[bi >> 5] >> (bi & 31u)) & 1u);
                 nkq = ((unsigned long long)nx << 42) | ((unsigned long long)ny << 21) | (unsigned long long)nz;
             }
             const unsigned long long km = __ballot(keep);
