@@ -2636,11 +2636,13 @@ __global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__r
                                                                  const float *__restrict__ OZ, float d,
                                                                  unsigned long long *tkey, uint32_t *thead,
                                                                  uint32_t *__restrict__ next, uint32_t *__restrict__ cells,
+                                                                 unsigned long long *__restrict__ ckeys,
                                                                  uint32_t *__restrict__ cell_of, float4 *__restrict__ trep,
                                                                  uint32_t cap_max, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<6>(fs);
     trep = lpx_slot(trep, fs);
+    ckeys = lpx_slot(ckeys, fs);
     frame = lpx_slot(frame, fs);
     OX = lpx_slot(OX, fs);
     OY = lpx_slot(OY, fs);
@@ -2653,8 +2655,9 @@ __global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__r
     __shared__ unsigned long long lkey[GI_SLOTS];  // the tile's cells
     __shared__ uint32_t lcnt[GI_SLOTS];            // points of the tile in the cell; after phase 2: where they begin in the cell's run
     __shared__ uint32_t lslot[GI_SLOTS];           // first: a point of the tile in that cell (the representative); then: the cell's table slot
-    __shared__ uint32_t lclaim[GI_TILE];           // table slots this workgroup claimed
+    __shared__ uint32_t lclaim[GI_TILE];           // table slots this workgroup claimed (then: their LDS slots, for the keys)
     __shared__ uint32_t llist[GI_TILE];            // the occupied LDS slots (phase 2 walks them with every lane busy)
+    __shared__ uint16_t lclaim_s[GI_TILE];         // LDS slot of every claimed cell (its key goes to the cell list too)
     __shared__ uint32_t nclaim, claim_base, nlist;
     const uint32_t M = frame->n_obstacle;
     const uint32_t tile0 = lpx_blk.x * GI_TILE;
@@ -2731,7 +2734,9 @@ __global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__r
             {
                 const uint32_t rep = lslot[s];
                 trep[h] = make_float4(OX[rep], OY[rep], OZ[rep], 0.0f);  // represents the cell in the quick test of the linking
-                lclaim[atomicAdd(&nclaim, 1u)] = h;
+                const uint32_t ci = atomicAdd(&nclaim, 1u);
+                lclaim[ci] = h;
+                lclaim_s[ci] = (uint16_t)s;
                 // ... and shows in the occupancy bitmap (one no-return atomic per CELL: lpx_cell_bit_index)
                 const uint32_t bi = lpx_cell_bit_index((uint32_t)(key >> 42), (uint32_t)(key >> 21) & 0x1fffffu,
                                                        (uint32_t)key & 0x1fffffu);
@@ -2750,7 +2755,12 @@ __global__ __launch_bounds__(GI_THREADS) void grid_insert_kernel(FrameState *__r
         claim_base = atomicAdd(&frame->n_cells, nclaim);
     __syncthreads();
     for (uint32_t c = tid; c < nclaim; c += GI_THREADS)
+    {
+        // the cell list carries the cell's key beside its slot: the linking reads both with ONE trip per round instead of
+        // slot -> key in two dependent ones
         cells[claim_base + c] = lclaim[c];
+        ckeys[claim_base + c] = lkey[lclaim_s[c]];
+    }
     // phase 3: what the scatter needs per point
 #pragma unroll
     for (int u = 0; u < GI_PER; ++u)
@@ -2836,12 +2846,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
                                                          uint32_t *tparent, const uint32_t *__restrict__ tcount,
                                                          const uint32_t *__restrict__ tstart,
                                                          const uint32_t *__restrict__ cells,
+                                                         const unsigned long long *__restrict__ ckeys,
                                                          const float4 *__restrict__ cpts,
                                                          const float4 *__restrict__ trep, float r2, uint32_t cap_max,
                                                          int dbg, size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<5>(fs);
     trep = lpx_slot(trep, fs);
+    ckeys = lpx_slot(ckeys, fs);
     frame = lpx_slot(frame, fs);
     tkey = lpx_slot(tkey, fs);
     tparent = lpx_slot(tparent, fs);
@@ -2989,7 +3001,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
             {
                 const uint32_t ci = item / P;
                 slq = cells[ci];
-                const unsigned long long key = tkey[slq];
+                const unsigned long long key = ckeys[ci];  // (beside the slot in the cell list: no second trip)
                 const uint32_t j = item - ci * P;
                 int dx, dy, dz;
                 if (FAR)
@@ -3560,12 +3572,16 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     uint32_t *tparent = (uint32_t *)ctx->cell_parent.p, *thead = (uint32_t *)ctx->cell_rep.p;
     // (nothing here touches a buffer of the kd build or of the chunk tables: a forked front end runs them side by side)
     uint32_t *next = (uint32_t *)ctx->parent.p, *cells = (uint32_t *)ctx->cell_list.p;
+    // (the keys of the cell list live in the segmentation's 64-bit key scratch: nothing of the clustering uses it)
+    unsigned long long *ckeys = (unsigned long long *)ctx->key64_a.p;
+    if (sizeof(unsigned long long) * (size_t)m_max > ctx->key64_a.bytes)
+        return lpx_fail(ctx, LPX_ERR_INTERNAL, "cell keys of %u points do not fit their scratch", m_max);
     if (!cleared)  // (nb_index_kernel has emptied the table when it ran right in front of this: one launch less)
         hipLaunchKernelGGL(grid_clear_kernel, gc, blk, 0, ctx->stream, frame, tkey, tparent, thead, ctx->cell_cap,
                            ctx->fs_tag);
     const dim3 gi((m_max + GI_TILE - 1) / GI_TILE, 1, ctx->cur_b);
     hipLaunchKernelGGL(grid_insert_kernel, gi, dim3(GI_THREADS), 0, ctx->stream, frame, (const float *)ctx->OX.p,
-                       (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells,
+                       (const float *)ctx->OY.p, (const float *)ctx->OZ.p, sqrtf(r2), tkey, thead, next, cells, ckeys,
                        (uint32_t *)ctx->cell_of.p, (float4 *)ctx->cell_xyz.p, ctx->cell_cap, ctx->fs_tag);
     uint32_t *tstart = (uint32_t *)ctx->cell_start.p;
     float4 *cpts = (float4 *)ctx->cell_pts.p;
@@ -3591,7 +3607,8 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
         const uint32_t pg1 = (m_max * 13u + 255u) / 256u < w1 ? (m_max * 13u + 255u) / 256u : w1;
 #define GP_ARGS                                                                                                        \
     (const FrameState *)frame, (const unsigned long long *)tkey, tparent, (const uint32_t *)thead,                    \
-        (const uint32_t *)tstart, (const uint32_t *)cells, (const float4 *)cpts, (const float4 *)ctx->cell_xyz.p, r2,  \
+        (const uint32_t *)tstart, (const uint32_t *)cells, (const unsigned long long *)ckeys, (const float4 *)cpts,    \
+        (const float4 *)ctx->cell_xyz.p, r2,                                                                           \
         ctx->cell_cap, gp_dbg, ctx->fs_tag
         static const int gp_dbg = LPX_KNOB("LPX_GP_DBG") ? atoi(LPX_KNOB("LPX_GP_DBG")) : 0;  // timing experiments only
         hipLaunchKernelGGL(grid_pairs_kernel<false>, dim3(pg0, 1, ctx->cur_b), blk, 0, ctx->stream, GP_ARGS);
