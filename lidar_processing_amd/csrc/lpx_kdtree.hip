@@ -2882,6 +2882,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
 #endif
     constexpr uint32_t QCAP = LPX_PAIRS_QCAP;  // survivors queued per round (12 bytes each)
     __shared__ uint32_t s_bits[LPX_CELL_BITS_WORDS];
+    __shared__ uint8_t s_far[FAR ? 52 : 4];
     __shared__ unsigned long long q_key[QCAP];
     __shared__ uint32_t q_slot[QCAP];
     __shared__ uint32_t q_n;
@@ -2895,6 +2896,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
             dst[i] = src[i];
         if (threadIdx.x == 0)
             q_n = c_n = 0;
+        // (the far pass's offset table from LDS: indexed per lane, the constant-memory copy was a vector load -- a trip to
+        // memory in front of every bitmap test)
+        if (FAR && threadIdx.x < 49)
+            s_far[threadIdx.x] = FAR_T[threadIdx.x];
     }
     __syncthreads();
     // The slow tail of an item -- the pair's representatives are farther apart than d: (far pass) the boxes of the two
@@ -2985,13 +2990,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
 #define GP_LAP(acc) ((void)0)
 #endif
     const uint32_t per_round = blockDim.x * (QCAP / 256u);  // items one round may queue at most
+    // The (slot, key) of the cells of a round's items are requested one round AHEAD, when the previous round's phase A is
+    // through with its own: they travel while phase B works, and phase A itself is LDS work only.
+    constexpr uint32_t RI = QCAP / 256u;  // items per thread and round
+    uint32_t f_slot[RI];
+    unsigned long long f_key[RI];
+    auto fetch = [&](unsigned long long r64) {
+#pragma unroll
+        for (uint32_t r = 0; r < RI; ++r)
+        {
+            const unsigned long long item = r64 + r * blockDim.x + threadIdx.x;
+            const uint32_t ci = item < total ? (uint32_t)item / P : 0u;  // (total > 0 here: cell 0 exists)
+            f_slot[r] = cells[ci];
+            f_key[r] = ckeys[ci];  // (beside the slot in the cell list: no second, dependent trip)
+        }
+    };
+    if ((unsigned long long)lpx_blk.x * per_round < total)
+        fetch((unsigned long long)lpx_blk.x * per_round);
     for (unsigned long long round64 = (unsigned long long)lpx_blk.x * per_round; round64 < total;
          round64 += (unsigned long long)gridDim.x * per_round)
     {
         const uint32_t round0 = (uint32_t)round64;
+        uint32_t c_slot[RI];
+        unsigned long long c_key[RI];
+#pragma unroll
+        for (uint32_t r = 0; r < RI; ++r)
+        {
+            c_slot[r] = f_slot[r];
+            c_key[r] = f_key[r];
+        }
+        if (round64 + (unsigned long long)gridDim.x * per_round < total)
+            fetch(round64 + (unsigned long long)gridDim.x * per_round);
         // ---- phase A: QCAP / 256 items per thread, consecutive lanes on consecutive items (49 / 13 items share a cell) ----
 #pragma unroll
-        for (uint32_t r = 0; r < QCAP / 256u; ++r)
+        for (uint32_t r = 0; r < RI; ++r)
         {
             const uint32_t item = round0 + r * blockDim.x + threadIdx.x;  // (below total + per_round: no wrap)
             bool keep = item < total;
@@ -3000,13 +3032,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, LPX_WPE_
             if (keep)
             {
                 const uint32_t ci = item / P;
-                slq = cells[ci];
-                const unsigned long long key = ckeys[ci];  // (beside the slot in the cell list: no second trip)
+                slq = c_slot[r];
+                const unsigned long long key = c_key[r];
                 const uint32_t j = item - ci * P;
                 int dx, dy, dz;
                 if (FAR)
                 {
-                    const int t = FAR_T[j];
+                    const int t = s_far[j];
                     dx = t / 25 - 2, dy = (t / 5) % 5 - 2, dz = t % 5 - 2;
                 }
                 else
