@@ -3628,8 +3628,10 @@ int lpx_grid_components(lpx_ctx *ctx, uint32_t m_max, float r2, uint32_t *d_root
     // far pass) 1589 Mpts/s, 128 / 512 1686, 32 / 128 1723, 16 / 64 1723, while the kernels alone take 336 + 313,
     // 295 + 234 (64 / 256) and 484 + 255 us (16 / 64).  A single frame keeps the wide launch.
     {
-        static const uint32_t g0_env = LPX_KNOB("LPX_GP_G0") ? (uint32_t)atoi(LPX_KNOB("LPX_GP_G0")) : 32u;
-        static const uint32_t g1_env = LPX_KNOB("LPX_GP_G1") ? (uint32_t)atoi(LPX_KNOB("LPX_GP_G1")) : 128u;
+        // (round 5, after the bitmap and the phase-A changes left every workgroup less to do: 16 / 64 per frame 2 272-2 283
+        // against 2 241-2 257 Mpts/s with 32 / 128)
+        static const uint32_t g0_env = LPX_KNOB("LPX_GP_G0") ? (uint32_t)atoi(LPX_KNOB("LPX_GP_G0")) : 16u;
+        static const uint32_t g1_env = LPX_KNOB("LPX_GP_G1") ? (uint32_t)atoi(LPX_KNOB("LPX_GP_G1")) : 64u;
         // (per 128k points of the largest frame: a 1M-point frame gets eight times the workgroups of a KITTI frame)
         static const uint32_t gs_env = LPX_KNOB("LPX_GP_SCALE") ? (uint32_t)atoi(LPX_KNOB("LPX_GP_SCALE")) : 1u;
         const uint32_t scale = gs_env ? (m_max + 131071u) / 131072u : 1u;
