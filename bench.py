@@ -688,7 +688,11 @@ def dist_selftest(local_rank=0):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     t0 = time.perf_counter()
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    # (under `python -m torch.distributed.run` the environment says TORCHELASTIC_USE_AGENT_STORE: the rendezvous would
+    # then wait as a CLIENT for the launcher's store on the port chosen above, where nobody listens -- the self-test of a
+    # world-1 run started by the launcher hung until its timeout.  This group is the self-test's own: it hosts its store.)
+    os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     try:
         dist.barrier()
         t1 = time.perf_counter()

@@ -212,16 +212,22 @@ def test_bench_line_verifies_its_own_timed_region():
     assert line["config"]["distributed_selftest"]["ok"] is True
 
 
-def test_rccl_world_1_selftest():
+@pytest.mark.parametrize("launcher_env", [False, True])
+def test_rccl_world_1_selftest(launcher_env):
     """the reporting collectives of the N > 1 line -- barrier, float64 MAX / SUM all-reduce, all-gather on
     device tensors -- executed on RCCL (torch.distributed backend "nccl") in a world of one rank bound to cuda:0,
-    through the very functions the N > 1 line uses (bench.aggregate, bench.gather_per_rank)."""
+    through the very functions the N > 1 line uses (bench.aggregate, bench.gather_per_rank).  launcher_env: with the
+    environment `python -m torch.distributed.run --nproc-per-node 1` leaves its worker (the agent-store flag and the
+    launcher's own port): the self-test must host its own store instead of waiting for the launcher's."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    if launcher_env:
+        env.update(TORCHELASTIC_USE_AGENT_STORE="True", TORCHELASTIC_RESTART_COUNT="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29517", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dist-selftest"], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
