@@ -1062,7 +1062,8 @@ def main(argv=None):
 
         def child(extra):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup",
-                                str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight", "--no-sub"] + extra,
+                                str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight", "--no-sub",
+                                "--no-dist-selftest"] + extra,
                                capture_output=True, text=True, timeout=900)
             return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         if not args.no_inflight:

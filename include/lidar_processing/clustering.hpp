@@ -65,9 +65,11 @@ class Clusterer final
     // Like the reference's, this call does not fail on a non-empty cloud (src/clustering.cpp:47-125: the only throw on
     // its path, KDTree::rebuild's, is unreachable after the empty check at :51-54).  Should the device report an error
     // (workspace, a transient HIP status), the call is repeated once on a re-reserved workspace; if that fails too the
-    // object degrades the way the reference's Segmenter does (src/segmentation.cpp:251-259): a line on std::cerr and a
-    // defined result -- every point INVALID, i.e. "no cluster", which the caller accepts (src/processor.cpp:180-200
-    // throws only on UNDEFINED) -- never an exception one layer above the C-ABI.
+    // object degrades in the SAFE direction, the one the reference's Segmenter takes when a plane fit fails
+    // (src/segmentation.cpp:251-259: everything is an obstacle): a line on std::cerr and a defined result -- every point
+    // in ONE cluster, label 0, so the unchanged caller (src/processor.cpp:180-200) publishes the whole obstacle cloud as
+    // one obstacle instead of "nothing there" -- and failed() says so.  Never an exception one layer above the C-ABI,
+    // never UNDEFINED, never an empty obstacle set for a non-empty cloud.
     template <typename PointT>
     void cluster(const pcl::PointCloud<PointT> &cloud_in, std::vector<ClusteringLabel> &labels)
     {
@@ -75,6 +77,7 @@ class Clusterer final
         last_size_ = 0U;
         last_clusters_ = 0U;
         last_epoch_ = 0U;
+        failed_ = false;
         if (cloud_in.empty())
         {
             return;
@@ -102,14 +105,24 @@ class Clusterer final
         }
         if (rc != LPX_OK)
         {
-            std::cerr << "Failed clustering: " << lpx_last_error(context_->get()) << std::endl;
-            labels.assign(cloud_in.size(), INVALID);
+            std::cerr << "Failed clustering: " << lpx_last_error(context_->get())
+                      << " -- the whole cloud is reported as one cluster" << std::endl;
+            labels.assign(cloud_in.size(), ClusteringLabel{0});
+            failed_ = true;
+            last_size_ = number_of_points;
             return;
         }
         last_size_ = number_of_points;
         last_clusters_ = number_of_clusters;
         last_epoch_ = lpx_cluster_epoch(context_->get());
         context_->cluster_owner = this;
+    }
+
+    // true when the last cluster() call could not be served by the device even after its retry and returned the
+    // degraded result (every point in cluster 0)
+    bool failed() const noexcept
+    {
+        return failed_;
     }
 
     // Optional fast path for the regrouping the reference's caller does right after cluster()
@@ -122,6 +135,17 @@ class Clusterer final
     void regroup(const pcl::PointCloud<PointT> &cloud_in, std::vector<pcl::PointCloud<PointOutT>> &clustered_cloud)
     {
         clustered_cloud.clear();
+        if (failed_ && cloud_in.size() == last_size_)
+        {
+            // the degraded result of cluster(): one group holding the whole cloud, like the caller's own loop builds it
+            clustered_cloud.resize(1U);
+            clustered_cloud[0].reserve(cloud_in.size());
+            for (const auto &point : cloud_in.points)
+            {
+                clustered_cloud[0].emplace_back(point.x, point.y, point.z);
+            }
+            return;
+        }
         if (last_clusters_ == 0U || cloud_in.size() != last_size_)
         {
             return;
@@ -208,6 +232,7 @@ class Clusterer final
     std::shared_ptr<detail::LpxContext> context_;
     ClusteringConfiguration configuration_;
     std::uint64_t last_epoch_{0U};
+    bool failed_{false};
     std::vector<std::uint32_t> hull_offsets_;
     std::vector<std::uint32_t> hull_indices_;
     std::vector<float> hull_xy_;

@@ -280,6 +280,15 @@ int lpx_segment_cluster_batch_fields_device(lpx_ctx *ctx, uint32_t n_frames, con
                                             const lpx_clu_cfg *clu_cfg, uint32_t *d_labels, uint32_t *d_ground_idx,
                                             uint32_t *d_obstacle_idx, float *d_planes, int32_t *d_cluster_labels,
                                             uint32_t *d_counts);
+/* LIFETIME OF THE INPUT.  The two coloured-cloud calls below read x, y, z of every point from the INPUT RECORDS of the
+ * segmentation call they follow -- d_pts / d_data of that call, where the caller put them: the segmentation keeps no
+ * copy of the cloud (16 bytes per point less written per frame).  That array must therefore stay allocated and
+ * unmodified until the coloured-cloud call has been enqueued AND has run (lpx_synchronize, or stream order on a
+ * caller-provided stream).  A caller that recycles its upload buffer earlier (a ring of staging buffers, a caching
+ * allocator) calls lpx_set_record_copy(ctx, 1) once: the segmentation then keeps its own copy of the coordinates in the
+ * context's arena and these calls read that instead.  The host form, lpx_coloured_clouds, is not affected (the host
+ * calls own their staging buffer). */
+int lpx_set_record_copy(lpx_ctx *ctx, int on);
 int lpx_coloured_clouds_device(lpx_ctx *ctx, const uint32_t *d_ground_idx, const uint32_t *d_obstacle_idx,
                                void *d_ground_records, void *d_obstacle_records);
 int lpx_coloured_clouds_batch_device(lpx_ctx *ctx, uint32_t n_frames, uint32_t frame_pitch,

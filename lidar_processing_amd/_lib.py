@@ -78,6 +78,8 @@ def lib():
         L.lpx_set_lookahead.argtypes = [vp, C.c_int]
         L.lpx_dbg_lookahead_hits.argtypes = [vp]
         L.lpx_dbg_lookahead_hits.restype = C.c_uint64
+    if hasattr(L, "lpx_set_record_copy"):
+        L.lpx_set_record_copy.argtypes = [vp, C.c_int]
     L.lpx_wait_previous.argtypes = [vp]
     L.lpx_segment.argtypes = [vp, vp, sz, u32, C.POINTER(SegCfg), vp, vp, pu32, vp, pu32, vp]
     L.lpx_cluster.argtypes = [vp, vp, sz, u32, C.POINTER(CluCfg), vp, pu32]

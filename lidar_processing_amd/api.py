@@ -136,6 +136,12 @@ class Context:
         """lpx_set_lookahead: segment() enqueues the clustering the cluster() call that follows it will ask for"""
         self.check(self._L.lpx_set_lookahead(self._h, 1 if on else 0))
 
+    def set_record_copy(self, on=True):
+        """lpx_set_record_copy: the segmentation keeps its own copy of the coordinates, so that coloured_clouds of a
+        DEVICE call no longer read the caller's input array.  Off (the default) that array has to stay allocated and
+        unmodified until the coloured-cloud call has run (include/lpx.h, LIFETIME OF THE INPUT)."""
+        self.check(self._L.lpx_set_record_copy(self._h, 1 if on else 0))
+
     def lookahead_hits(self):
         """cluster() calls of this context that found their clustering already enqueued by segment()"""
         return int(self._L.lpx_dbg_lookahead_hits(self._h))

@@ -715,6 +715,16 @@ extern "C" int lpx_set_lookahead(lpx_ctx *ctx, int on)
     return LPX_OK;
 }
 
+extern "C" int lpx_set_record_copy(lpx_ctx *ctx, int on)
+{
+    if (!ctx)
+        return LPX_ERR_ARG;
+    ctx->keep_copy = on != 0;
+    if (ctx->twin)
+        ctx->twin->keep_copy = ctx->keep_copy;
+    return LPX_OK;
+}
+
 extern "C" uint64_t lpx_dbg_lookahead_hits(lpx_ctx *ctx)
 {
     return ctx ? ctx->la_hits : 0;
@@ -1531,9 +1541,11 @@ extern "C" int lpx_cluster_groups(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters,
     uint32_t *d_off = (uint32_t *)ctx->lpos.p, *d_ind = (uint32_t *)ctx->rpos.p;
     const bool seg_valid = ctx->seg_valid;  // regrouping touches neither the frame state nor the segmentation's buffers
     rc = begin_call(ctx, 1, 0);
+    if (rc)
+        return rc;  // (a failed begin_call leaves the labels invalidated: ADVICE round 5)
     ctx->seg_valid = seg_valid;
     ctx->clu_valid = true;                  // ... nor the labels
-    if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)))
+    if ((rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)))
         return rc;
     LPX_HIP(ctx, hipMemcpyAsync(offsets, d_off, sizeof(uint32_t) * ((size_t)n_clusters + 1),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -1581,9 +1593,11 @@ extern "C" int lpx_cluster_hulls(lpx_ctx *ctx, uint32_t m, uint32_t n_clusters, 
     float *d_hxy = (float *)ctx->key64_a.p;
     const bool seg_valid = ctx->seg_valid;  // (as lpx_cluster_groups)
     rc = begin_call(ctx, 1, 0);
+    if (rc)
+        return rc;
     ctx->seg_valid = seg_valid;
     ctx->clu_valid = true;
-    if (rc || (rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)) ||
+    if ((rc = lpx_run_groups(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind)) ||
         (rc = lpx_run_hulls(ctx, (const int32_t *)ctx->d_clabels.p, m, d_off, d_ind, max_points, d_hoff, d_hidx, d_hxy)))
         return rc;
     LPX_HIP(ctx, hipMemcpyAsync(hull_offsets, d_hoff, sizeof(uint32_t) * ((size_t)n_clusters + 1), hipMemcpyDeviceToHost,

@@ -261,6 +261,8 @@ struct lpx_ctx
     uint32_t rec_off[3] = {0, 4, 8};
     uint32_t rec_pitch = 0;
     bool rec_direct = false;
+    bool keep_copy = false;    // lpx_set_record_copy: the segmentation keeps its own copy of the coordinates (pts4), so that
+                               // lpx_coloured_clouds*_device never read the caller's input buffer after the call returned
     Buf key_a, key_b;          // u32 keys ping-pong
     Buf val_a, val_b;          // u32 values ping-pong
     Buf key64_a, key64_b;      // u64 keys ping-pong
@@ -433,7 +435,8 @@ __device__ __forceinline__ float4 lpx_rec_xyz(const float4 *rec, uint32_t i, con
 
 // first_hist_ready: the producer of keys_a has left the tile histograms of the lowest key byte in lpx_sort_first_hist()
 // iota_vals: vals_a[i] == i is MEANT, the array is never read (nobody has to write it)
-// keys_below_n: every key of a frame is below that frame's element count *d_n (passes above log2 of it only copy)
+// keys_below_n: every key of a frame is below that frame's element count *d_n (passes above log2 of it only copy);
+// ignored together with `gather` (the gathering last pass has no copy-only form)
 int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, uint32_t n,
                    const uint32_t *d_n, uint32_t bits, uint32_t **keys_out, uint32_t **vals_out,
                    bool first_hist_ready = false, const LpxSortGather *gather = nullptr, bool iota_vals = false,

@@ -613,7 +613,9 @@ int lpx_sort_pairs(lpx_ctx *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *v
     const int large = nblocks > FUSED_SCAN_MAX_BLOCKS;
     // (the identity shortcut needs the per-frame count on the device and the small-table form: hist_rows_kernel would
     // scan a table nobody filled)
-    const int below = (keys_below_n && d_n && !large) ? SORT_KEYS_BELOW_N : 0;
+    // ... and no gathering last pass: that scatter form has no identity branch, it would rank against a table the
+    // histogram pass skipped.  No caller combines the two; the shortcut is simply off then.
+    const int below = (keys_below_n && d_n && !large && !gather) ? SORT_KEYS_BELOW_N : 0;
     const int prefixed = (!large && ctx->cur_b > 1) ? SORT_PREFIXED : 0;
     uint32_t *ka = keys_a, *kb = keys_b, *va = vals_a, *vb = vals_b;
     const uint32_t B = ctx->cur_b;

@@ -1792,11 +1792,16 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
         __hip_atomic_store(rows + (size_t)b * LPX_ACC_WORDS + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prm.head_solve)
         return;  // (the next launch reads the rows: every block of it solves at its head)
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row has left for memory
+    // The hand-off: rows stored, then the ticket as an ACQUIRE-RELEASE read-modify-write at agent scope -- the release
+    // half orders this block's row (and its far-point atomics) before the ticket for whoever draws a later one, the
+    // acquire half makes the rows of every earlier ticket visible to the block that draws the last.  (Round 5 had a
+    // relaxed ticket behind s_waitcnt(0): correct on this part, but resting on the builtin acting as a compiler barrier
+    // and on write-through stores rather than on the memory model -- ADVICE round 5.)
     SegState *const cur = st + (size_t)(t & 1u) * LPX_MAX_PARTITIONS + s;
     uint32_t ticket = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (every lane's row words, not only lane 0's)
     if (lane == 0)
-        ticket = __hip_atomic_fetch_add(&cur->pad[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __hip_atomic_fetch_add(&cur->pad[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __shfl(ticket, 0, WAVE);
     if (ticket != prm.bps - 1u)
         return;
@@ -2285,16 +2290,19 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     ctx->rec_stride = stride;
     ctx->rec_off[0] = ctx->in_off[0], ctx->rec_off[1] = ctx->in_off[1], ctx->rec_off[2] = ctx->in_off[2];
     ctx->rec_pitch = ctx->upitch;
-    ctx->rec_direct = fused_gather;
+    // (lpx_set_record_copy: the caller recycles its input buffer before it asks for the coloured clouds -- the ingest then
+    // writes the 16-byte copy as it did before round 5, and the last sort pass and colour_kernel read THAT)
+    const bool direct = fused_gather && !ctx->keep_copy;
+    ctx->rec_direct = direct;
     {
         StageTimer tm(ctx, ST_INGEST);
-        launch_ingest(ctx, n, d_pts, stride, nullptr, nullptr, nullptr, fused_gather ? (float4 *)nullptr : P4,
+        launch_ingest(ctx, n, d_pts, stride, nullptr, nullptr, nullptr, direct ? (float4 *)nullptr : P4,
                       (uint32_t *)ctx->key_a.p, (uint32_t *)nullptr, frame, nullptr, first_hist);  // (values: iota_vals)
     }
     LpxSortGather sg;
-    sg.records = fused_gather ? d_pts : (const void *)P4;
+    sg.records = direct ? d_pts : (const void *)P4;
     sg.x = XS, sg.y = YS, sg.z = ZS;
-    if (fused_gather)
+    if (direct)
     {
         sg.stride = stride;
         sg.off[0] = ctx->in_off[0], sg.off[1] = ctx->in_off[1], sg.off[2] = ctx->in_off[2];

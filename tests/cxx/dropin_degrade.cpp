@@ -1,6 +1,7 @@
 // Test harness for the failure and ownership behaviour of the drop-in Clusterer (include/lidar_processing/clustering.hpp):
-//   * a device error inside cluster() is retried once and otherwise degrades to "every point INVALID" with a line on
-//     std::cerr -- no exception (the reference's cluster() cannot fail on a non-empty cloud, src/clustering.cpp:47-125);
+//   * a device error inside cluster() is retried once and otherwise degrades to "the whole cloud is ONE cluster" (the
+//     safe direction: the caller publishes everything as an obstacle, never an empty set) with a line on std::cerr and
+//     failed() == true -- no exception (the reference's cluster() cannot fail on a non-empty cloud, src/clustering.cpp:47-125);
 //     run against liblpx_dev.so with LPX_FAIL_CLUSTER=1 (retry succeeds) / =2 (degrades);
 //   * regroup() / convex_outlines() refuse to serve labels that another object's call has replaced on the shared
 //     default context (a Segmenter::segment with its look-ahead, another Clusterer): std::runtime_error.
@@ -69,9 +70,10 @@ int main(int argc, char **argv)
         undefined += l == lp::Clusterer::UNDEFINED;
         top = l > top ? l : top;
     }
-    clusterer.regroup(obstacles, groups);  // a degraded call has no groups; must not throw either way
-    std::printf("points=%zu obstacle=%zu labels=%zu invalid=%zu undefined=%zu clusters=%lld groups=%zu threw=%d", cloud.size(),
-                obstacles.size(), labels.size(), invalid, undefined, static_cast<long long>(top + 1), groups.size(), threw);
+    clusterer.regroup(obstacles, groups);  // a degraded call has one group, the whole cloud; must not throw either way
+    std::printf("points=%zu obstacle=%zu labels=%zu invalid=%zu undefined=%zu clusters=%lld groups=%zu group0=%zu failed=%d "
+                "threw=%d", cloud.size(), obstacles.size(), labels.size(), invalid, undefined, static_cast<long long>(top + 1),
+                groups.size(), groups.empty() ? std::size_t{0} : groups[0].size(), clusterer.failed() ? 1 : 0, threw);
 
     // 2. frame after frame (the look-ahead arms itself on the second pair): regroup right after cluster() works ...
     int ok_pairs = 0;

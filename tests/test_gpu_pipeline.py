@@ -655,8 +655,9 @@ def test_cxx_dropin_latency_harness_shares_one_context(tmp_path):
 def test_cxx_clusterer_degrades_without_throwing_and_guards_its_resident_labels(tmp_path):
     """tests/cxx/dropin_degrade.cpp through include/lidar_processing/*.hpp: (1) Clusterer::cluster never throws on a
     device error -- the reference's cannot fail on a non-empty cloud (src/clustering.cpp:47-125) -- it retries once
-    (forced failure 1 of 1: the reference's labels) and else degrades to every point INVALID with a line on stderr
-    (forced failures 2 of 2), liblpx_dev.so's LPX_FAIL_CLUSTER; (2) regroup() / convex_outlines() throw instead of
+    (forced failure 1 of 1: the reference's labels) and else degrades in the SAFE direction -- the whole cloud one
+    cluster, failed() set, a line on stderr (forced failures 2 of 2; ADVICE round 5: never "nothing there"),
+    liblpx_dev.so's LPX_FAIL_CLUSTER; (2) regroup() / convex_outlines() throw instead of
     serving another cloud's labels after a Segmenter::segment (look-ahead) or another Clusterer used the shared
     context, and work frame after frame in the node's own order."""
     import os
@@ -688,11 +689,12 @@ def test_cxx_clusterer_degrades_without_throwing_and_guards_its_resident_labels(
         d, err = run(fail)
         assert d["threw"] == 0 and d["obstacle"] == d["labels"] == no and d["undefined"] == 0, d
         assert d["clusters"] == wn and d["invalid"] == int((wl == -1).sum()) and d["groups"] == wn, (fail, d)
+        assert d["failed"] == 0, d
         assert ("retrying once" in err) == bool(fail) and "Failed clustering" not in err
         assert d["ok_pairs"] == 3 and d["after_segment"] == 2 and d["after_other"] == 2 and d["other_ok"] == 1, d
-    d, err = run(2)  # both attempts fail: every point INVALID, reported on stderr, nothing thrown, no groups
-    assert d["threw"] == 0 and d["labels"] == no and d["invalid"] == no and d["undefined"] == 0 and d["clusters"] == 0, d
-    assert d["groups"] == 0 and "Failed clustering: forced failure 2" in err
+    d, err = run(2)  # both attempts fail: ONE cluster holding every point, reported on stderr and by failed(), nothing thrown
+    assert d["threw"] == 0 and d["labels"] == no and d["invalid"] == 0 and d["undefined"] == 0 and d["clusters"] == 1, d
+    assert d["groups"] == 1 and d["group0"] == no and d["failed"] == 1 and "Failed clustering: forced failure 2" in err
     assert d["ok_pairs"] == 3 and d["after_segment"] == 2 and d["after_other"] == 2  # the object works again afterwards
 
 

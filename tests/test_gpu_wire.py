@@ -156,3 +156,62 @@ def test_coloured_clouds_batch_device(ctx):
         assert (ng, no) == (len(r["ground_idx"]), len(r["obstacle_idx"]))
         assert np.array_equal(d_grec[b, :ng].cpu().numpy(), oracle.coloured_records(c, r["ground_idx"], True))
         assert np.array_equal(d_orec[b, :no].cpu().numpy(), oracle.coloured_records(c, r["obstacle_idx"], False))
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_record_copy_lets_the_caller_recycle_its_input(B):
+    """lpx_set_record_copy: by default lpx_coloured_clouds*_device read x, y, z from the INPUT array of
+    the segmentation call (include/lpx.h, LIFETIME OF THE INPUT), so a caller that overwrites its upload buffer first gets
+    the new bytes; with the copy on, the segmentation keeps the coordinates in its arena and the records are those of
+    the segmented cloud -- same labels, lists and clusters either way."""
+    import torch
+    dev = torch.device("cuda:0")
+    clouds = [load_frame(f)[:30_000 + 500 * i] for i, f in enumerate(FRAMES[:B])]
+    pitch, P = 32_000, SEG["number_of_planar_partitions"]
+    host = np.zeros((B, pitch, 4), np.float32)
+    for b, c in enumerate(clouds):
+        host[b, :c.shape[0]] = c
+    n = np.array([c.shape[0] for c in clouds], np.uint32)
+    want = [oracle.segment(c, oracle.SegCfg(**SEG)) for c in clouds]
+    for keep in (True, False):
+        d_pts = torch.from_numpy(host).to(dev)
+        mk = lambda *s, dt=torch.int32: torch.zeros(s, dtype=dt, device=dev)  # noqa: E731
+        d_labels, d_g, d_o, d_cl, d_cnt = mk(B, pitch), mk(B, pitch), mk(B, pitch), mk(B, pitch), mk(B, 4)
+        d_planes = mk(B, 4 * P, dt=torch.float32)
+        d_grec, d_orec = mk(B, pitch, 32, dt=torch.uint8), mk(B, pitch, 32, dt=torch.uint8)
+        torch.cuda.synchronize()
+        c = Context(0, batch=B)
+        try:
+            c.set_record_copy(keep)
+            scfg, ccfg = SegmentationConfiguration(**SEG), ClusteringConfiguration(**CLU)
+            if B == 1:
+                c.segment_cluster_device(d_pts.data_ptr(), 16, int(n[0]), scfg, ccfg, d_labels.data_ptr(), d_g.data_ptr(),
+                                         d_o.data_ptr(), d_planes.data_ptr(), d_cl.data_ptr(), d_cnt.data_ptr())
+            else:
+                c.segment_cluster_batch_device(n, d_pts.data_ptr(), 16, pitch, scfg, ccfg, d_labels.data_ptr(),
+                                               d_g.data_ptr(), d_o.data_ptr(), d_planes.data_ptr(), d_cl.data_ptr(),
+                                               d_cnt.data_ptr())
+            c.synchronize()
+            d_pts.fill_(7.0)  # the caller recycles its upload buffer
+            torch.cuda.synchronize()
+            if B == 1:
+                c.check(c._L.lpx_coloured_clouds_device(c._h, d_g.data_ptr(), d_o.data_ptr(), d_grec.data_ptr(),
+                                                        d_orec.data_ptr()))
+            else:
+                c.check(c._L.lpx_coloured_clouds_batch_device(c._h, B, pitch, d_g.data_ptr(), d_o.data_ptr(),
+                                                              d_grec.data_ptr(), d_orec.data_ptr()))
+            c.synchronize()
+        finally:
+            c.close()
+        cnt = d_cnt.cpu().numpy()
+        for b, cl in enumerate(clouds):
+            r = want[b]
+            ng, no = int(cnt[b, 0]), int(cnt[b, 1])
+            assert (ng, no) == (len(r["ground_idx"]), len(r["obstacle_idx"]))
+            assert np.array_equal(d_labels[b, :cl.shape[0]].cpu().numpy().astype(np.uint32), r["labels"])
+            got = d_orec[b, :no].cpu().numpy()
+            if keep:
+                assert np.array_equal(d_grec[b, :ng].cpu().numpy(), oracle.coloured_records(cl, r["ground_idx"], True))
+                assert np.array_equal(got, oracle.coloured_records(cl, r["obstacle_idx"], False))
+            else:  # the documented default: the records are read where the caller left them -- now all sevens
+                assert np.array_equal(got[:, :12].view(np.float32), np.full((no, 3), 7.0, np.float32))
