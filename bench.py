@@ -184,8 +184,8 @@ def binding_resources(workload, chain_ms, frames_per_chain, frames_per_s):
         out["requests"] = {"error": repr(e)[:160]}
     try:
         path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_pmc_active.json")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r04_stream_pmc_active1.json")
+        if not os.path.exists(path) and workload in ("stream", "kitti"):  # (the same frames and chain shape)
+            path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_stream_pmc_active.json")
         d = json.load(open(path))
         d = d.get("kernels", d)
         own = {k: v for k, v in d.items() if not k.startswith(("__amd", "at::", "copy_kernel", "burn_"))}
@@ -356,6 +356,10 @@ def parse_args(argv=None):
                     help="lpx_set_fork: the component grid of a chain on a side stream beside its kd build and chunk tables")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default=None,
                     help="torch.distributed backend of the barrier / MAX / SUM (default nccl = RCCL; gloo with --dry-run)")
+    ap.add_argument("--device-map", default=os.environ.get("LPX_BENCH_DEVICES"),
+                    help="comma list: the GPU index of every local rank (e.g. 0,0 puts two ranks on GPU 0 so that the "
+                         "N > 1 path runs real frames on a 1-GPU box; needs --backend gloo, RCCL refuses two ranks on one "
+                         "device).  No scaling claim follows from such a run; the line says so")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="only: a world-1 RCCL process group on this GPU runs the barrier / all-reduce / all-gather of the "
                          "N > 1 line once and prints the record (the default N = 1 run does this in a child process)")
@@ -880,9 +884,11 @@ def latency_of(plan, host_frames, lpx):
             "device_resident_ms": round(dev_ms, 4), "device_resident_mpts_s": round(n0 / dev_ms / 1e3, 2),
             "host_api_pageable_ms": round(host_ms, 4), "host_api_pinned_ms": round(pin_ms, 4),
             "host_api_pinned_mpts_s": round(n0 / pin_ms / 1e3, 2),
-            "dropin_segment_then_cluster_ms": round(two_ms, 4),
-            "dropin_what": "lpx_segment, host copy of the obstacle cloud, lpx_cluster: the two blocking calls of "
-                           "the unchanged processor node (pageable memory)",
+            # (the Python mirror's two calls with a numpy fancy-index copy of the obstacle cloud in between: a measure of
+            # numpy on large clouds, not of the boundary -- the node's two calls are `dropin_cxx`, measured in C++)
+            "python_mirror_segment_then_cluster_ms": round(two_ms, 4),
+            "python_mirror_what": "lidar_processing_amd/api.py (ctypes test plumbing): segment, numpy copy of the "
+                                  "obstacle cloud, cluster -- NOT the drop-in's number, see dropin_cxx",
             "device_resident_ms_search_mode": round(dev_search_ms, 4),
             "workspace_mb": {"frame_slot_arena": round(ws_lists[0] / 1e6, 1), "neighbour_lists": round(ws_lists[1] / 1e6, 1),
                              "what": "device memory of the single-frame context in lists mode (lpx_workspace_bytes)"},
@@ -1033,7 +1039,7 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baselines(host_frames, wl, args.cpu_seconds)  # before the GPU is initialised (fork)
 
-    sub, overlap_sub, inflight_child, feeder_child, cxx_latency, rccl = None, None, None, None, None, None
+    sub, overlap_sub, inflight_child, feeder_child, cxx_latency, rccl, other_workloads = None, None, None, None, None, None, None
     if rank == 0 and world == 1 and not args.dry_run and not args.no_dist_selftest and not args.inflight_only \
             and not args.feeder_only:
         # the RCCL leg of the N > 1 line, executed once at world 1 by a child process that is gone before
@@ -1060,10 +1066,10 @@ def main(argv=None):
         # (2) the round-1/2 headline shape, configs[1] on three frames cycled.
         import subprocess
 
-        def child(extra):
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup",
-                                str(args.warmup), "--no-cpu-baseline", "--no-latency", "--no-inflight", "--no-sub",
-                                "--no-dist-selftest"] + extra,
+        def child(extra, steps=None, warmup=None):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(steps or args.steps), "--warmup",
+                                str(args.warmup if warmup is None else warmup), "--no-cpu-baseline", "--no-latency",
+                                "--no-inflight", "--no-sub", "--no-dist-selftest"] + extra,
                                capture_output=True, text=True, timeout=900)
             return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         if not args.no_inflight:
@@ -1094,6 +1100,28 @@ def main(argv=None):
                    "what": WORKLOADS["kitti"]["config"] + " (own process)"}
         except Exception as e:
             sub = {"error": repr(e)[:200]}
+        # (3) BASELINE's two synthetic configurations, two timed steps each, so that the driver's record of the default
+        # run holds a measured, verified number for every configuration and not for the headline alone
+        other_workloads = {}
+        for w in ("synth1m", "synth5m"):
+            try:
+                t_child = time.perf_counter()
+                dw = child(["--workload", w], steps=2, warmup=1)
+                rf = dw.get("roofline") or {}
+                other_workloads[w] = {
+                    "mpts_s": dw["value"], "ms_per_step": dw["ms_per_step"], "frames_per_s": dw["config"]["frames_per_s"],
+                    "frames_in_flight": dw["completion"]["frames_in_flight"],
+                    "p99_frame_completion_ms": dw["completion"]["p99_frame_completion_ms"],
+                    "verified_frames": dw["verified"]["frames"], "verified_mismatches": dw["verified"]["mismatches"],
+                    "neighbour_mode": dw["config"]["neighbour_mode"], "dominant_kernel": rf.get("kernel"),
+                    "roofline_frac": rf.get("frac"), "frame_frac": (rf.get("frame") or {}).get("frac"),
+                    "streaming_kernels_frac": {k: v.get("frac") for k, v in dict(rf.get("streaming_kernels") or {},
+                                                                                 plane_passes=rf.get("plane_passes") or {}).items()},
+                    "stage_ms_per_launch_alone": rf.get("stage_ms_per_launch_alone"),
+                    "wall_s": round(time.perf_counter() - t_child, 1), "steps": 2,
+                    "what": WORKLOADS[w]["config"] + " (own process, before this one touched the GPU)"}
+            except Exception as e:
+                other_workloads[w] = {"error": repr(e)[:200]}
 
     import torch
     import torch.distributed as dist
@@ -1145,9 +1173,24 @@ def main(argv=None):
     shared_gpus = world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count()
     if shared_gpus and backend == "nccl" and not args.backend:
         backend = "gloo"  # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the line then says so
-    local_rank = local_rank % max(1, torch.cuda.device_count())
+    device_map = None
+    if args.device_map:
+        device_map = [int(v) for v in str(args.device_map).split(",") if v.strip() != ""]
+        if len(device_map) <= local_rank or min(device_map) < 0 or max(device_map) >= torch.cuda.device_count():
+            raise SystemExit(f"--device-map {args.device_map}: need one valid GPU index per local rank "
+                             f"({torch.cuda.device_count()} GPUs here, local rank {local_rank})")
+        shared_gpus = shared_gpus or len(set(device_map[:max(world, 1)])) < min(world, len(device_map))
+        if shared_gpus and backend == "nccl":
+            if args.backend == "nccl":
+                raise SystemExit("--device-map puts two ranks on one GPU: RCCL refuses that, use --backend gloo")
+            backend = "gloo"
+        local_rank = device_map[local_rank]
+    else:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the tensors of the throughput report (a few float64 words): on the GPU for RCCL, on the host for gloo
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": dev} if backend == "nccl" else {}))
@@ -1171,18 +1214,24 @@ def main(argv=None):
     numa_node = pin_to_gpu_numa_node(torch, local_rank) if world > 1 else None
     plan = Plan(args.workload, host_frames, args, rank, world, local_rank, torch, lpx)
     own_elapsed, counts = plan.timed(args.steps, args.warmup, barrier)
-    elapsed, total_points_per_step, total_frames_per_step = aggregate(own_elapsed, plan.points_per_step, dev, world, plan.F)
+    elapsed, total_points_per_step, total_frames_per_step = aggregate(own_elapsed, plan.points_per_step, coll_dev, world,
+                                                                      plan.F)
     # what every rank measured by itself (the line's value uses the MAX of the times, the SUM of the points)
     verified = None if args.no_verify else verify_outputs(plan)
     per_rank = [{"rank": r, "frames_per_s": round(v[0], 2), "ms_per_step": round(v[1], 4), "mpts_s": round(v[2], 3),
                  "p99_frame_completion_ms": round(v[3], 3), "verified_mismatches": int(v[4]),
-                 "numa_node": None if v[5] < 0 else int(v[5]), "gpu_pci": pci_id_str(v[6])}
+                 "numa_node": None if v[5] < 0 else int(v[5]), "gpu_pci": pci_id_str(v[6]), "gpu_index": int(v[7]),
+                 "points_per_step": int(v[8]), "verified_frames": int(v[9]),
+                 # the frames this rank processed first: rank r of N owns frames r, r + N, r + 2 N, ...
+                 "first_frame_ids": [int(x) for x in v[10:14] if x >= 0]}
                 for r, v in enumerate(gather_per_rank(
                     [plan.F * args.steps / own_elapsed, own_elapsed / args.steps * 1e3,
                      plan.points_per_step * args.steps / own_elapsed / 1e6,
                      plan.completion["p99_frame_completion_ms"] or 0.0,
                      -1.0 if not verified or verified["mismatches"] is None else float(verified["mismatches"]),
-                     -1.0 if numa_node is None else float(numa_node), pci_id_of(torch, local_rank)], dev, world))]
+                     -1.0 if numa_node is None else float(numa_node), pci_id_of(torch, local_rank), float(local_rank),
+                     float(plan.points_per_step), float((verified or {}).get("frames") or 0)]
+                    + [float(x) for x in (list(plan.my_ids[:4]) + [-1] * 4)[:4]], coll_dev, world))]
 
     roofline, latency, stream_info, inflight = None, None, None, None
     stage_ms = {}
@@ -1231,12 +1280,19 @@ def main(argv=None):
                        "frames_per_s": round(total_frames_per_step * args.steps / elapsed, 2),
                        "sharding": "frame i -> GPU i mod N, no data-path collective",
                        "distributed_backend": (backend + (" (RCCL)" if backend == "nccl" else "")
-                                               + (" -- ranks share GPUs: fewer devices than ranks on this box"
+                                               + (" -- ranks SHARE GPUs (fewer devices than ranks, or --device-map): "
+                                                  "the N > 1 code path on real frames, NOT a scaling measurement"
                                                   if shared_gpus else "")) if world > 1
                                               else (rccl["summary"] if rccl else None),
                        "distributed_selftest": rccl,
+                       "device_map": device_map, "ranks_share_gpus": bool(shared_gpus),
                        "distributed_world_size": dist.get_world_size() if world > 1 else 1},
             "vs_target": {"north_star_mpts_s": 50.0, "ratio": round(value / 50.0, 2)},
+            # (top-level scalars: a driver that keeps only the scalar keys of the line keeps these)
+            "verified_frames": None if not verified else (sum(r["verified_frames"] for r in per_rank)),
+            "verified_mismatches": None if not verified else int(sum(max(0, r["verified_mismatches"]) for r in per_rank)),
+            "p50_frame_completion_ms": plan.completion["p50_frame_completion_ms"],
+            "p99_frame_completion_ms": max(r["p99_frame_completion_ms"] for r in per_rank),
             "verified": verified,
             "completion": dict(plan.completion, budget_ms=FRAME_BUDGET_MS,
                                within_budget=(plan.completion["p99_frame_completion_ms"] or 0.0) <= FRAME_BUDGET_MS),
@@ -1253,6 +1309,8 @@ def main(argv=None):
             line["kitti_3_frames_cycled"] = sub
         if overlap_sub:
             line["beyond_latency_budget"] = overlap_sub
+        if other_workloads:
+            line["other_workloads"] = other_workloads
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:

@@ -4,12 +4,18 @@
 
 #include "lpx.h"
 
+#include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <iostream>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <system_error>
+#include <thread>
+#include <type_traits>
+#include <vector>
 
 namespace lidar_processing
 {
@@ -81,6 +87,61 @@ inline std::shared_ptr<LpxContext> default_context()
 template <typename PointT> inline const void *points_base(const PointT *p) noexcept
 {
     return static_cast<const void *>(&p->x);
+}
+
+// cloud_out = the points of cloud_in named by indices[0 .. count), in that order: what the reference builds with one
+// push_back per point (src/segmentation.cpp:331-343).  push_back re-checks the capacity and bumps the size for every
+// point, and a 5M-point frame spent 45 of its 59 ms there -- the indices arrive x-sorted, so every source record is a
+// cache miss that one core takes one at a time.  Here: one resize, then an indexed copy, split over a few threads from
+// kParallelGatherFrom points on (each thread owns a contiguous slice of the OUTPUT; nothing is shared but the read-only
+// input).  Same records in the same order; a thread that cannot be started just leaves its slice to the caller.
+constexpr std::uint32_t kParallelGatherFrom = 250'000U;
+constexpr unsigned kGatherThreads = 4U;
+
+template <typename CloudT>
+inline void gather_cloud(const CloudT &cloud_in, const std::uint32_t *indices, std::uint32_t count, CloudT &cloud_out)
+{
+    using PointT = typename std::remove_cv<typename std::remove_reference<decltype(cloud_in.points[0])>::type>::type;
+    static_assert(std::is_trivially_copyable<PointT>::value, "PCL point records are plain data");
+    cloud_out.resize(count);
+    if (count == 0U)
+    {
+        return;
+    }
+    const PointT *const source = cloud_in.points.data();
+    PointT *const target = cloud_out.points.data();
+    const auto copy_slice = [source, target, indices](std::uint32_t begin, std::uint32_t end) {
+        for (std::uint32_t i = begin; i < end; ++i)
+        {
+            target[i] = source[indices[i]];
+        }
+    };
+    unsigned workers = 1U;
+    if (count >= kParallelGatherFrom)
+    {
+        const unsigned cores = std::thread::hardware_concurrency();
+        workers = std::max(1U, std::min(kGatherThreads, cores == 0U ? 1U : cores));
+    }
+    const std::uint32_t slice = (count + workers - 1U) / workers;
+    std::vector<std::thread> helpers;
+    std::uint32_t done_to = slice < count ? slice : count;  // the caller's own slice is the first
+    for (unsigned w = 1U; w < workers; ++w)
+    {
+        const std::uint32_t begin = std::min(count, w * slice), end = std::min(count, begin + slice);
+        try
+        {
+            helpers.emplace_back(copy_slice, begin, end);
+        }
+        catch (const std::system_error &)
+        {
+            copy_slice(begin, end);  // no thread to be had: do it here
+        }
+    }
+    copy_slice(0U, done_to);
+    for (std::thread &helper : helpers)
+    {
+        helper.join();
+    }
 }
 } // namespace detail
 } // namespace lidar_processing

@@ -129,16 +129,10 @@ class Segmenter final
 
         last_ground_ = number_of_ground;
         last_obstacle_ = number_of_obstacle;
-        ground_cloud.reserve(number_of_ground);
-        obstacle_cloud.reserve(number_of_obstacle);
-        for (std::uint32_t i = 0U; i < number_of_ground; ++i)
-        {
-            ground_cloud.push_back(cloud_in[ground_indices_[i]]);
-        }
-        for (std::uint32_t i = 0U; i < number_of_obstacle; ++i)
-        {
-            obstacle_cloud.push_back(cloud_in[obstacle_indices_[i]]);
-        }
+        // the two output clouds in the order of the index lists (src/segmentation.cpp:331-343): one resize and an indexed
+        // copy each, on a few threads for large clouds (lpx_context.hpp: gather_cloud)
+        detail::gather_cloud(cloud_in, ground_indices_.data(), number_of_ground, ground_cloud);
+        detail::gather_cloud(cloud_in, obstacle_indices_.data(), number_of_obstacle, obstacle_cloud);
     }
 
     // Optional fast path for what the reference's caller does right after segment() (src/processor.cpp:152-163):

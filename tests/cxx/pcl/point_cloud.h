@@ -12,6 +12,7 @@ template <typename PointT> struct PointCloud
     bool empty() const { return points.empty(); }
     void clear() { points.clear(); }
     void reserve(std::size_t n) { points.reserve(n); }
+    void resize(std::size_t n) { points.resize(n); }  // (pcl::PointCloud::resize also keeps width x height == n)
     void push_back(const PointT &p) { points.push_back(p); }
     template <typename... A> PointT &emplace_back(A &&...a) { return points.emplace_back(std::forward<A>(a)...); }
     const PointT &operator[](std::size_t i) const { return points[i]; }

@@ -482,9 +482,12 @@ def test_full_size_1m_label_for_label(ctx, q):
     assert (np.diff(first) > 0).all()  # dense labels in seed order (src/clustering.cpp:120-123)
 
 
-def test_cxx_dropin_headers_run_like_processor(ctx, tmp_path):
+@pytest.mark.parametrize("cloud", ["frame", "synth1m"])
+def test_cxx_dropin_headers_run_like_processor(ctx, tmp_path, cloud):
     """include/lidar_processing/*.hpp driven by the call sequence of reference src/processor.cpp:150-200,
-    compiled against the test-only PCL stand-in and run on the GPU; outputs equal the oracle's."""
+    compiled against the test-only PCL stand-in and run on the GPU; outputs equal the oracle's.  synth1m: a 1M-point
+    cloud, whose two output clouds (682k / 318k points) are gathered on several threads (lpx_context.hpp: gather_cloud) --
+    same records, same order."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -495,7 +498,7 @@ def test_cxx_dropin_headers_run_like_processor(ctx, tmp_path):
            "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    pts = load_frame("0000000000")
+    pts = load_frame("0000000000") if cloud == "frame" else synthetic_scene(600_000, 2000, 200, 20240601)
     fin, fout = tmp_path / "in.f32", tmp_path / "out.bin"
     pts.tofile(fin)
     r = subprocess.run([str(exe), str(fin), str(fout)], capture_output=True, text=True)

@@ -235,3 +235,38 @@ def test_rccl_world_1_selftest(launcher_env):
     assert rec["ok"] is True and rec["world"] == 1 and rec["backend"].startswith("nccl")
     assert rec["rccl_version"].count(".") >= 1 and "self-test ok" in rec["summary"]
     assert rec["gpu_pci"] is None or rec["gpu_pci"].count(":") == 2
+
+
+def test_two_ranks_on_one_gpu_run_real_frames():
+    """SURVEY 8(e), the N > 1 path on REAL frames before an 8-GPU node sees it: `bench.py --gpus 2 --backend gloo
+    --device-map 0,0` starts its two ranks itself (before anything touches the GPU), both on GPU 0 (RCCL refuses two ranks
+    on one device, hence gloo: the collectives carry a few float64 words of the report either way).  Asserted: rank r got
+    the frames r, r + 2, ... of the stream; every frame of every rank's last step equals tests/golden; per_rank has two
+    entries; value = sum of the ranks' points / the slowest rank's time.  No scaling claim follows from two ranks on one
+    device, and the line says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    steps = 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device-map",
+                        "0,0", "--steps", str(steps), "--warmup", "1", "--workload", "stream", "--frames-per-step", "24",
+                        "--batch", "8", "--contexts", "3", "--no-cpu-baseline", "--no-latency", "--no-inflight", "--no-sub"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["distributed_world_size"] == 2 and cfg["ranks_share_gpus"] is True
+    assert cfg["device_map"] == [0, 0] and "NOT a scaling measurement" in cfg["distributed_backend"]
+    pr = line["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and all(p["gpu_index"] == 0 for p in pr)
+    assert pr[0]["first_frame_ids"] == [0, 2, 4, 6] and pr[1]["first_frame_ids"] == [1, 3, 5, 7]  # frame i -> rank i mod 2
+    assert all(p["verified_mismatches"] == 0 and p["verified_frames"] == 24 for p in pr), pr
+    assert line["verified_mismatches"] == 0 and line["verified_frames"] == 48
+    assert cfg["frames_per_step"] == 48 and cfg["points_per_step"] == sum(p["points_per_step"] for p in pr)
+    slowest_ms = max(p["ms_per_step"] for p in pr)
+    assert abs(line["ms_per_step"] - slowest_ms) <= 1e-3 * slowest_ms + 1e-3
+    want = cfg["points_per_step"] / (line["ms_per_step"] * 1e-3) / 1e6
+    assert abs(line["value"] - want) <= 2e-3 * want, (line["value"], want)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the measured artefacts under gpurun_out/<tag>/ on the GPU box (copy them to profiles/ afterwards):
 # per workload the bench line, the rocprofv3 kernel stats of the default command (under load) and of --contexts 1 (the
-# kernels alone), FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes); for the stream also the memory REQUESTS per
+# kernels alone), FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes); for the stream and configs[2] also the memory REQUESTS per
 # chain (tools/probe.sh requests) and the vector-ALU activity (SQ_ACTIVE_INST_VALU); and the hash of the library's
 # sources (lpx_build_info) that bench.py compares with the loaded library's (`traffic_stale`).
 # usage: tools/refresh_profiles.sh TAG [workloads...]
@@ -32,7 +32,7 @@ for W in $WORKLOADS; do
   # counter passes: one context, one chain per step (synth5m: two frames, rocprofv3 --pmc crashed with eight resident)
   (cd $R && tools/probe.sh traffic $TAG $W > $O/traffic_$W.log 2>&1)
   cp $O/${W}_pmc_fetch_write_per_kernel.json $O/${TAG}_${W}_pmc_fetch_write_per_kernel.json
-  if [ $W = stream ]; then
+  if [ $W = stream ] || [ $W = synth1m ]; then
     (cd $R && tools/probe.sh requests $TAG $W > $O/requests_$W.log 2>&1)
     python3 - $O/requests_$W.json > $O/${TAG}_${W}_requests.json <<'PY'
 import json, sys
