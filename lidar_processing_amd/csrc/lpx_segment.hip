@@ -1584,28 +1584,34 @@ __device__ __noinline__ void pass_solve(const long long *rows, uint32_t bps, con
     *out = o;
 }
 
-template <bool FINAL>
-__global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_kernel(const float *__restrict__ XS,
-                                                                   const float *__restrict__ YS,
-                                                                   const float *__restrict__ ZS, SegParams prm,
-                                                                   uint32_t t, SegState *st, long long *part,
-                                                                   long long *facc, uint8_t *__restrict__ flags,
-                                                                   uint32_t *__restrict__ blk_counts,
-                                                                   const FrameState *__restrict__ frame, size_t fs)
+// S_t of a segment as another block of the SAME launch published it (chained passes): twelve words read past the caches
+// by twelve lanes, handed round by readlane
+__device__ __forceinline__ SegState seg_state_load_agent(const SegState *p, uint32_t lane)
 {
-    const LpxBlock lpx_blk = lpx_block<2>(fs);
-    XS = lpx_slot(XS, fs);
-    YS = lpx_slot(YS, fs);
-    ZS = lpx_slot(ZS, fs);
-    st = lpx_slot(st, fs);
-    part = lpx_slot(part, fs);
-    facc = lpx_slot(facc, fs);
-    flags = lpx_slot(flags, fs);
-    blk_counts = lpx_slot(blk_counts, fs);
-    frame = lpx_slot(frame, fs);
+    constexpr int NW = (int)(sizeof(SegState) / sizeof(uint32_t));
+    static_assert(NW == 12, "SegState is twelve words");
+    const uint32_t w = __hip_atomic_load((const uint32_t *)p + (lane < (uint32_t)NW ? lane : 0u), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t v[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        v[i] = (uint32_t)__builtin_amdgcn_readlane((int)w, i);
+    SegState o;
+    __builtin_memcpy(&o, v, sizeof o);
+    return o;
+}
+
+// CHAINED: the block belongs to a launch that holds ALL passes of the frames of a call (plane_chain_kernel): it waits
+// for the state it tests against -- published by a block of the same launch -- instead of being started after it.
+template <bool FINAL, bool CHAINED>
+__device__ __forceinline__ void plane_pass_block(const float *__restrict__ XS, const float *__restrict__ YS,
+                                                 const float *__restrict__ ZS, SegParams prm, uint32_t t, SegState *st,
+                                                 long long *part, long long *facc, uint8_t *__restrict__ flags,
+                                                 uint32_t *__restrict__ blk_counts, const FrameState *__restrict__ frame,
+                                                 uint32_t s, uint32_t b)
+{
     seg_bind(prm, frame);
     const bool any_far = frame->has_far != 0;
-    const uint32_t s = lpx_blk.y, b = lpx_blk.x;
     const uint32_t lane = threadIdx.x;
     const uint32_t nb = prm.P * prm.bps;
     uint32_t base, lo, hi;
@@ -1650,6 +1656,32 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
         // the far set pass t + 1 accumulates into was read by pass t - 1 and is free
         if (any_far && b == 0 && lane < LPX_FAR_WORDS)
             facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
+    }
+    else if (CHAINED && t > 0)
+    {
+        // S_t comes from the block of pass t - 1 that finished this segment last -- a block of THIS launch with a lower
+        // workgroup number (pass-major grid), i.e. one that was started before this one: the wait cannot deadlock however
+        // few blocks are resident (see plane_chain_kernel).  pad[1] is the pass the record belongs to (release / acquire).
+        SegState *const cur = st + (size_t)(t & 1u) * LPX_MAX_PARTITIONS + s;
+        // (relaxed agent-scope loads: past the caches; the record itself is read the same way right after)
+        if (__hip_atomic_load(&cur->pad[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != t)
+        {
+            const uint64_t t0 = wall_clock64();  // 100 MHz
+            while (__hip_atomic_load(&cur->pad[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != t)
+            {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 400000000ull)
+                {
+                    // four seconds: the dispatch-order premise does not hold on this machine.  Report instead of hanging
+                    // (the frame fails with LPX_ERR_INTERNAL; LPX_PASS_CHAIN=0 of the development build is the way out)
+                    if (lane == 0)
+                        atomicCAS((uint32_t *)&frame->status, 0u, (uint32_t)(-LPX_ERR_INTERNAL));
+                    break;
+                }
+            }
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        sst = seg_state_load_agent(cur, lane);
     }
     else
         sst = st[(size_t)(t & 1u) * LPX_MAX_PARTITIONS + s];
@@ -1792,27 +1824,112 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_ke
         __hip_atomic_store(rows + (size_t)b * LPX_ACC_WORDS + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prm.head_solve)
         return;  // (the next launch reads the rows: every block of it solves at its head)
-    // The hand-off: rows stored, then the ticket as an ACQUIRE-RELEASE read-modify-write at agent scope -- the release
-    // half orders this block's row (and its far-point atomics) before the ticket for whoever draws a later one, the
-    // acquire half makes the rows of every earlier ticket visible to the block that draws the last.  (Round 5 had a
-    // relaxed ticket behind s_waitcnt(0): correct on this part, but resting on the builtin acting as a compiler barrier
-    // and on write-through stores rather than on the memory model -- ADVICE round 5.)
+    // The hand-off.  The payload (this block's row, its far-point atomics) goes out as agent-scope atomic stores --
+    // write-through to the device's coherence point -- and is DRAINED (s_waitcnt) before the ticket is taken; the block
+    // that draws the last ticket reads every row with agent-scope atomic loads, past the caches.  That is the hand-off
+    // form of the CDNA guide.  Compiler ordering is pinned by the two signal fences (formal compiler barriers: ADVICE
+    // round 5 -- the waitcnt builtin alone is not one on paper).  The memory-model form -- a release fence and an
+    // ACQ_REL ticket at agent scope -- was built and measured in round 6: the legalizer turns the release into a
+    // write-back of the XCD's whole L2 per block, 92 -> 403 us per pass of a 32-frame 1M-point chain.  Not used.
     SegState *const cur = st + (size_t)(t & 1u) * LPX_MAX_PARTITIONS + s;
     uint32_t ticket = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (every lane's row words, not only lane 0's)
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the row has left for memory
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     if (lane == 0)
-        ticket = __hip_atomic_fetch_add(&cur->pad[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __hip_atomic_fetch_add(&cur->pad[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __shfl(ticket, 0, WAVE);
     if (ticket != prm.bps - 1u)
         return;
     // the last block of the segment: every row is in memory
     SegState o;
     pass_solve(rows, prm.bps, &sst, fa, any_far ? 1u : 0u, prm.odt, lane, &o);
-    if (lane == 0)
-        st[(size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS + s] = o;  // what pass t + 1 tests against; the compaction's planes
+    o.pad[1] = t + 1u;  // the pass this record is the state of
     // the far set pass t + 1 accumulates into was read at the end of pass t - 2 and is free
     if (any_far && lane < LPX_FAR_WORDS)
-        facc[((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane] = 0;
+        __hip_atomic_store(facc + ((size_t)((t + 1u) % 3u) * LPX_MAX_PARTITIONS + s) * LPX_FAR_WORDS + lane, 0ll,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // what pass t + 1 tests against and the compaction's planes: the record (write-through words), then -- behind a release
+    // fence -- the pass number a chained block of pass t + 1 waits for
+    SegState *const nxt = st + (size_t)((t + 1u) & 1u) * LPX_MAX_PARTITIONS + s;
+    {
+        constexpr int NW = (int)(sizeof(SegState) / sizeof(uint32_t));
+        uint32_t v[NW];
+        __builtin_memcpy(v, &o, sizeof o);
+        uint32_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            mine = lane == (uint32_t)i ? v[i] : mine;
+        if (lane < (uint32_t)NW - 1u)  // every word but the last, pad[1]
+            __hip_atomic_store((uint32_t *)nxt + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the same hand-off form as the ticket above: write-through payload, drained, then the word that is waited for)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (lane == 0)
+            __hip_atomic_store(&nxt->pad[1], t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <bool FINAL>
+__global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_pass_kernel(const float *__restrict__ XS,
+                                                                   const float *__restrict__ YS,
+                                                                   const float *__restrict__ ZS, SegParams prm,
+                                                                   uint32_t t, SegState *st, long long *part,
+                                                                   long long *facc, uint8_t *__restrict__ flags,
+                                                                   uint32_t *__restrict__ blk_counts,
+                                                                   const FrameState *__restrict__ frame, size_t fs)
+{
+    const LpxBlock lpx_blk = lpx_block<2>(fs);
+    XS = lpx_slot(XS, fs);
+    YS = lpx_slot(YS, fs);
+    ZS = lpx_slot(ZS, fs);
+    st = lpx_slot(st, fs);
+    part = lpx_slot(part, fs);
+    facc = lpx_slot(facc, fs);
+    flags = lpx_slot(flags, fs);
+    blk_counts = lpx_slot(blk_counts, fs);
+    frame = lpx_slot(frame, fs);
+    plane_pass_block<FINAL, false>(XS, YS, ZS, prm, t, st, part, facc, flags, blk_counts, frame, lpx_blk.y, lpx_blk.x);
+}
+
+// ALL passes of the frames of a call in ONE launch.  Grid (blocks of a segment, segments, (I + 1) x frames): workgroup
+// numbers run pass-major -- every block of pass t of every frame before any block of pass t + 1 -- and a block of pass
+// t + 1 waits for its segment's S_{t+1}, which the block of pass t that finishes the segment last solves and publishes
+// (tail form).  Why that cannot deadlock without a cooperative launch: the hardware starts the workgroups of a launch in
+// the order of their numbers (round-robin over the XCDs, in order on each), and a block only ever waits for blocks with
+// LOWER numbers; the lowest-numbered unfinished block of the launch therefore waits for nobody, has been started (its
+// XCD started it before anything above it) and finishes -- by induction everything does, whatever else occupies the
+// device.  (A wait that lasts four seconds reports LPX_ERR_INTERNAL instead of hanging.)  What it buys: between the
+// launches of a chain the device drained and refilled -- the last segments' solves (~10 us each of dependent double
+// precision) and the ramp of ~3000 one-wavefront blocks, four times per 1M-point chain; here the next pass's blocks
+// stream while the stragglers of the last one solve, and the x-sorted SoA of a frame is re-read while the Infinity
+// Cache still holds it.  The XCD-affine renumbering permutes workgroups inside groups of eight z values: frames of ONE
+// pass when the frame count is a multiple of eight (the host leaves it on only then).
+__global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_chain_kernel(const float *__restrict__ XS,
+                                                                    const float *__restrict__ YS,
+                                                                    const float *__restrict__ ZS, SegParams prm,
+                                                                    uint32_t frames, SegState *st, long long *part,
+                                                                    long long *facc, uint8_t *__restrict__ flags,
+                                                                    uint32_t *__restrict__ blk_counts,
+                                                                    const FrameState *__restrict__ frame, size_t fs)
+{
+    LpxBlock lpx_blk = lpx_block<2>(fs);
+    const uint32_t t = lpx_blk.z / frames;
+    lpx_blk.z -= t * frames;
+    XS = lpx_slot(XS, fs);
+    YS = lpx_slot(YS, fs);
+    ZS = lpx_slot(ZS, fs);
+    st = lpx_slot(st, fs);
+    part = lpx_slot(part, fs);
+    facc = lpx_slot(facc, fs);
+    flags = lpx_slot(flags, fs);
+    blk_counts = lpx_slot(blk_counts, fs);
+    frame = lpx_slot(frame, fs);
+    if (t == prm.I)
+        plane_pass_block<true, true>(XS, YS, ZS, prm, t, st, part, facc, flags, blk_counts, frame, lpx_blk.y, lpx_blk.x);
+    else
+        plane_pass_block<false, true>(XS, YS, ZS, prm, t, st, part, facc, flags, blk_counts, frame, lpx_blk.y, lpx_blk.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1825,7 +1942,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
                                                                const float *__restrict__ YS,
                                                                const float *__restrict__ ZS, SegParams prm,
                                                                const uint32_t *__restrict__ blk_offs,
-                                                               uint32_t *__restrict__ labels,
+                                                               uint8_t *__restrict__ lab8,
                                                                uint32_t *__restrict__ gidx, uint32_t *__restrict__ oidx,
                                                                float *__restrict__ OX, float *__restrict__ OY,
                                                                float *__restrict__ OZ, float4 *__restrict__ nodes,
@@ -1847,7 +1964,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     nodes = lpx_slot(nodes, fv.fs);
     st = lpx_slot(st, fv.fs);
     frame = lpx_slot(frame, fv.fs);
-    labels = lpx_user(labels, fv.upitch);
+    lab8 = lpx_slot(lab8, fv.fs);
     gidx = lpx_user(gidx, fv.upitch);
     oidx = lpx_user(oidx, fv.upitch);
     planes = lpx_user(planes, 4u * prm.P);
@@ -1957,7 +2074,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
             if (in)
             {
                 const uint32_t i = si[r];
-                labels[i] = f[r];
+                lab8[i] = (uint8_t)f[r];  // one BYTE by original index: see labels_widen_kernel
                 if (f[r] == 1u)
                     gidx[gpos + __popcll(mg & lt)] = i;
                 else if (f[r] == 2u)
@@ -1992,7 +2109,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     {
         // the N mod P highest-x points belong to no segment (Q2); written UNKNOWN (Q3)
         for (uint32_t p = prm.P * prm.n_per + tid; p < prm.n; p += SEG_THREADS)
-            labels[sidx[p]] = LPX_LABEL_UNKNOWN;
+            lab8[sidx[p]] = (uint8_t)LPX_LABEL_UNKNOWN;
         if (tid == 0)
         {
             frame->n_ground = total_g;
@@ -2002,6 +2119,42 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
             for (uint32_t i = tid; i < prm.P * 4; i += SEG_THREADS)
                 planes[i] = st[i / 4].plane[i % 4];
     }
+}
+
+// The labels in ORIGINAL order.  The compaction walks the cloud in x-sorted order and knows a point's label there; its
+// original index is random with respect to that order, so writing the caller's 4-byte label from there touched a
+// different line with every store -- a 1M-point frame's 4 MB label array does not stay in an XCD's L2 beside the other
+// frames of a chain, every store went out as a partial line and the kernel moved 3.5 x its algorithmic bytes (round 5:
+// 15 % of the HBM roofline).  Now the compaction scatters ONE BYTE per point into a frame-sized scratch (1 MB per
+// million points: resident in the frame's L2, where the partial stores merge and every line leaves once), and this
+// kernel streams the bytes out as the caller's 32-bit labels: 16 points per thread, one 16-byte load, four 16-byte
+// stores (VEC: the caller's array and pitch are 16-byte aligned; otherwise word stores).
+template <bool VEC>
+__global__ __launch_bounds__(256) void labels_widen_kernel(const uint8_t *__restrict__ lab8, uint32_t *__restrict__ labels,
+                                                           const FrameState *__restrict__ frame, FV fv)
+{
+    const LpxBlock lpx_blk = lpx_block<0>(fv.fs);
+    lab8 = lpx_slot(lab8, fv.fs);
+    frame = lpx_slot(frame, fv.fs);
+    labels = lpx_user(labels, fv.upitch);
+    const uint32_t n = frame->n_in;
+    const uint32_t p0 = (lpx_blk.x * 256u + threadIdx.x) * 16u;
+    if (p0 >= n)
+        return;
+    const uint4 b = *(const uint4 *)(lab8 + p0);  // (the scratch is padded to a multiple of 16 bytes)
+    const uint32_t w[4] = {b.x, b.y, b.z, b.w};
+    if (VEC && p0 + 16u <= n)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(uint4 *)(labels + p0 + 4 * q) =
+                make_uint4(w[q] & 255u, (w[q] >> 8) & 255u, (w[q] >> 16) & 255u, w[q] >> 24);
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (p0 + q < n)
+            labels[p0 + q] = (w[q >> 2] >> (8 * (q & 3))) & 255u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2386,6 +2539,21 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         // for all passes -- a 1024-thread workgroup per segment with its points in registers: under load that workgroup
         // waited for a whole CU to drain (3.2 ms against 0.5), and alone it has since been overtaken too: 0.145 ms
         // against 0.095 ms for the six launches of a 123k-point frame.  Removed.)
+        static const char *chain_env = LPX_KNOB("LPX_PASS_CHAIN");  // development build: 1 / 0 forces the form
+        // one launch for all passes where the passes are separate launches of MORE blocks than the device holds (the tail
+        // form's domain: chains of 1M-point frames); launches that are resident at once keep the head form, whose
+        // blocks wait for nothing
+        const bool chained = I >= 1 && (size_t)(I + 1) * B <= 65535u &&
+                             (chain_env ? chain_env[0] == '1' : lpx_pass_form(prm.bps * P * B) == 0u);
+        if (chained)
+        {
+            prm.head_solve = 0;
+            // (the XCD-affine renumbering only where a group of eight z values holds frames of ONE pass)
+            const size_t fs_chain = (B % 8u == 0) ? fv.fs : (fv.fs & ~(size_t)(1u << 2));
+            hipLaunchKernelGGL(plane_chain_kernel, dim3(prm.bps, P, (I + 1) * B), dim3(PASS_THREADS), 0, st, XS, YS, ZS, prm,
+                               B, sst, part, facc, (uint8_t *)ctx->flags.p, blk_counts, (const FrameState *)frame, fs_chain);
+        }
+        else
         {
             const dim3 g2(prm.bps, P, B);
             prm.head_solve = lpx_pass_form(prm.bps * P * B);
@@ -2398,11 +2566,20 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     }
     {
         StageTimer tm(ctx, ST_COMPACT);
+        // (the byte labels live in the second key buffer of the x sort: free from the sort's last pass to the clustering)
+        uint8_t *const lab8 = (uint8_t *)ctx->key_b.p;
         hipLaunchKernelGGL(compact_kernel, dim3(prm.bps, P, B), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p,
-                           sidx, XS, YS, ZS, prm, blk_counts, d_labels, d_gidx, d_oidx, (float *)ctx->OX.p,
+                           sidx, XS, YS, ZS, prm, blk_counts, lab8, d_gidx, d_oidx, (float *)ctx->OX.p,
                            (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p,
                            sst + (size_t)(I & 1u) * LPX_MAX_PARTITIONS,  // the state the head of the final pass published
                            d_planes, frame, fv);
+        const dim3 gw((n + 4095u) / 4096u, 1, B);
+        if ((((uintptr_t)d_labels | ((size_t)fv.upitch * sizeof(uint32_t))) & 15u) == 0)
+            hipLaunchKernelGGL(labels_widen_kernel<true>, gw, dim3(256), 0, st, (const uint8_t *)lab8, d_labels,
+                               (const FrameState *)frame, fv);
+        else
+            hipLaunchKernelGGL(labels_widen_kernel<false>, gw, dim3(256), 0, st, (const uint8_t *)lab8, d_labels,
+                               (const FrameState *)frame, fv);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
