@@ -36,6 +36,10 @@ constexpr float FIX_SCALE = 65536.0f;
 constexpr float FIX_LIMIT = 2048.0f;       // below: |q| < 2^27, the int32 / int64 fast path
 constexpr float FIX_CLAMP = 16777216.0f;   // 2^24 m: |q| <= 2^40, the wide path of the rare far points
 
+// SegState::pad[1] is the pass a record is the state of (what a chained plane pass waits for, plane_chain_kernel); the seed
+// kernels, which write S_0 into set 0, mark the record the LAST call left in set 1 with a number no pass has
+constexpr uint32_t SEG_STATE_STALE = 0xffffffffu;
+
 struct SegParams
 {
     uint32_t n;        // points in the frame      } host values are the maximum over the frames of the
@@ -377,6 +381,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seed_kernel(const uint64_t *__res
         o.thr = 0.0f;
         o.pad[0] = o.pad[1] = 0;
         st[s] = o;
+        st[LPX_MAX_PARTITIONS + s].pad[1] = SEG_STATE_STALE;  // (set 1 still holds the last call's record)
     }
 }
 
@@ -702,6 +707,7 @@ __global__ __launch_bounds__(THREADS) void seed_select_kernel(const float *__res
         o.thr = 0.0f;
         o.pad[0] = o.pad[1] = 0;
         st[s] = o;
+        st[LPX_MAX_PARTITIONS + s].pad[1] = SEG_STATE_STALE;  // (set 1 still holds the last call's record)
     }
 }
 #undef SEL_REM
@@ -924,6 +930,7 @@ __global__ __launch_bounds__(SEL_THREADS) void selw_final_kernel(SegParams prm, 
             o.thr = 0.0f;
             o.pad[0] = o.pad[1] = 0;
             st[s] = o;
+            st[LPX_MAX_PARTITIONS + s].pad[1] = SEG_STATE_STALE;  // (set 1 still holds the last call's record)
         }
         return;
     }
@@ -963,6 +970,7 @@ __global__ __launch_bounds__(SEL_THREADS) void selw_final_kernel(SegParams prm, 
         o.thr = 0.0f;
         o.pad[0] = o.pad[1] = 0;
         st[s] = o;
+        st[LPX_MAX_PARTITIONS + s].pad[1] = SEG_STATE_STALE;  // (set 1 still holds the last call's record)
     }
 }
 
@@ -1936,13 +1944,14 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_chain_k
 // compaction: flags -> labels (original order), ground / obstacle index lists in output-cloud
 // order (:331-343, Q7) and the obstacle SoA handed to clustering.
 // ------------------------------------------------------------------------------------------------
+template <bool BYTE_LABELS>  // large frames: one byte per point into an L2-resident scratch (labels_widen_kernel follows)
 __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__restrict__ flags,
                                                                const uint32_t *__restrict__ sidx,
                                                                const float *__restrict__ XS,
                                                                const float *__restrict__ YS,
                                                                const float *__restrict__ ZS, SegParams prm,
                                                                const uint32_t *__restrict__ blk_offs,
-                                                               uint8_t *__restrict__ lab8,
+                                                               uint8_t *__restrict__ lab8, uint32_t *__restrict__ labels,
                                                                uint32_t *__restrict__ gidx, uint32_t *__restrict__ oidx,
                                                                float *__restrict__ OX, float *__restrict__ OY,
                                                                float *__restrict__ OZ, float4 *__restrict__ nodes,
@@ -1965,6 +1974,7 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     st = lpx_slot(st, fv.fs);
     frame = lpx_slot(frame, fv.fs);
     lab8 = lpx_slot(lab8, fv.fs);
+    labels = lpx_user(labels, fv.upitch);
     gidx = lpx_user(gidx, fv.upitch);
     oidx = lpx_user(oidx, fv.upitch);
     planes = lpx_user(planes, 4u * prm.P);
@@ -2074,7 +2084,10 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
             if (in)
             {
                 const uint32_t i = si[r];
-                lab8[i] = (uint8_t)f[r];  // one BYTE by original index: see labels_widen_kernel
+                if (BYTE_LABELS)
+                    lab8[i] = (uint8_t)f[r];  // one BYTE by original index: see labels_widen_kernel
+                else
+                    labels[i] = f[r];
                 if (f[r] == 1u)
                     gidx[gpos + __popcll(mg & lt)] = i;
                 else if (f[r] == 2u)
@@ -2109,7 +2122,12 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     {
         // the N mod P highest-x points belong to no segment (Q2); written UNKNOWN (Q3)
         for (uint32_t p = prm.P * prm.n_per + tid; p < prm.n; p += SEG_THREADS)
-            lab8[sidx[p]] = (uint8_t)LPX_LABEL_UNKNOWN;
+        {
+            if (BYTE_LABELS)
+                lab8[sidx[p]] = (uint8_t)LPX_LABEL_UNKNOWN;
+            else
+                labels[sidx[p]] = LPX_LABEL_UNKNOWN;
+        }
         if (tid == 0)
         {
             frame->n_ground = total_g;
@@ -2125,10 +2143,12 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
 // original index is random with respect to that order, so writing the caller's 4-byte label from there touched a
 // different line with every store -- a 1M-point frame's 4 MB label array does not stay in an XCD's L2 beside the other
 // frames of a chain, every store went out as a partial line and the kernel moved 3.5 x its algorithmic bytes (round 5:
-// 15 % of the HBM roofline).  Now the compaction scatters ONE BYTE per point into a frame-sized scratch (1 MB per
-// million points: resident in the frame's L2, where the partial stores merge and every line leaves once), and this
-// kernel streams the bytes out as the caller's 32-bit labels: 16 points per thread, one 16-byte load, four 16-byte
+// 15 % of the HBM roofline).  Frames of more than LABEL_BYTES_FROM points now scatter ONE BYTE per point into a
+// frame-sized scratch (1 MB per million points: resident in the frame's L2, where the partial stores merge and every
+// line leaves once), and this kernel streams the bytes out as the caller's 32-bit labels (1M-point chains: 583 -> 408 +
+// 45 us; a 120k-point frame's 0.5 MB of labels merge in L2 as they are, there the second launch would only cost): 16 points per thread, one 16-byte load, four 16-byte
 // stores (VEC: the caller's array and pitch are 16-byte aligned; otherwise word stores).
+constexpr uint32_t LABEL_BYTES_FROM = 262144u;  // points of the largest frame of a call
 template <bool VEC>
 __global__ __launch_bounds__(256) void labels_widen_kernel(const uint8_t *__restrict__ lab8, uint32_t *__restrict__ labels,
                                                            const FrameState *__restrict__ frame, FV fv)
@@ -2568,18 +2588,26 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
         StageTimer tm(ctx, ST_COMPACT);
         // (the byte labels live in the second key buffer of the x sort: free from the sort's last pass to the clustering)
         uint8_t *const lab8 = (uint8_t *)ctx->key_b.p;
-        hipLaunchKernelGGL(compact_kernel, dim3(prm.bps, P, B), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p,
-                           sidx, XS, YS, ZS, prm, blk_counts, lab8, d_gidx, d_oidx, (float *)ctx->OX.p,
-                           (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p,
-                           sst + (size_t)(I & 1u) * LPX_MAX_PARTITIONS,  // the state the head of the final pass published
-                           d_planes, frame, fv);
-        const dim3 gw((n + 4095u) / 4096u, 1, B);
-        if ((((uintptr_t)d_labels | ((size_t)fv.upitch * sizeof(uint32_t))) & 15u) == 0)
-            hipLaunchKernelGGL(labels_widen_kernel<true>, gw, dim3(256), 0, st, (const uint8_t *)lab8, d_labels,
-                               (const FrameState *)frame, fv);
+        const bool byte_labels = n > LABEL_BYTES_FROM;
+#define LPX_COMPACT_ARGS                                                                                               \
+    dim3(prm.bps, P, B), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p, sidx, XS, YS, ZS, prm, blk_counts, lab8, \
+        d_labels, d_gidx, d_oidx, (float *)ctx->OX.p, (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p,     \
+        sst + (size_t)(I & 1u) * LPX_MAX_PARTITIONS, /* the state the head of the final pass published */               \
+        d_planes, frame, fv
+        if (!byte_labels)
+            hipLaunchKernelGGL(compact_kernel<false>, LPX_COMPACT_ARGS);
         else
-            hipLaunchKernelGGL(labels_widen_kernel<false>, gw, dim3(256), 0, st, (const uint8_t *)lab8, d_labels,
-                               (const FrameState *)frame, fv);
+        {
+            hipLaunchKernelGGL(compact_kernel<true>, LPX_COMPACT_ARGS);
+            const dim3 gw((n + 4095u) / 4096u, 1, B);
+            if ((((uintptr_t)d_labels | ((size_t)fv.upitch * sizeof(uint32_t))) & 15u) == 0)
+                hipLaunchKernelGGL(labels_widen_kernel<true>, gw, dim3(256), 0, st, (const uint8_t *)lab8, d_labels,
+                                   (const FrameState *)frame, fv);
+            else
+                hipLaunchKernelGGL(labels_widen_kernel<false>, gw, dim3(256), 0, st, (const uint8_t *)lab8, d_labels,
+                                   (const FrameState *)frame, fv);
+        }
+#undef LPX_COMPACT_ARGS
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;
