@@ -247,8 +247,51 @@ static int set_fields(lpx_ctx *ctx, size_t point_step, uint32_t off_x, uint32_t 
     return LPX_OK;
 }
 
+// The list workspace grows on evidence (lpx_internal.h: nb_per_point): the records the list-mode clusterings of this
+// context have left in pinned memory since the last look -- only those whose sequence number says they are complete --
+// raise the words per point of the two regions to 1.25 x the largest demand.  The reallocation itself happens in
+// lpx_ensure_capacity right after (it waits for the stream: rare, and never for a scene the workspace has seen).
+static void lists_grow_on_evidence(lpx_ctx *ctx)
+{
+    if (!ctx->use_lists || !ctx->h_liststat || !ctx->cap_n || ctx->list_seq == ctx->list_seq_seen)
+        return;
+    uint32_t newest = ctx->list_seq_seen;
+    for (uint32_t b = 0; b < ctx->batch; ++b)
+    {
+        const uint32_t seq = __atomic_load_n(&ctx->h_liststat[b].seq, __ATOMIC_ACQUIRE);
+        if ((int32_t)(seq - ctx->list_seq_seen) <= 0 || (int32_t)(seq - ctx->list_seq) > 0)
+            continue;  // looked at already, or not a record of this context's calls
+        const LpxListStat e = ctx->h_liststat[b];
+        if (e.seq != seq)
+            continue;  // (being rewritten by a later call: that call's record will be looked at next time)
+        newest = (int32_t)(seq - newest) > 0 ? seq : newest;
+        const uint64_t stripe_cap = ctx->cap_rs / LPX_RS_STRIPES;
+        if (e.stripe_max > stripe_cap && ctx->cap_rs)
+        {
+            const uint64_t want = (e.stripe_max + e.stripe_max / 4) * LPX_RS_STRIPES;
+            const uint64_t per = (want + ctx->cap_n - 1) / ctx->cap_n;
+            if (per > ctx->rs_per_point)
+                ctx->rs_per_point = (uint32_t)(per < 4096 ? per : 4096);
+        }
+        if (e.nb_total > ctx->cap_nb)
+        {
+            const uint64_t want = e.nb_total + e.nb_total / 4;
+            const uint64_t per = (want + ctx->cap_n - 1) / ctx->cap_n;
+            if (per > ctx->nb_per_point)
+                ctx->nb_per_point = (uint32_t)(per < 8192 ? per : 8192);
+        }
+    }
+    ctx->list_seq_seen = newest;
+    if (ctx->twin)
+    {
+        ctx->twin->nb_per_point = ctx->nb_per_point > ctx->twin->nb_per_point ? ctx->nb_per_point : ctx->twin->nb_per_point;
+        ctx->twin->rs_per_point = ctx->rs_per_point > ctx->twin->rs_per_point ? ctx->rs_per_point : ctx->twin->rs_per_point;
+    }
+}
+
 static int ensure_for(lpx_ctx *ctx, uint32_t n)
 {
+    lists_grow_on_evidence(ctx);
     uint64_t nb = (uint64_t)n * ctx->nb_per_point;
     if (nb > 0xfffffff0ull)
         nb = 0xfffffff0ull;  // offsets are 32-bit
@@ -459,6 +502,10 @@ static int create_common(int device, hipStream_t stream, bool own, uint32_t batc
         memset(ctx->h_search, 0, 6 * sizeof(uint64_t));
     else
         ctx->h_search = nullptr;
+    if (hipHostMalloc((void **)&ctx->h_liststat, sizeof(LpxListStat) * batch, hipHostMallocDefault) == hipSuccess)
+        memset(ctx->h_liststat, 0, sizeof(LpxListStat) * batch);
+    else
+        ctx->h_liststat = nullptr;  // (no evidence, no growth: the workspace stays what lpx_reserve made it)
     ctx->reg_index = reg_claim(device, batch);
     ctx->use_lists = batch == 1;  // LPX_NEIGHBOURS_AUTO
     int rc;
@@ -576,6 +623,8 @@ extern "C" void lpx_destroy(lpx_ctx *ctx)
         hipStreamDestroy(ctx->stream);
     if (ctx->h_search)
         hipHostFree(ctx->h_search);
+    if (ctx->h_liststat)
+        hipHostFree(ctx->h_liststat);
     if (ctx->reg_index >= 0)
         g_reg[ctx->reg_index].device.store(-1);
     delete ctx;
@@ -883,6 +932,22 @@ static int check_clu(lpx_ctx *ctx, const lpx_clu_cfg *c, size_t stride, bool pcl
         return lpx_fail(ctx, LPX_ERR_ARG, "stride must be a multiple of 4 and at least 12 bytes");
     if (!(c->distance_squared >= 0.0f) || !(c->distance_squared < 3.0e38f))
         return lpx_fail(ctx, LPX_ERR_ARG, "distance_squared must be finite and >= 0");
+    // The list workspace's prior: a point's list grows with the surface its ball cuts out of the scene, i.e. with d^2.  The
+    // defaults (64 + 192 words per point) are sized for the reference's d = 0.5 m; a larger radius scales them before the
+    // first frame is seen -- up to 4 x, the 256 + 768 words of rounds 1-5, which carried every d = 1 m scene of
+    // tools/fuzz.py -- and the evidence of the frames themselves takes over from there (lists_grow_on_evidence).
+    if (ctx->use_lists)
+    {
+        const float scale = c->distance_squared / 0.25f;
+        const uint32_t k = scale <= 1.0f ? 1u : (scale >= 4.0f ? 4u : (uint32_t)ceilf(scale));
+        for (lpx_ctx *t = ctx; t; t = (t == ctx ? ctx->twin : nullptr))
+        {
+            if (64u * k > t->nb_per_point)
+                t->nb_per_point = 64u * k;
+            if (192u * k > t->rs_per_point)
+                t->rs_per_point = 192u * k;
+        }
+    }
     return LPX_OK;
 }
 

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void flatten_kernel(uint32_t *parent, const Fr
                                                       uint32_t *__restrict__ root, uint32_t *__restrict__ iota,
                                                       uint8_t *__restrict__ state, uint32_t *__restrict__ valid,
                                                       uint32_t *__restrict__ cc_lo, uint32_t *__restrict__ cc_hi,
-                                                      uint32_t *__restrict__ hist, size_t fs)
+                                                      uint32_t *__restrict__ hist, LpxListStat *hstat, uint32_t seq,
+                                                      size_t fs)
 {
     const LpxBlock lpx_blk = lpx_block<6>(fs);
     __shared__ uint32_t h[256];
@@ -54,6 +55,20 @@ __global__ __launch_bounds__(256) void flatten_kernel(uint32_t *parent, const Fr
     hist = lpx_slot(hist, fs);
     const uint32_t tid = threadIdx.x, M = frame->n_obstacle;
     const bool forest = !frame->status;  // (a frame whose lists did not fit has no forest: every point its own root)
+    if (hstat && lpx_blk.x == 0 && tid == 0)
+    {
+        // list path: what this frame asked of the list workspace, for the host's sizing of the NEXT call (pinned memory)
+        LpxListStat *o = hstat + lpx_blk.z;
+        uint64_t mx = 0;
+        for (uint32_t i = 0; i < LPX_RS_STRIPES; ++i)
+            mx = frame->rs_stripe[i].v > mx ? frame->rs_stripe[i].v : mx;
+        o->nb_total = frame->nb_total;
+        o->stripe_max = mx;
+        o->status = frame->status;
+        o->n_obstacle = M;
+        __threadfence_system();
+        __hip_atomic_store(&o->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (hist)
     {
         h[tid] = 0;
@@ -1302,7 +1317,9 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
         uint32_t *const iota_out = skip_sort ? iota : (uint32_t *)nullptr;
         if (ctx->use_lists || lpx_cc_from_chunks(m_max) || sweep_cc)
             hipLaunchKernelGGL(flatten_kernel, gtile, blk, 0, st, (uint32_t *)ctx->parent.p, frame, root, iota_out,
-                               (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, first_hist, fv.fs);
+                               (uint8_t *)ctx->state.p, valid, cc_lo, cc_hi, first_hist,
+                               ctx->use_lists ? ctx->h_liststat : (LpxListStat *)nullptr,
+                               ctx->use_lists ? ++ctx->list_seq : 0u, fv.fs);
         else if (grid_cc && !skip_grid)
             rc = lpx_grid_flatten(ctx, m_max, root, iota_out, first_hist);
         if (rc)

@@ -151,6 +151,17 @@ struct ChunkRec
     float lo[3], hi[3];
 };
 
+// what a list-mode clustering asked of the list workspace (one record per frame slot, in pinned host memory, written by
+// thread 0 of flatten_kernel once the neighbour kernel of the call is done; seq last)
+struct LpxListStat
+{
+    uint64_t nb_total;       // words the exact-length region was asked for (groups that found no single-pass room)
+    uint64_t stripe_max;     // largest demand on one of the LPX_RS_STRIPES sub-regions of the single-pass region
+    uint32_t status, n_obstacle;
+    uint32_t seq;            // lpx_ctx::list_seq of the call that wrote the record
+    uint32_t pad;
+};
+
 struct Buf
 {
     void *p = nullptr;
@@ -208,10 +219,19 @@ struct lpx_ctx
 
     uint32_t cap_n = 0;        // points per frame slot
     uint64_t cap_nb = 0;       // neighbour entries per frame slot
-    uint32_t nb_per_point = 256;  // (192 + 256 was tried in round 5: 221 instead of 379 MB per 123k-point frame at the same latency,
-                                  // but a DEVICE call cannot retry, and d = 1 m on a dense cloud needs more: tools/fuzz.py)
+    // List workspace per point of the slot: 64 words of exact-length lists + 192 words of single-pass lists (126 MB for a
+    // 123k-point frame, 5.1 GB for a 5M-point one; rounds 1-5: 256 + 512, 379 MB / 15.4 GB) -- enough for the reference's
+    // frames at d = 0.5 m but for the densest and for BASELINE's synthetic clouds.  It GROWS on evidence: every list-mode
+    // clustering leaves what it asked for in pinned memory (LpxListStat, written by flatten_kernel), the next call on the
+    // context sizes the regions to 1.25 x the largest demand seen (lists_grow_on_evidence, lpx_api.hip).  A frame that
+    // outgrows the workspace before that still reports LPX_ERR_CAPACITY: the host calls repeat it (cluster_resident),
+    // a device call's caller sees the status of that ONE frame and may lpx_reserve() ahead for dense scenes.
+    uint32_t nb_per_point = 64;
     uint64_t cap_rs = 0;       // words of the single-pass list region per frame slot (behind the cap_nb words)
-    uint32_t rs_per_point = 512;
+    uint32_t rs_per_point = 192;
+    struct LpxListStat *h_liststat = nullptr;  // pinned, one record per frame slot
+    uint32_t list_seq = 0;         // list-mode clusterings enqueued on this context
+    uint32_t list_seq_seen = 0;    // ... whose demand has been looked at
     uint32_t batch = 1;        // frame slots
     uint32_t cur_b = 1;        // frames of the call being enqueued (gridDim.z)
     uint32_t in_off[3] = {0, 4, 8};  // byte offsets of x, y, z inside a record of the call being enqueued
