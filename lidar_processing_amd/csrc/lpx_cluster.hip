@@ -165,112 +165,135 @@ struct ReplayParams
     float thr_f;  // largest float <= thr: for a float d, (double)d <= thr  <=>  d <= thr_f
     float r2;     // distance_squared (list membership)
     uint32_t min_size, max_size;
+    uint32_t dbg_rows;  // rows of the tools-only statistics buffer (0: none)
 };
 
 constexpr int RP_DEPTH = 4;    // neighbour lists kept in flight ahead of the expansion being processed
 constexpr int RP_RING = 4096;  // queue entries mirrored in LDS by replay_lds_kernel
+constexpr int RP_STAGE = 512;  // first touches of a queue window held in LDS until their seed_of stores go out
+typedef __attribute__((address_space(3))) uint32_t lds_u32;  // LDS words by their own address space: ds_* instructions, not flat_*
 
-// Same replay with the point states in LDS: 2 bits per point over the whole index range (bit 0 queued,
-// bit 1 removed), one wavefront per workgroup.  Removes the global round trip from the dependent chain
-// of every step; list chunks are loaded four at a time; offsets/lengths are fetched with the queue
-// window.  STATE_LDS is used when the bitmap fits (M <= 393 216 points), which covers every real frame; beyond
-// that (a 5M-point cloud) the same sequencer keeps one byte per point in HBM (`gstate`, zeroed by flatten_kernel) and
-// pays a block-level fence per list step, but keeps the window, the ring and the lists in flight.
-template <bool STATE_LDS>
-__global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__restrict__ frame,
-                                                           const uint32_t *__restrict__ cc_lo,
-                                                           const uint32_t *__restrict__ cc_hi,
-                                                           const uint32_t *__restrict__ members,
-                                                           const uint32_t *__restrict__ nb_off,
-                                                           const uint32_t *__restrict__ nb_len,
-                                                           const uint32_t *__restrict__ nb_idx,
-                                                           const float *__restrict__ OX, const float *__restrict__ OY,
-                                                           const float *__restrict__ OZ, int32_t *seed_of,
-                                                           uint32_t *queue, uint32_t *valid, ReplayParams prm,
-                                                           uint64_t cap, FrameState *fstate,
-                                                           const uint32_t *__restrict__ roots,
-                                                           uint32_t *__restrict__ dbg, uint8_t *gstate, FV fv)
+// The list replay: one sequencer wavefront per workgroup, components from a work list.  Where the 2-bit point states
+// (bit 0 queued, bit 1 removed) live is the template argument:
+//   RP_STATE_LDS    a bitmap over the WHOLE index range in LDS (M <= 393 216 points: every real frame).  No global round
+//                   trip in the dependent chain of a step; list chunks are loaded four at a time; offsets / lengths are
+//                   fetched with the queue window.
+//   RP_STATE_HBM    one byte per point in HBM (`gstate`, zeroed by flatten_kernel): a dependent global round trip and a
+//                   block-level fence per list step.  Rounds 2-5 ran every larger cloud this way: a 5M-point frame's
+//                   replay lasted as long as its largest component's chain -- 3 964 expansions at ~2 500 cycles each, 4.3
+//                   of the frame's 13.9 ms (tools/r6_replay5m.py).
+//   RP_STATE_LOCAL  (round 6) a bitmap over the COMPONENT's points in LDS, indexed by a point's position in the member
+//                   list (`pos_of`, written by pos_of_kernel).  A component owns its points, so nothing else is ever
+//                   asked; 65 536 members fit 16 KiB.  The position of a list entry is one more gather, but an
+//                   INDEPENDENT one: it is requested two expansions ahead, right behind the list that is requested four
+//                   ahead, and the chain of a step is LDS only -- as in RP_STATE_LDS.  Components beyond the capacity
+//                   take the HBM form inside the same kernel.
+enum
 {
-    const LpxBlock lpx_blk = lpx_block<7>(fv.fs);
-    extern __shared__ uint32_t sbits[];
-    frame = lpx_slot(frame, fv.fs);
-    fstate = lpx_slot(fstate, fv.fs);
-    cc_lo = lpx_slot(cc_lo, fv.fs);
-    cc_hi = lpx_slot(cc_hi, fv.fs);
-    members = lpx_slot(members, fv.fs);
-    nb_off = lpx_slot(nb_off, fv.fs);
-    nb_len = lpx_slot(nb_len, fv.fs);
-    nb_idx = lpx_slot(nb_idx, fv.fs_nb);
-    OX = lpx_slot(OX, fv.fs);
-    OY = lpx_slot(OY, fv.fs);
-    OZ = lpx_slot(OZ, fv.fs);
-    seed_of = lpx_slot(seed_of, fv.fs);
-    queue = lpx_slot(queue, fv.fs);
-    valid = lpx_slot(valid, fv.fs);
-    roots = lpx_slot(roots, fv.fs);
-    gstate = lpx_slot(gstate, fv.fs);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t M = frame->n_obstacle;
-    if (frame->nb_total > cap)
-        return;
-    const uint32_t n_roots = frame->n_roots;
-    if (lpx_blk.x >= n_roots)
-        return;
-    // the bitmap is zeroed once: components own disjoint points, so the 2-bit states of one component
-    // are never read by another
-    const uint32_t words = STATE_LDS ? (M + 15) / 16 : 0u;
-    for (uint32_t i = lane; i < words; i += WAVE)
-        sbits[i] = 0;
-    // the most recent RP_RING queue entries are mirrored in LDS: a window of pops is then read without
-    // waiting for the global queue stores (the global queue remains the fallback for long queues)
-    uint32_t *ring = sbits + ((words + 3) & ~3u);
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long st_entries = 0;
-    uint32_t st_exp = 0;
-  for (;;)
-  {
-    uint32_t ticket = 0;
-    if (lane == 0)
-        ticket = atomicAdd(&fstate->root_cursor, 1u);
-    ticket = __shfl(ticket, 0, 64);
-    if (ticket >= n_roots)
-        break;
-    const uint32_t r = roots[ticket];
-    const uint32_t lo = cc_lo[r], hi = cc_hi[r];
-    const unsigned long long cc_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long cc_e0 = st_entries;
-    const uint32_t cc_x0 = st_exp;
-    uint32_t cc_windows = 0, cc_seeds = 0;
-#define ST_GET(k) (STATE_LDS ? ((sbits[(k) >> 4] >> (((k) & 15u) * 2u)) & 3u) : (uint32_t)gstate[k])
+    RP_STATE_LDS = 0,
+    RP_STATE_HBM = 1,
+    RP_STATE_LOCAL = 2
+};
+constexpr uint32_t RP_LOCAL_CAP = 65536;  // members of a component whose states fit the local bitmap
+
+struct ReplayArrays
+{
+    const uint32_t *members, *nb_off, *nb_len, *nb_idx, *pos_of;
+    const float *OX, *OY, *OZ;
+    int32_t *seed_of;
+    uint32_t *queue, *valid;
+    uint8_t *gstate;
+};
+
+template <int MODE>
+__device__ __forceinline__ void replay_component(const ReplayArrays &A, const ReplayParams &prm, uint32_t lo, uint32_t hi,
+                                                 lds_u32 *sbits, lds_u32 *ring, lds_u32 *stg, uint32_t lane,
+                                                 unsigned long long &st_entries, uint32_t &st_exp, uint32_t &cc_windows,
+                                                 uint32_t &cc_seeds, unsigned long long *ph)
+{
+    // GLOBAL STORES AND THE LOAD PIPELINE (round 6).  vmcnt counts loads and stores alike, and the two complete out of
+    // order with respect to each other: while a store is pending, a wait for ANY load is `s_waitcnt vmcnt(0)` -- the
+    // compiler has no other choice, and it decides per loop, not per trip.  Rounds 1-5 stored seed_of[k] and queue[qi]
+    // right where a list step produced them; every wait of the sequencer was therefore a wait for everything, the lists
+    // "in flight ahead" included: one full memory round trip per expansion, whatever the pipeline depth (replay_lds_kernel:
+    // 26 of 33 waits were vmcnt(0)).  Now the loop that walks the expansions of a window issues NO global store (LDS and
+    // LOCAL forms; the HBM form's state bytes are what it is the fallback for): first touches are staged in LDS (`stg`),
+    // pushes go to the ring only, and both reach memory between windows (stores_out), where the next window's gathers
+    // wait for everything anyway.  A stage or ring that fills up inside a window drains at once, with an explicit wait
+    // behind it, so that the loop's other trips stay store-free for the compiler's counting.
+    // tools only (ph != nullptr): cycles of this component's sequencer by phase -- 0 seed search, 1 window set-up (ring,
+    // gathers, selection), 2 the wait for the first lists / positions of a window, 3 applying the lists
+#define RP_LAP(i)                                                                                                     \
+    do                                                                                                                \
+    {                                                                                                                 \
+        if (ph)                                                                                                       \
+        {                                                                                                             \
+            const unsigned long long n_ = __builtin_amdgcn_s_memtime();                                               \
+            ph[i] += n_ - ph_t;                                                                                       \
+            ph_t = n_;                                                                                                \
+        }                                                                                                             \
+    } while (0)
+    unsigned long long ph_t = ph ? __builtin_amdgcn_s_memtime() : 0ull;
+    // state id of a point: its index (LDS / HBM forms) or its position in the component (LOCAL)
+#define ST_GET(k) (MODE == RP_STATE_HBM ? (uint32_t)A.gstate[k] : ((sbits[(k) >> 4] >> (((k) & 15u) * 2u)) & 3u))
 #define ST_OR(k, v)                                                                                                   \
     do                                                                                                                \
     {                                                                                                                 \
-        if (STATE_LDS)                                                                                                \
-            atomicOr(&sbits[(k) >> 4], (uint32_t)(v) << (((k) & 15u) * 2u));                                         \
+        if (MODE == RP_STATE_HBM)                                                                                     \
+            A.gstate[k] = (uint8_t)(A.gstate[k] | (v));                                                               \
         else                                                                                                          \
-            gstate[k] = (uint8_t)(gstate[k] | (v));                                                                   \
+            __hip_atomic_fetch_or(&sbits[(k) >> 4], (uint32_t)(v) << (((k) & 15u) * 2u), __ATOMIC_RELAXED,                 \
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);                                         \
     } while (0)
+    // lists in flight ahead of the expansion being processed (LOCAL: the positions half as far ahead).  The large clouds
+    // that take the LOCAL / HBM forms read their lists from HBM or the Infinity Cache (~1 us): eight ahead
+    constexpr int DEPTH = MODE == RP_STATE_LDS ? RP_DEPTH : 2 * RP_DEPTH;
+    // chunks of 64 list words a slot of the pipeline holds: lists of up to 64 CH entries are fetched ahead in full (the
+    // reference's frames at d = 0.5 m: ~140 entries on average, several hundred where the scene is dense), longer ones
+    // take their tail straight from memory (tail loop below)
+    constexpr int CH = MODE == RP_STATE_LDS ? 4 : 2;
+    // UNCOND: every load of the pipeline is issued whether or not there is something to fetch (below).  The LDS form keeps
+    // its loads conditional: its lists come from the L2 / Infinity Cache of a frame that is alone on the device, an
+    // expansion costs ~650 cycles there -- the apply itself -- and the dummy loads of the unconditional form only add
+    // instructions (a 123k-point frame alone: 1.70 -> 1.77 ms with them)
+    constexpr bool UNCOND = MODE != RP_STATE_LDS;
+    // ... and its stores where a list step produces them (DEFER off): there the staging below is one ballot, one LDS
+    // write, one LDS read and a loop more per step of an instruction-bound sequencer (the densest of the three committed
+    // frames alone: 2.73 -> 3.11 ms with it)
+    constexpr bool DEFER = MODE != RP_STATE_LDS;
     const unsigned long long lt = lpx_lanemask_lt();
-    uint32_t *q = queue + lo;
+    if (MODE == RP_STATE_LOCAL)
+    {
+        // this component's bitmap (the work list hands a sequencer one component after the other)
+        for (uint32_t i = lane; i < (hi - lo + 15u) / 16u; i += WAVE)
+            sbits[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t *q = A.queue + lo;
     uint32_t cursor = lo;
     for (;;)
     {
-        uint32_t seed = 0xffffffffu;
+        uint32_t seed = 0xffffffffu, seed_sid = 0;
+        uint32_t sc = 0;      // first touches staged (wave-uniform)
+        uint32_t q_done = 1;  // queue entries [0, q_done) are in the global queue (the seed is)
         while (cursor < hi)
         {
             const uint32_t p = cursor + lane;
-            const uint32_t cand = (p < hi) ? members[p] : 0u;
-            const bool ok = (p < hi) && !(ST_GET(cand) & 2u);
+            const uint32_t cand = (p < hi) ? A.members[p] : 0u;
+            const uint32_t sid = MODE == RP_STATE_LOCAL ? ((p < hi) ? p - lo : 0u) : cand;
+            const bool ok = (p < hi) && !(ST_GET(sid) & 2u);
             const unsigned long long m = __ballot(ok);
             if (m)
             {
                 const int f = __ffsll((long long)m) - 1;
                 seed = __shfl(cand, f, 64);
+                seed_sid = __shfl(sid, f, 64);
                 cursor += f + 1;
                 break;
             }
             cursor += WAVE;
         }
+        RP_LAP(0);
         if (seed == 0xffffffffu)
             break;
         uint32_t qh = 0, qt = 1;
@@ -279,11 +302,23 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
         {
             q[0] = seed;
             ring[0] = seed;
-            ST_OR(seed, 1u);
-            seed_of[seed] = (int32_t)seed;  // queued before it is ever touched
+            ST_OR(seed_sid, 1u);
+            A.seed_of[seed] = (int32_t)seed;  // queued before it is ever touched
         }
-        if (!STATE_LDS)
+        if (MODE == RP_STATE_HBM)
             __threadfence_block();
+        auto stores_out = [&]() {
+            if (!DEFER)
+                return;
+            for (uint32_t b0 = 0; b0 < sc; b0 += WAVE)
+                if (b0 + lane < sc)
+                    A.seed_of[stg[b0 + lane]] = (int32_t)seed;  // first touch; later touches carry the same seed
+            sc = 0;
+            for (uint32_t j0 = q_done; j0 < qt; j0 += WAVE)
+                if (j0 + lane < qt)
+                    q[j0 + lane] = ring[(j0 + lane) % RP_RING];
+            q_done = qt;
+        };
         // The queue is consumed in windows of up to 64 pops.  Which of a window's candidates the reference
         // expands is decided inside the window: candidate c is skipped iff it is already removed, or an
         // EXPANDED earlier candidate h of the window holds it within the absorb radius (c is then in h's
@@ -300,15 +335,47 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                 wcand = inw ? ring[(wb + lane) % RP_RING] : 0u;  // LDS: in order with the pushes of this wave
             else
             {
+                // (more entries pending than the ring holds: the window comes from the global queue, which stores_out
+                // keeps complete before a ring slot is reused)
+                if (DEFER)
+                {
+                    stores_out();
+                    __builtin_amdgcn_s_waitcnt(0);
+                }
                 __threadfence_block();  // queue entries pushed by other lanes
                 wcand = inw ? q[wb + lane] : 0u;
             }
-            const bool alive = inw && !(ST_GET(wcand) & 2u);
-            // unconditional loads (index 0 for idle lanes): the five gathers are issued back to back
-            const uint32_t ci = alive ? wcand : 0u;
-            const uint32_t woff = nb_off[ci];
-            const uint32_t wlen = alive ? nb_len[ci] : 0u;
-            const float wx = OX[ci], wy = OY[ci], wz = OZ[ci];
+            // LOCAL: the candidates' positions in the component -- a gather like the five below, but the states are
+            // asked first, so this one is waited for
+            uint32_t wsid, woff, wlen;
+            float wx, wy, wz;
+            bool alive;
+            if (MODE == RP_STATE_LDS)
+            {
+                wsid = wcand;
+                alive = inw && !(ST_GET(wsid) & 2u);
+                // unconditional loads (index 0 for idle lanes): the five gathers are issued back to back
+                const uint32_t ci = alive ? wcand : 0u;
+                woff = A.nb_off[ci];
+                wlen = alive ? A.nb_len[ci] : 0u;
+                wx = A.OX[ci], wy = A.OY[ci], wz = A.OZ[ci];
+            }
+            else
+            {
+                // the states are a global round trip away (HBM) or behind one (LOCAL: the position): the five gathers go
+                // out WITH it, for every candidate of the window, instead of waiting to know which are alive -- one
+                // dependent trip less per window (a window holds ~9 expansions on a 5M-point cloud: four trips were 45 %
+                // of the largest component's chain)
+                const uint32_t ci = wcand;  // (0 for idle lanes)
+                const uint32_t wpos = MODE == RP_STATE_LOCAL ? A.pos_of[ci] : 0u;
+                const uint32_t wst = MODE == RP_STATE_HBM ? (uint32_t)A.gstate[ci] : 0u;
+                woff = A.nb_off[ci];
+                const uint32_t wlen_raw = A.nb_len[ci];
+                wx = A.OX[ci], wy = A.OY[ci], wz = A.OZ[ci];
+                wsid = MODE == RP_STATE_LOCAL ? (inw ? wpos - lo : 0u) : wcand;
+                alive = inw && !((MODE == RP_STATE_HBM ? wst : ST_GET(wsid)) & 2u);
+                wlen = alive ? wlen_raw : 0u;
+            }
             ++cc_windows;
             unsigned long long am = __ballot(alive), em = 0;
             while (am)
@@ -325,34 +392,63 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                 am &= ~(1ull << h);
             }
             qh = wb + wn;
+            RP_LAP(1);
             if (!em)
                 continue;
-            // software pipeline, RP_DEPTH lists in flight: slot s holds the first four chunks of the
-            // expansion that will be processed RP_DEPTH steps after the one that last used the slot
-            uint32_t K4[RP_DEPTH][4];  // words index | absorb << 31; 0xffffffff past the end of the list
+            // software pipeline, DEPTH lists in flight: slot s holds the first four chunks of the
+            // expansion that will be processed DEPTH steps after the one that last used the slot.
+            // LOCAL: a second stage DEPTH / 2 steps ahead gathers the positions of the entries of the list
+            // that has arrived by then (P4: state ids; 0xffffffff past the end of the list).
+            // (K4 / P4 hold what the loads return, untouched: a select on a loaded value is a use, and a use is a wait --
+            // lanes past the end of a list are masked where the words are applied, from the list's length)
+            uint32_t K4[DEPTH][CH];  // words index | absorb << 31
+            uint32_t P4[DEPTH / 2][CH];
+            uint32_t KC[DEPTH];      // entries of the list in the slot (wave-uniform)
             unsigned long long lm = em;  // expansions whose list still has to be requested
+            unsigned long long pm = em;  // ... whose positions still have to be requested (LOCAL)
+            // EVERY load of the pipeline is issued unconditionally (an address of 0 where there is nothing to fetch, the
+            // value discarded): a load behind a branch -- `if (lm)`, or the per-lane `t < cg` the compiler turns into one --
+            // leaves the number of loads YOUNGER than the one being waited for unknown, and the only safe wait is then
+            // vmcnt(0) again.
 #pragma unroll
-            for (int sl = 0; sl < RP_DEPTH; ++sl)
+            for (int sl = 0; sl < DEPTH; ++sl)
             {
-                if (lm)
-                {
-                    const int g = __ffsll((long long)lm) - 1;
-                    lm &= lm - 1;
-                    const uint32_t og = (uint32_t)__builtin_amdgcn_readlane((int)woff, g);
-                    const uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)wlen, g);
+                const int g = lm ? __ffsll((long long)lm) - 1 : 0;
+                const uint32_t og = (uint32_t)__builtin_amdgcn_readlane((int)woff, g);
+                const uint32_t cg = lm ? (uint32_t)__builtin_amdgcn_readlane((int)wlen, g) : 0u;
+                lm &= lm - 1;  // (0 stays 0)
+                KC[sl] = cg;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                    {
-                        const uint32_t t = c * WAVE + lane;
-                        const bool in = t < cg;
-                        K4[sl][c] = in ? nb_idx[og + t] : 0xffffffffu;
-                    }
+                for (int c = 0; c < CH; ++c)
+                {
+                    const uint32_t t = c * WAVE + lane;
+                    if (UNCOND)
+                        K4[sl][c] = A.nb_idx[t < cg ? og + t : 0u];
+                    else if (t < cg)
+                        K4[sl][c] = A.nb_idx[og + t];
                 }
+            }
+            if (MODE == RP_STATE_LOCAL)
+            {
+#pragma unroll
+                for (int sp = 0; sp < DEPTH / 2; ++sp)
+                {
+                    pm &= pm - 1;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        P4[sp][c] = A.pos_of[(uint32_t)(c * WAVE) + lane < KC[sp] ? K4[sp][c] & 0x7fffffffu : 0u];
+                }
+            }
+            if (ph)
+            {
+                // (tools: make the wait for the first list -- and its positions -- visible as a phase of its own)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RP_LAP(2);
             }
             while (em)
             {
 #pragma unroll
-                for (int sl = 0; sl < RP_DEPTH; ++sl)
+                for (int sl = 0; sl < DEPTH; ++sl)
                 {
                     if (!em)
                         break;
@@ -362,91 +458,241 @@ __global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__re
                     const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)wlen, f);
                     st_entries += cnt;
                     ++st_exp;
-                    uint32_t kk[4];
+                    uint32_t kk[CH], pp[CH];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        kk[c] = K4[sl][c];
-                    if (lm)
+                    for (int c = 0; c < CH; ++c)
                     {
-                        // refill the slot with the list of the expansion RP_DEPTH steps ahead
-                        const int g = __ffsll((long long)lm) - 1;
-                        lm &= lm - 1;
-                        const uint32_t og = (uint32_t)__builtin_amdgcn_readlane((int)woff, g);
-                        const uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)wlen, g);
+                        const bool in = (uint32_t)(c * WAVE) + lane < cnt;
+                        kk[c] = in ? K4[sl][c] : 0xffffffffu;
+                        pp[c] = MODE == RP_STATE_LOCAL ? P4[sl % (DEPTH / 2)][c] - lo : 0u;
+                    }
+                    if (MODE == RP_STATE_LOCAL)
+                    {
+                        // the positions of the expansion DEPTH / 2 steps ahead: its list is in slot sl + DEPTH / 2
+                        // (past the window's last expansion the slot holds 0xffffffff: dummy loads of word 0)
+                        pm &= pm - 1;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
+                        for (int c = 0; c < CH; ++c)
                         {
-                            const uint32_t t = c * WAVE + lane;
-                            const bool in = t < cg;
-                            K4[sl][c] = in ? nb_idx[og + t] : 0xffffffffu;
+                            const uint32_t kn = K4[(sl + DEPTH / 2) % DEPTH][c];
+                            P4[sl % (DEPTH / 2)][c] =
+                                A.pos_of[(uint32_t)(c * WAVE) + lane < KC[(sl + DEPTH / 2) % DEPTH] ? kn & 0x7fffffffu : 0u];
                         }
                     }
-                    for (uint32_t base = 0; base < cnt; base += 4 * WAVE)
                     {
-                        if (base)
-                        {
+                        // refill the slot with the list of the expansion DEPTH steps ahead (none left: dummy loads)
+                        const int g = lm ? __ffsll((long long)lm) - 1 : 0;
+                        const uint32_t og = (uint32_t)__builtin_amdgcn_readlane((int)woff, g);
+                        const uint32_t cg = lm ? (uint32_t)__builtin_amdgcn_readlane((int)wlen, g) : 0u;
+                        lm &= lm - 1;
+                        KC[sl] = cg;
 #pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                            {
-                                const uint32_t t = base + c * WAVE + lane;
-                                const bool in = t < cnt;
-                                kk[c] = in ? nb_idx[o0 + t] : 0xffffffffu;
-                            }
+                        for (int c = 0; c < CH; ++c)
+                        {
+                            const uint32_t t = c * WAVE + lane;
+                            if (UNCOND)
+                                K4[sl][c] = A.nb_idx[t < cg ? og + t : 0u];
+                            else if (t < cg)
+                                K4[sl][c] = A.nb_idx[og + t];
+                        }
+                    }
+                    // one step of 64 list words in reference order (src/clustering.cpp:92-110): touch, absorb or queue.
+                    // LDS only, but for the rare drain of a full stage / ring.
+                    auto apply_step = [&](uint32_t kw, uint32_t pw) {
+                        const bool in = kw != 0xffffffffu;
+                        const uint32_t k = in ? (kw & 0x7fffffffu) : 0u;
+                        const uint32_t sid = MODE == RP_STATE_LOCAL ? (in ? pw : 0u) : k;
+                        const uint32_t sk = in ? ST_GET(sid) : 2u;
+                        const bool vis = in && !(sk & 2u);
+                        touches += __popcll(__ballot(vis));
+                        const bool absorb = vis && (kw >> 31);
+                        const bool push = vis && !absorb && sk == 0u;
+                        const unsigned long long pmask = __ballot(push);
+                        const bool first = vis && sk == 0u;
+                        if (DEFER)
+                        {
+                            const unsigned long long fmask = __ballot(first);
+                            if (first)
+                                stg[sc + __popcll(fmask & lt)] = k;  // its seed_of store goes out with the window's
+                            sc += __popcll(fmask);
+                        }
+                        else if (first)
+                            A.seed_of[k] = (int32_t)seed;  // first touch; later touches carry the same seed
+                        if (absorb)
+                            ST_OR(sid, 2u);
+                        if (push)
+                        {
+                            const uint32_t qi = qt + __popcll(pmask & lt);
+                            if (!DEFER)
+                                q[qi] = k;
+                            ring[qi % RP_RING] = k;  // (DEFER: the global queue follows in stores_out)
+                            ST_OR(sid, 1u);
+                        }
+                        qt += __popcll(pmask);
+                        if (MODE == RP_STATE_HBM)
+                            __threadfence_block();  // the next step reads states written by other lanes
+                        if (DEFER && (sc > (uint32_t)(RP_STAGE - WAVE) || qt - q_done > (uint32_t)(RP_RING - WAVE)))
+                        {
+                            stores_out();                    // rare: drained on the spot, so that the other trips of
+                            __builtin_amdgcn_s_waitcnt(0);   // this loop have no store pending
+                        }
+                    };
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                    {
+                        if ((uint32_t)(c * WAVE) >= cnt)
+                            break;
+                        apply_step(kk[c], pp[c]);
+                    }
+                    // the tail of a list beyond what a slot holds: CH chunks at a time, waited for in place (LOCAL: and
+                    // their positions behind them)
+                    for (uint32_t t0 = (uint32_t)(CH * WAVE); t0 < cnt; t0 += (uint32_t)(CH * WAVE))
+                    {
+                        uint32_t kw[CH], pw[CH];
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+                        {
+                            const uint32_t t = t0 + c * WAVE + lane;
+                            kw[c] = A.nb_idx[t < cnt ? o0 + t : 0u];
                         }
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
+                        for (int c = 0; c < CH; ++c)
                         {
-                            if (base + c * WAVE >= cnt)
+                            const bool in = t0 + c * WAVE + lane < cnt;
+                            pw[c] = MODE == RP_STATE_LOCAL ? A.pos_of[in ? kw[c] & 0x7fffffffu : 0u] - lo : 0u;
+                            kw[c] = in ? kw[c] : 0xffffffffu;
+                        }
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+                        {
+                            if (t0 + (uint32_t)(c * WAVE) >= cnt)
                                 break;
-                            const bool in = kk[c] != 0xffffffffu;
-                            const uint32_t k = in ? (kk[c] & 0x7fffffffu) : 0u;
-                            const uint32_t sk = in ? ST_GET(k) : 2u;
-                            const bool vis = in && !(sk & 2u);
-                            touches += __popcll(__ballot(vis));
-                            const bool absorb = vis && (kk[c] >> 31);
-                            const bool push = vis && !absorb && sk == 0u;
-                            const unsigned long long pm = __ballot(push);
-                            if (vis && sk == 0u)
-                                seed_of[k] = (int32_t)seed;  // first touch; later touches carry the same seed
-                            if (absorb)
-                                ST_OR(k, 2u);
-                            if (push)
-                            {
-                                const uint32_t qi = qt + __popcll(pm & lt);
-                                q[qi] = k;
-                                ring[qi % RP_RING] = k;
-                                ST_OR(k, 1u);
-                            }
-                            qt += __popcll(pm);
-                            if (!STATE_LDS)
-                                __threadfence_block();  // the next step reads states written by other lanes
+                            apply_step(kw[c], pw[c]);
                         }
                     }
                 }
             }
+            stores_out();  // between windows: the next window's gathers wait for everything anyway
+            RP_LAP(3);
         }
         if (lane == 0)
-            valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;
+            A.valid[seed] = (touches >= prm.min_size && touches <= prm.max_size) ? 1u : 0u;
         ++cc_seeds;
     }
-    if (dbg && lane == 0 && ticket < 4096)
+#undef ST_GET
+#undef ST_OR
+#undef RP_LAP
+}
+
+template <int MODE>
+__global__ __launch_bounds__(WAVE) void replay_lds_kernel(const FrameState *__restrict__ frame,
+                                                           const uint32_t *__restrict__ cc_lo,
+                                                           const uint32_t *__restrict__ cc_hi,
+                                                           const uint32_t *__restrict__ members,
+                                                           const uint32_t *__restrict__ nb_off,
+                                                           const uint32_t *__restrict__ nb_len,
+                                                           const uint32_t *__restrict__ nb_idx,
+                                                           const float *__restrict__ OX, const float *__restrict__ OY,
+                                                           const float *__restrict__ OZ, int32_t *seed_of,
+                                                           uint32_t *queue, uint32_t *valid, ReplayParams prm,
+                                                           uint64_t cap, FrameState *fstate,
+                                                           const uint32_t *__restrict__ roots,
+                                                           uint32_t *__restrict__ dbg, uint8_t *gstate,
+                                                           const uint32_t *__restrict__ pos_of, FV fv)
+{
+    const LpxBlock lpx_blk = lpx_block<7>(fv.fs);
+    extern __shared__ uint32_t sbits[];
+    frame = lpx_slot(frame, fv.fs);
+    fstate = lpx_slot(fstate, fv.fs);
+    cc_lo = lpx_slot(cc_lo, fv.fs);
+    cc_hi = lpx_slot(cc_hi, fv.fs);
+    roots = lpx_slot(roots, fv.fs);
+    ReplayArrays A;
+    A.members = lpx_slot(members, fv.fs);
+    A.nb_off = lpx_slot(nb_off, fv.fs);
+    A.nb_len = lpx_slot(nb_len, fv.fs);
+    A.nb_idx = lpx_slot(nb_idx, fv.fs_nb);
+    A.pos_of = lpx_slot(pos_of, fv.fs);
+    A.OX = lpx_slot(OX, fv.fs);
+    A.OY = lpx_slot(OY, fv.fs);
+    A.OZ = lpx_slot(OZ, fv.fs);
+    A.seed_of = lpx_slot(seed_of, fv.fs);
+    A.queue = lpx_slot(queue, fv.fs);
+    A.valid = lpx_slot(valid, fv.fs);
+    A.gstate = lpx_slot(gstate, fv.fs);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t M = frame->n_obstacle;
+    if (frame->nb_total > cap)
+        return;
+    const uint32_t n_roots = frame->n_roots;
+    if (lpx_blk.x >= n_roots)
+        return;
+    // RP_STATE_LDS: the bitmap is zeroed once -- components own disjoint points, so the 2-bit states of one component
+    // are never read by another.  RP_STATE_LOCAL: per component (replay_component).
+    const uint32_t words = MODE == RP_STATE_LDS ? (M + 15) / 16 : (MODE == RP_STATE_LOCAL ? RP_LOCAL_CAP / 16u : 0u);
+    for (uint32_t i = lane; MODE == RP_STATE_LDS && i < words; i += WAVE)
+        sbits[i] = 0;
+    // the most recent RP_RING queue entries are mirrored in LDS: a window of pops is then read without
+    // waiting for the global queue stores (the global queue remains the fallback for long queues)
+    lds_u32 *const lbits = (lds_u32 *)sbits;
+    lds_u32 *const ring = lbits + ((words + 3) & ~3u);
+    lds_u32 *const stg = ring + RP_RING;
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long st_entries = 0;
+    uint32_t st_exp = 0;
+    for (;;)
     {
-        dbg[ticket * 8 + 0] = hi - lo;
-        dbg[ticket * 8 + 1] = st_exp - cc_x0;
-        dbg[ticket * 8 + 2] = (uint32_t)(st_entries - cc_e0);
-        dbg[ticket * 8 + 3] = cc_windows;
-        dbg[ticket * 8 + 4] = cc_seeds;
-        dbg[ticket * 8 + 5] = (uint32_t)(__builtin_amdgcn_s_memtime() - cc_t0);
-        dbg[ticket * 8 + 6] = 0;
+        uint32_t ticket = 0;
+        if (lane == 0)
+            ticket = atomicAdd(&fstate->root_cursor, 1u);
+        ticket = __shfl(ticket, 0, 64);
+        if (ticket >= n_roots)
+            break;
+        const uint32_t r = roots[ticket];
+        const uint32_t lo = cc_lo[r], hi = cc_hi[r];
+        const unsigned long long cc_t0 = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long cc_e0 = st_entries;
+        const uint32_t cc_x0 = st_exp;
+        uint32_t cc_windows = 0, cc_seeds = 0;
+        unsigned long long phase[4] = {0, 0, 0, 0};
+        unsigned long long *const ph = (dbg && prm.dbg_rows == 65536u) ? phase : (unsigned long long *)nullptr;
+        if (MODE == RP_STATE_LOCAL && hi - lo > RP_LOCAL_CAP)
+            replay_component<RP_STATE_HBM>(A, prm, lo, hi, lbits, ring, stg, lane, st_entries, st_exp, cc_windows, cc_seeds,
+                                           ph);
+        else
+            replay_component<MODE>(A, prm, lo, hi, lbits, ring, stg, lane, st_entries, st_exp, cc_windows, cc_seeds, ph);
+        if (ph && lane == 0 && ticket < prm.dbg_rows)
+            for (int i = 0; i < 4; ++i)  // (tools/r6_replay5m.py: a second block of rows behind the first 65536)
+                dbg[(65536u + ticket) * 8 + i] = (uint32_t)(phase[i] >> 4);
+        if (dbg && lane == 0 && ticket < prm.dbg_rows)
+        {
+            dbg[ticket * 8 + 0] = hi - lo;
+            dbg[ticket * 8 + 1] = st_exp - cc_x0;
+            dbg[ticket * 8 + 2] = (uint32_t)(st_entries - cc_e0);
+            dbg[ticket * 8 + 3] = cc_windows;
+            dbg[ticket * 8 + 4] = cc_seeds;
+            dbg[ticket * 8 + 5] = (uint32_t)(__builtin_amdgcn_s_memtime() - cc_t0);
+            dbg[ticket * 8 + 6] = 0;
+        }
     }
-  }
     if (lane == 0 && st_exp)
     {
         atomicAdd((unsigned long long *)&fstate->replay_entries, st_entries);
         atomicAdd(&fstate->n_expansions, st_exp);
     }
-#undef ST_GET
-#undef ST_OR
+}
+
+// position of every point in the sorted member list (RP_STATE_LOCAL): pos_of[members[p]] = p
+__global__ void pos_of_kernel(const uint32_t *__restrict__ members, const FrameState *__restrict__ frame,
+                              uint32_t *__restrict__ pos_of, size_t fs)
+{
+    const LpxBlock lpx_blk = lpx_block<6>(fs);
+    members = lpx_slot(members, fs);
+    frame = lpx_slot(frame, fs);
+    pos_of = lpx_slot(pos_of, fs);
+    const uint32_t p = lpx_blk.x * blockDim.x + threadIdx.x;
+    if (p < frame->n_obstacle)
+        pos_of[members[p]] = p;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -490,7 +736,9 @@ struct RsShared  // fixed part of the LDS of replay_search_kernel (the bitmap fo
 {
     uint32_t ring[RS_WAVES][RS_RING];
     uint32_t hits[RS_WAVES][RS_HITS];
+    uint32_t stage[RS_WAVES][RS_HITS];  // first touches of the expansion applied last, until their global stores go out
 };
+// (lds_u32: above, at the list replay)
 
 typedef float4 KdNode;
 
@@ -637,7 +885,7 @@ __global__ RS_BOUNDS void replay_search_kernel(
     __syncthreads();  // the only workgroup barrier: from here on the wavefronts are independent sequencers
     const unsigned long long lt = lpx_lanemask_lt();
     const float r2 = prm.r2, thr_f = prm.thr_f;
-    uint32_t *ring = sh.ring[w];
+    lds_u32 *const ring = (lds_u32 *)&sh.ring[w][0];
 #define ST_GET(k) (STATE_LDS ? ((sbits[(k) >> 4] >> (((k) & 15u) * 2u)) & 3u) : (uint32_t)gstate[k])
 #define ST_OR(k, v)                                                                                                   \
     do                                                                                                                \
@@ -699,12 +947,41 @@ __global__ RS_BOUNDS void replay_search_kernel(
             }
             if (!STATE_LDS)
                 __threadfence_block();
-            // one chunk step of list words in order (:92-110): touch, absorb or queue
-            auto apply = [&](uint32_t word) {
+            // Global stores and the load pipeline (round 6).  vmcnt counts loads AND stores, and the two complete out of
+            // order with respect to each other: with a store pending, a wait for ANY load is a wait for everything
+            // (s_waitcnt vmcnt(0) -- the compiler has no choice).  Rounds 2-5 applied the hits of expansion i, seed_of and
+            // queue stores included, under the candidate loads of expansion i + 1: every state read of the apply then
+            // waited for those loads first, which is where "56-59 % of a sequencer's time in apply" came from; and the
+            // hit buffer was reached through a generic pointer (64 flat_load + 63 flat_store per kernel: flat operations
+            // count on vmcnt AND lgkmcnt).  Now: the buffers are LDS-address-space pointers; an apply that runs under
+            // prefetched loads (DEFER) touches LDS only and leaves its first touches in `stage`; their seed_of stores, and
+            // the global copy of the queue entries pushed meanwhile (from the ring), go out once the prefetched candidates
+            // have been consumed (stores_out).
+            lds_u32 *const hb = (lds_u32 *)&sh.hits[w][0];
+            lds_u32 *const stg = (lds_u32 *)&sh.stage[w][0];
+            uint32_t hc = 0;        // words gathered (wave-uniform)
+            uint32_t staged = 0;    // words of `stage` whose stores are still owed
+            uint32_t q_done = 1;    // queue entries [0, q_done) are in the global queue (the seed is)
+            auto stores_out = [&]() {
+                for (uint32_t b0 = 0; b0 < staged; b0 += WAVE)
+                {
+                    const uint32_t wd = b0 + lane < staged ? stg[b0 + lane] : 0u;
+                    if (wd >> 31)
+                        seed_of[wd & 0x7fffffffu] = (int32_t)seed;  // first touch; later touches carry the same seed
+                }
+                staged = 0;
+                for (uint32_t j0 = q_done; j0 < qt; j0 += WAVE)
+                    if (j0 + lane < qt)
+                        q[j0 + lane] = ring[(j0 + lane) % RS_RING];
+                q_done = qt;
+            };
+            // one chunk step of list words in order (:92-110): touch, absorb or queue.  DEFER: no global store (see above);
+            // returns the word to stage: index | first touch << 31
+            auto apply = [&](uint32_t word, bool defer) -> uint32_t {
                 const bool in = word != 0xffffffffu;
                 const unsigned long long im = __ballot(in);
                 if (!im)
-                    return;  // no candidate of this chunk is a neighbour
+                    return 0u;  // no candidate of this chunk is a neighbour
                 st_entries += __popcll(im);
                 const uint32_t k = in ? (word & 0x7fffffffu) : 0u;
                 const uint32_t sk = in ? ST_GET(k) : 2u;
@@ -713,30 +990,35 @@ __global__ RS_BOUNDS void replay_search_kernel(
                 const bool absorb = vis && (word >> 31);
                 const bool push = vis && !absorb && sk == 0u;
                 const unsigned long long pm = __ballot(push);
-                if (vis && sk == 0u)
+                const bool first = vis && sk == 0u;
+                if (first && !defer)
                     seed_of[k] = (int32_t)seed;  // first touch; later touches carry the same seed
                 if (absorb)
                     ST_OR(k, 2u);
                 if (push)
                 {
                     const uint32_t qi = qt + __popcll(pm & lt);
-                    q[qi] = k;
+                    if (!defer)
+                        q[qi] = k;
                     ring[qi % RS_RING] = k;
                     ST_OR(k, 1u);
                 }
                 qt += __popcll(pm);
+                if (!defer)
+                    q_done = qt;
                 if (!STATE_LDS)
                     __threadfence_block();  // the next step reads states written by other lanes
+                return k | (first ? 0x80000000u : 0u);
             };
             // The list words of an expansion (the hits of its candidate chunks, in candidate = pre-order order) are
             // gathered in LDS first and applied 64 at a time: a chunk of 64 candidates holds ~5 hits on a KITTI frame,
             // and applying chunk by chunk paid one state read, three ballots and the LDS atomics for every chunk with a
-            // hit (56-59 % of a sequencer's time); gathering costs one ballot and one LDS store per chunk.
-            volatile uint32_t *hb = sh.hits[w];
-            uint32_t hc = 0;  // words gathered (wave-uniform)
-            auto flush64 = [&]() {
+            // hit; gathering costs one ballot and one LDS store per chunk.
+            auto flush64 = [&]() {  // (while the expansion's own candidates are consumed: nothing is prefetched, stores go out)
                 __builtin_amdgcn_wave_barrier();  // one wavefront, in-order LDS: the stores above are visible
-                apply(lane < hc ? hb[lane] : 0xffffffffu);
+                if (staged)
+                    stores_out();  // (keeps the global queue in order with the direct stores below)
+                apply(lane < hc ? hb[lane] : 0xffffffffu, false);
                 if (hc > (uint32_t)WAVE)
                 {
                     const uint32_t mv = lane < hc - WAVE ? hb[WAVE + lane] : 0u;
@@ -747,6 +1029,19 @@ __global__ RS_BOUNDS void replay_search_kernel(
                 }
                 else
                     hc = 0;
+            };
+            auto flush_rest = [&](bool defer) {  // the (fewer than 128) hits left when an expansion has been searched
+                __builtin_amdgcn_wave_barrier();
+                if (staged)
+                    stores_out();
+                for (uint32_t b0 = 0; b0 < hc; b0 += WAVE)
+                {
+                    const uint32_t o = apply(b0 + lane < hc ? hb[b0 + lane] : 0xffffffffu, defer);
+                    if (defer && b0 + lane < hc)
+                        stg[b0 + lane] = o;
+                }
+                staged = defer ? hc : 0u;
+                hc = 0;
             };
             auto collect = [&](uint32_t word) {
                 const bool in = word != 0xffffffffu;
@@ -842,6 +1137,8 @@ __global__ RS_BOUNDS void replay_search_kernel(
                     }
                     ++st_exp;
                     rs_consume(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
+                    if (staged)
+                        stores_out();  // the stores the apply of the expansion before this one owes (its hits are all applied)
                     while (km)
                     {
                         rs_issue(bt, PR, ch, km, lane);
@@ -859,8 +1156,9 @@ __global__ RS_BOUNDS void replay_search_kernel(
                         rs_issue(bt, PR, ch, km, lane);
                     }
                     RS_LAP(pf_tab, pf_t);
-                    while (hc)
-                        flush64();  // the hits of the expansion just searched, before any hit of the next one
+                    // the hits of the expansion just searched, before any hit of the next one -- under the first candidate
+                    // batch of the next expansion when there is one (then without global stores: DEFER)
+                    flush_rest(STATE_LDS && e_next >= 0);
                     RS_LAP(pf_apply, pf_t);
                     if (e_next < 0)
                         break;
@@ -1281,6 +1579,7 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     prm.r2 = cfg->distance_squared;
     prm.min_size = cfg->min_cluster_size;
     prm.max_size = cfg->max_cluster_size;
+    prm.dbg_rows = ctx->dbg_buf ? (uint32_t)(ctx->dbg_store.bytes / 32 < 65536 ? ctx->dbg_store.bytes / 32 : 65536) : 0u;
     uint32_t *sroot = nullptr, *members = nullptr;
     uint32_t *cc_lo = (uint32_t *)ctx->cc_lo.p, *cc_hi = (uint32_t *)ctx->cc_hi.p;
     uint32_t *valid = (uint32_t *)ctx->valid.p;
@@ -1460,32 +1759,45 @@ int lpx_run_cluster(lpx_ctx *ctx, uint32_t m_max, const lpx_clu_cfg *cfg, int32_
     else if (ctx->use_lists)
     {
         StageTimer tm(ctx, ST_REPLAY);
-        const size_t lds = sizeof(uint32_t) * (((((size_t)m_max + 15) / 16 + 3) & ~(size_t)3) + RP_RING);
+        const size_t lds = sizeof(uint32_t) * (((((size_t)m_max + 15) / 16 + 3) & ~(size_t)3) + RP_RING + RP_STAGE);
         static const int rp_grid = LPX_KNOB("LPX_RP_GRID") ? atoi(LPX_KNOB("LPX_RP_GRID")) : 2048;
-        static const int rp_state = LPX_KNOB("LPX_RP_STATE") ? atoi(LPX_KNOB("LPX_RP_STATE")) : 0;  // 1: states in HBM (tests)
+        // (tests) 1 / 2: component-local LDS states for every frame, 3: states in HBM for every frame
+        static const int rp_state = LPX_KNOB("LPX_RP_STATE") ? atoi(LPX_KNOB("LPX_RP_STATE")) : 0;
 #define RP_ARGS                                                                                                       \
     frame, cc_lo, cc_hi, members, (const uint32_t *)ctx->nb_off.p, (const uint32_t *)ctx->nb_len.p,                   \
         (const uint32_t *)ctx->nb_idx.p, (const float *)ctx->OX.p, (const float *)ctx->OY.p,                          \
         (const float *)ctx->OZ.p, (int32_t *)ctx->seed_of.p, (uint32_t *)ctx->queue.p, valid, prm, ctx->cap_nb,       \
-        frame, (const uint32_t *)ctx->rpos.p, (uint32_t *)ctx->dbg_buf, (uint8_t *)ctx->state.p, fv
-        if (lds <= 112 * 1024 && rp_state != 1)
+        frame, (const uint32_t *)ctx->rpos.p, (uint32_t *)ctx->dbg_buf, (uint8_t *)ctx->state.p,                      \
+        (const uint32_t *)ctx->lpos.p, fv
+        if (lds <= 112 * 1024 && rp_state == 0)
         {
             if (!ctx->attr_replay)
             {
-                LPX_HIP(ctx, hipFuncSetAttribute((const void *)replay_lds_kernel<true>,
+                LPX_HIP(ctx, hipFuncSetAttribute((const void *)replay_lds_kernel<RP_STATE_LDS>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
                 ctx->attr_replay = true;
             }
             const uint32_t rgrid = m_max < 512u ? m_max : 512u;  // persistent: blocks pull components from a list
-            hipLaunchKernelGGL(replay_lds_kernel<true>, dim3(rgrid, 1, ctx->cur_b), dim3(WAVE), lds, st, RP_ARGS);
+            hipLaunchKernelGGL(replay_lds_kernel<RP_STATE_LDS>, dim3(rgrid, 1, ctx->cur_b), dim3(WAVE), lds, st, RP_ARGS);
+        }
+        else if (rp_state != 3)
+        {
+            // clouds beyond the LDS bitmap (a 5M-point frame) and LPX_RP_STATE=2 (tests: every frame): the states of a
+            // component in LDS by member position -- pos_of in the kd build's stop-list scratch, free since the build
+            if (sizeof(uint32_t) * (size_t)m_max > ctx->lpos.bytes)
+                return lpx_fail(ctx, LPX_ERR_INTERNAL, "member positions of %u points do not fit their scratch", m_max);
+            hipLaunchKernelGGL(pos_of_kernel, grd, blk, 0, st, (const uint32_t *)members, (const FrameState *)frame,
+                               (uint32_t *)ctx->lpos.p, fv.fs);
+            const uint32_t rgrid = m_max < (uint32_t)rp_grid ? m_max : (uint32_t)rp_grid;
+            hipLaunchKernelGGL(replay_lds_kernel<RP_STATE_LOCAL>, dim3(rgrid, 1, ctx->cur_b), dim3(WAVE),
+                               sizeof(uint32_t) * (RP_LOCAL_CAP / 16u + RP_RING + RP_STAGE), st, RP_ARGS);
         }
         else
         {
-            // states in HBM, everything else as above; only the ring lives in LDS, so many more sequencers fit
-            // (5M-point frame: 4.4 ms against 5.75 ms for the plain pop-one-expand-one loop this replaced)
+            // LPX_RP_STATE=3 (tests): states in HBM for every component, the form a component beyond RP_LOCAL_CAP takes
             const uint32_t rgrid = m_max < (uint32_t)rp_grid ? m_max : (uint32_t)rp_grid;
-            hipLaunchKernelGGL(replay_lds_kernel<false>, dim3(rgrid, 1, ctx->cur_b), dim3(WAVE),
-                               sizeof(uint32_t) * RP_RING, st, RP_ARGS);
+            hipLaunchKernelGGL(replay_lds_kernel<RP_STATE_HBM>, dim3(rgrid, 1, ctx->cur_b), dim3(WAVE),
+                               sizeof(uint32_t) * (RP_RING + RP_STAGE), st, RP_ARGS);
         }
 #undef RP_ARGS
     }

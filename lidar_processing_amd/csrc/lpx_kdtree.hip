@@ -1742,6 +1742,8 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
         T = s_n[1];
         cur = seqbuf + s_n[2];
     }
+    if (dbg && lane == 0 && (!BLOCK || w == 0))
+        dbg[gid * 8 + 6] = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);  // the traversal
 
     const unsigned long long lt = lpx_lanemask_lt();
     uint32_t my_cnt = 0;     // lane j (of the wavefront that owns query j): room asked for the list of query j

@@ -1,6 +1,7 @@
-"""Helper of tests/test_gpu_pipeline.py::test_point_states_in_hbm_give_the_same_labels: run with LPX_RP_STATE=1 and
-LPX_RS_STATE=1 in the environment (read once per process) -- the replay kernels then keep their point states in HBM (one
-byte per point) whatever the frame size, the path that otherwise only frames beyond the LDS bitmap take.  Real frames in
+"""Helper of tests/test_gpu_pipeline.py::test_point_states_in_hbm_give_the_same_labels: run with LPX_RP_STATE=2 | 3
+and LPX_RS_STATE=1 in the environment (read once per process) -- the replay kernels then keep their point states per
+component in LDS by member position (2) or in HBM, one byte per point (3; the search replay: LPX_RS_STATE), whatever the
+frame size: the paths that otherwise only frames beyond the whole-cloud LDS bitmap take.  Real frames in
 both neighbour modes against the C restatement, and a ragged batch against the single-frame path."""
 import os
 import sys
@@ -14,7 +15,7 @@ from test_gpu_batch import check_frame, run_batch, single  # noqa: E402
 from test_gpu_pipeline import check_against_oracle  # noqa: E402
 from util import FRAMES, load_frame, synthetic_scene  # noqa: E402
 
-assert os.environ.get("LPX_RP_STATE") == "1" and os.environ.get("LPX_RS_STATE") == "1"
+assert os.environ.get("LPX_RP_STATE") in ("1", "2", "3") and os.environ.get("LPX_RS_STATE") == "1"
 from lidar_processing_amd import _lib as _l  # noqa: E402
 assert b"development build" in _l.lib().lpx_build_info(), "the knobs are read by liblpx_dev.so only (LPX_LIB)"
 skw = dict(number_of_planar_partitions=6, number_of_iterations=5)

@@ -784,16 +784,19 @@ def test_search_tables_adapt_their_group_size_to_the_scene():
     assert cand[3] < 0.9 * cand[4] and cand[5] == cand[4], cand  # the first frame still with 32, then back to 64
 
 
-def test_point_states_in_hbm_give_the_same_labels():
-    """the replay kernels keep their point states in an LDS bitmap while it fits and in HBM (one byte per point) beyond;
-    LPX_RP_STATE=1 / LPX_RS_STATE=1 (read once per process -- hence the subprocess) force the HBM form on the real
-    frames and on a ragged batch: every output equals the C restatement's / the single-frame path's"""
+@pytest.mark.parametrize("rp_state", ["2", "3"])
+def test_point_states_in_hbm_give_the_same_labels(rp_state):
+    """the replay kernels keep their point states in an LDS bitmap over the whole cloud while it fits; beyond that the
+    list replay keeps the states of ONE component in LDS by member position (round 6; components of more than 65 536
+    points: one byte per point in HBM) and the search replay one byte per point in HBM.  LPX_RP_STATE=2 (component-local)
+    / 3 (HBM) and LPX_RS_STATE=1 (read once per process -- hence the subprocess) force those forms on the real frames and
+    on a ragged batch: every output equals the C restatement's / the single-frame path's"""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     from lidar_processing_amd import _lib
-    env = dict(os.environ, LPX_RP_STATE="1", LPX_RS_STATE="1", LPX_LIB=_lib.DEV_LIB_PATH,  # knobs: development build only
+    env = dict(os.environ, LPX_RP_STATE=rp_state, LPX_RS_STATE="1", LPX_LIB=_lib.DEV_LIB_PATH,  # knobs: development build only
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get("PYTHONPATH", "")]))
     r = subprocess.run([sys.executable, os.path.join(here, "state_check.py")], env=env, capture_output=True, text=True,
                        timeout=900)

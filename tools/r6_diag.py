@@ -46,9 +46,10 @@ out = np.zeros((G, 8), np.uint32)
 assert L.lpx_dbg_group_stats(ctx._h, G, out.ctypes.data_as(C.c_void_p)) == 0
 used = out[4096:]
 used = used[used[:, 2] > 0]
-T, ncur, nq, tot, c1, c2 = [used[:, i].astype(np.float64) for i in range(6)]
+T, ncur, nq, tot, c1, c2, c0 = [used[:, i].astype(np.float64) for i in range(7)]
 print("groups", len(used))
-for name, v in [("T", T), ("intervals", ncur), ("queries", nq), ("reserved/query", tot / nq), ("kcycles alloc", c1 / 1e3),
+for name, v in [("T", T), ("intervals", ncur), ("queries", nq), ("reserved/query", tot / nq), ("kcycles traverse", c0 / 1e3),
+                ("kcycles alloc", c1 / 1e3),
                 ("kcycles total", c2 / 1e3)]:
     print(f"  {name:14s} mean {v.mean():9.1f}  p50 {np.percentile(v, 50):9.1f}  p90 {np.percentile(v, 90):9.1f} "
           f" p99 {np.percentile(v, 99):9.1f}  max {v.max():9.1f}")
