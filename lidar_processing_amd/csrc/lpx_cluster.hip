@@ -7,7 +7,7 @@
 // (removed, never expanded), otherwise queued (:102-109); groups whose TOUCH COUNT (duplicates
 // included, :99-100) is outside [min,max] are relabelled INVALID (:113-119).  The partition depends
 // on that order, so it cannot be produced by a union-find alone.  What is parallel:
-//   * every radius-neighbour list, already in reference emission order   (lpx_kdtree.hip)
+//   * every radius-neighbour list, already in reference emission order   (lpx_lists.hip)
 //   * the connected components of the d-graph (union-find while filling the lists).  A BFS never
 //     leaves its component and components do not interact, so replaying the greedy loop per
 //     component -- seeds ascending inside the component -- gives the reference's partition.
@@ -697,7 +697,7 @@ __global__ void pos_of_kernel(const uint32_t *__restrict__ members, const FrameS
 
 // ------------------------------------------------------------------------------------------------
 // Expansion-driven replay: the same greedy loop, but the radius search of a point happens WHEN the loop expands
-// it, against the candidate chunks of the point's kd group (lpx_kdtree.hip: nb_index_kernel).  Nothing is
+// it, against the candidate chunks of the point's kd group (lpx_chunks.hip: nb_index_kernel).  Nothing is
 // materialised for the ~80 % of the points the reference never expands.
 //
 // This is the THROUGHPUT path (batch contexts): a single frame alone on the device is served faster by the list
@@ -1113,28 +1113,37 @@ __global__ RS_BOUNDS void replay_search_kernel(
                 // does not depend on the point states, so the searches are software-pipelined: the chunk table of
                 // expansion i + 1 is requested before expansion i is searched, and the first candidate batch of i + 1
                 // goes out before the hits of i are applied (the LDS work of the apply then runs under those loads).
+                // Order of the loads (round 6): a wait for one load is a wait for every load issued before it AND, as soon
+                // as a load behind a branch may lie in between, for everything (s_waitcnt vmcnt(0)).  So nothing is requested
+                // shortly before something older is waited for: the candidate batch of expansion i + 1 and the chunk table
+                // of expansion i + 2 go out TOGETHER, right after the candidates of expansion i have been consumed, and
+                // the one drain per expansion -- at the head of the next consume -- finds both at least an apply old.
+                // (Rounds 2-5 requested table i + 1 at the head of the loop, immediately in front of the consume of batch
+                // i: every expansion waited a full round trip for a table it needed much later.)
                 int e = __ffsll((long long)em) - 1;
                 em &= em - 1;
                 ChunkRec ch = ch_first;
+                uint32_t g_cur = g_held;  // the group ch belongs to
                 float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), e));
                 float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), e));
                 float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), e));
                 unsigned long long km = rs_cull(ch, qx, qy, qz, r2);
                 RsBatch bt;
                 rs_issue(bt, PR, ch, km, lane);
+                // the table of the window's second expansion, behind the first batch
+                int e_next = em ? __ffsll((long long)em) - 1 : -1;
+                ChunkRec ch_next = ch;
+                uint32_t g_nxt = g_cur;
+                if (e_next >= 0)
+                {
+                    em &= em - 1;
+                    g_nxt = (uint32_t)__builtin_amdgcn_readlane((int)wg, e_next);
+                    if (!REUSE || g_nxt != g_cur)
+                        ch_next = chunks[(size_t)g_nxt * LPX_GROUP_CHUNKS + lane];
+                }
                 RS_LAP(pf_tab, pf_t);
                 for (;;)
                 {
-                    const int e_next = em ? __ffsll((long long)em) - 1 : -1;
-                    ChunkRec ch_next = ch;
-                    if (e_next >= 0)
-                    {
-                        em &= em - 1;
-                        const uint32_t g_next = (uint32_t)__builtin_amdgcn_readlane((int)wg, e_next);
-                        if (!REUSE || g_next != g_held)
-                            ch_next = chunks[(size_t)g_next * LPX_GROUP_CHUNKS + lane];
-                        g_held = g_next;
-                    }
                     ++st_exp;
                     rs_consume(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
                     if (staged)
@@ -1145,24 +1154,36 @@ __global__ RS_BOUNDS void replay_search_kernel(
                         rs_consume(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
                     }
                     RS_LAP(pf_cand, pf_t);
-                    if (e_next >= 0)
+                    const bool more = e_next >= 0;
+                    if (more)
                     {
                         e = e_next;
                         ch = ch_next;
+                        g_cur = g_nxt;
                         qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), e));
                         qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), e));
                         qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), e));
                         km = rs_cull(ch, qx, qy, qz, r2);
                         rs_issue(bt, PR, ch, km, lane);
+                        // ... and the table of the expansion after it
+                        e_next = em ? __ffsll((long long)em) - 1 : -1;
+                        if (e_next >= 0)
+                        {
+                            em &= em - 1;
+                            g_nxt = (uint32_t)__builtin_amdgcn_readlane((int)wg, e_next);
+                            if (!REUSE || g_nxt != g_cur)
+                                ch_next = chunks[(size_t)g_nxt * LPX_GROUP_CHUNKS + lane];
+                        }
                     }
                     RS_LAP(pf_tab, pf_t);
                     // the hits of the expansion just searched, before any hit of the next one -- under the first candidate
                     // batch of the next expansion when there is one (then without global stores: DEFER)
-                    flush_rest(STATE_LDS && e_next >= 0);
+                    flush_rest(STATE_LDS && more);
                     RS_LAP(pf_apply, pf_t);
-                    if (e_next < 0)
+                    if (!more)
                         break;
                 }
+                g_held = g_cur;
                 if (REUSE)
                     ch_held = ch;  // (the table of group g_held)
             }

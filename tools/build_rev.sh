@@ -11,7 +11,7 @@ rm -rf "$src"; mkdir -p "$src" "$root/lidar_processing_amd/ab"
 git -C "$root" archive "$rev" lidar_processing_amd/csrc include $(git -C "$root" ls-tree --name-only "$rev" experiments 2>/dev/null) | tar -x -C "$src"
 cd "$src/lidar_processing_amd/csrc"
 pids=()
-for f in lpx_primitives lpx_segment lpx_kdtree lpx_cluster lpx_api lpx_feeder; do
+for f in $(ls *.hip | sed "s/\.hip$//"); do  # (every source of the tree as it is / was: the file set changed in round 6)
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I../../include -I. \
     -Wno-unused-value -Wno-unused-result "$@" -c $f.hip -o $f.o &
   pids+=($!)

@@ -7,10 +7,10 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/lpx_variant_$name
-mkdir -p "$obj" "$root/lidar_processing_amd/ab"
+rm -rf "$obj"; mkdir -p "$obj" "$root/lidar_processing_amd/ab"
 cd "$root/lidar_processing_amd/csrc"
 pids=()
-for f in lpx_primitives lpx_segment lpx_kdtree lpx_cluster lpx_api lpx_feeder; do
+for f in $(ls *.hip | sed "s/\.hip$//"); do  # (every source of the tree as it is / was: the file set changed in round 6)
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I../../include -I. \
     -Wno-unused-value -Wno-unused-result -DLPX_DEV_KNOBS "$@" -c $f.hip -o "$obj/$f.o" &
   pids+=($!)
