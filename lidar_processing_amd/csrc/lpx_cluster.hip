@@ -126,10 +126,11 @@ __global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, const uint3
     valid = lpx_slot(valid, fs);
     const uint32_t p = lpx_blk.x * blockDim.x + threadIdx.x;
     const uint32_t M = frame->n_obstacle;
-    bool single = false;
+    bool single = false, opens = false;
+    uint32_t r = 0;
     if (p < M)
     {
-        const uint32_t r = sroot[p];
+        r = sroot[p];
         const bool first = p == 0 || sroot[p - 1] != r, last = p + 1 == M || sroot[p + 1] != r;
         single = first && last;
         if (single)
@@ -140,23 +141,32 @@ __global__ void cc_ranges_kernel(const uint32_t *__restrict__ sroot, const uint3
         }
         else
         {
+            opens = first;
             if (first)
-            {
                 cc_lo[r] = p;
-                roots[atomicAdd(&frame->n_roots, 1u)] = r;  // work list of the replay
-            }
             if (last)
                 cc_hi[r] = p + 1;
         }
     }
+    // work list of the replay: one bump of the frame's counter per WAVEFRONT (a 5M-point frame has 30 000 sets with a
+    // sequencer: one same-address atomic each was 170 us of serialisation at L2; the order of the list is free)
+    const unsigned long long om = __ballot(opens);
+    if (om)
+    {
+        uint32_t base = 0;
+        if ((threadIdx.x % WAVE) == (uint32_t)(__ffsll((long long)om) - 1))
+            base = atomicAdd(&frame->n_roots, (uint32_t)__popcll(om));
+        base = __shfl(base, __ffsll((long long)om) - 1, WAVE);
+        if (opens)
+            roots[base + __popcll(om & lpx_lanemask_lt())] = r;
+    }
     // the statistics keep counting the radius searches the reference makes: one per single-point set, one neighbour each
+    // (ONE bump per wavefront that holds a single-point set: n_single; relabel_kernel adds it to n_expansions and
+    // replay_entries at the end of the call -- three same-line atomics per wavefront were most of this kernel's 163 us on a
+    // 5M-point frame)
     const uint32_t ns = (uint32_t)__popcll(__ballot(single));
     if (ns && (threadIdx.x % WAVE) == 0)
-    {
-        atomicAdd(&frame->n_expansions, ns);
         atomicAdd(&frame->n_single, ns);
-        atomicAdd((unsigned long long *)&frame->replay_entries, (unsigned long long)ns);
-    }
 }
 
 struct ReplayParams
@@ -1237,6 +1247,9 @@ __global__ void relabel_kernel(FrameState *frame, const int32_t *__restrict__ se
     {
         const uint32_t nc = (uint32_t)*total;  // number of valid seeds = number of clusters
         frame->n_clusters = nc;
+        // the single-point sets cc_ranges_kernel settled: one radius search and one list entry each in the reference
+        frame->n_expansions += frame->n_single;
+        frame->replay_entries += frame->n_single;
         if (counts)  // last kernel of the call: hand the frame counts to the caller
         {
             counts += 4 * (size_t)lpx_blk.z;

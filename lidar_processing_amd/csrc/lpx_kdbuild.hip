@@ -1194,7 +1194,10 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     // A single frame stages up to 4096 nodes per workgroup (96 KiB of LDS: fewest global-memory rounds, best
     // latency).  A batch shares the device with the small-LDS workgroups of other chains' neighbour kernels,
     // next to which a 96 KiB workgroup rarely finds room; half the capacity schedules freely.
-    const int blk_cap = ctx->cur_b > 1 ? BLK_CAP_BATCH : BLK_CAP_MAX;
+    // (a single frame of more than a million points has hundreds of LDS subtrees: with 3968 nodes and 16-bit stop lists a
+    // subtree takes 79.6 KB and TWO share a compute unit -- 5M-point frame: kd_lds_kernel 0.90 -> see docs/experiments.md)
+    const bool big_single = ctx->cur_b == 1 && m_max >= (1u << 20);
+    const int blk_cap = ctx->cur_b > 1 ? BLK_CAP_BATCH : (big_single ? 3968 : BLK_CAP_MAX);
     const size_t key_lds = sizeof(float) * BLK_G_MAX * 4;  // key buffer of kd_block_kernel's flag pass
     const size_t blk_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint32_t) * blk_cap + 64 * sizeof(uint32_t);
     const size_t lds_lds = sizeof(Node) * blk_cap + 2 * sizeof(uint16_t) * blk_cap + 64 * sizeof(uint32_t);  // batches
@@ -1291,7 +1294,7 @@ int lpx_kd_build(lpx_ctx *ctx, uint32_t m_max)
     // search path: the kernel that writes every node to its final place also makes every point its own set (the
     // union-find forest nb_index_kernel links); the list path builds its forest from the lists
     uint32_t *forest = (!ctx->use_lists && lpx_cc_from_chunks(m_max)) ? (uint32_t *)ctx->parent.p : (uint32_t *)nullptr;
-    if (ctx->cur_b > 1)
+    if (ctx->cur_b > 1 || big_single)
         hipLaunchKernelGGL(kd_lds_kernel<uint16_t>, dim3(1u << level, 1, ctx->cur_b), dim3(LG), lds_lds, ctx->stream, nodes,
                            (Node *)ctx->nodes_pre.p, frame, (uint32_t *)ctx->dbg_buf, blk_cap, forest, ctx->fs_tag);
     else

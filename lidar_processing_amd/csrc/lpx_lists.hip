@@ -55,6 +55,7 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
     __shared__ float s_cbox[NB_NODES / NB_GRAN][6];
     __shared__ uint32_t s_q[2][WAVE];  // per-query counts / write cursors (BLOCK mode)
     __shared__ uint32_t s_n[4];        // n_cur, T, cur offset, abort
+    __shared__ uint32_t s_phase;       // the group tries a single-pass reservation
     const uint32_t w = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     const uint32_t M = frame->n_obstacle;
     if (M == 0)
@@ -154,6 +155,8 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
             s_n[1] = T;
             s_n[2] = (uint32_t)(cur - seqbuf);
             s_n[3] = 0;
+            // whether the group tries a single-pass reservation: decided ONCE per group, here (see `phase` below)
+            s_phase = frame->rs_stripe[gid % LPX_RS_STRIPES].v < cap_rs / LPX_RS_STRIPES ? 1u : 0u;
         }
     }
     if (BLOCK)
@@ -182,8 +185,18 @@ __global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__rest
         PH_COUNT,
         PH_FILL
     };
-    int phase = (frame->rs_stripe[gid % LPX_RS_STRIPES].v < cap_rs / LPX_RS_STRIPES) ? PH_RESERVE : PH_COUNT;  // sub-region
-                                                                                               // exhausted: do not try
+    // (sub-region exhausted: do not try.)  The four wavefronts of a bucket group MUST agree -- they meet at the barriers of
+    // the phase loop and pool their per-query sizes for ONE allocation.  Rounds 1-5 let every thread read the stripe's
+    // cursor for itself: the cursor moves while other groups allocate, and close to the end of a sub-region one wavefront
+    // of a group could still see room where another no longer did -- one reserved by upper bounds while the other counted
+    // exact lengths, and the group's lists came out with the wrong sizes.  Never seen with 512 words per point of
+    // single-pass room (1000 fresh contexts: 0 wrong partitions); 2-5 per 1000 with the 192 words of round 6, which is
+    // how it was found (tools/r6_flaky.py).  Now lane 0 of wavefront 0 decides (s_phase, behind the barrier above); a
+    // single-node group is one wavefront and takes lane 0's reading.
+    const uint32_t try_rs = BLOCK ? s_phase
+                                  : (uint32_t)__builtin_amdgcn_readfirstlane(
+                                        frame->rs_stripe[gid % LPX_RS_STRIPES].v < cap_rs / LPX_RS_STRIPES ? 1 : 0);
+    int phase = try_rs ? PH_RESERVE : PH_COUNT;
     bool staged_once = false;
     for (;;)
     {
@@ -534,6 +547,100 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
         }
     }
 }
+
+// The same check over the lists of 64 consecutive points AT ONCE (round 6).  cc_hook_kernel gives every list a whole
+// wavefront and three dependent round trips (offset / length / root, the list, the parents of its entries): on a
+// 5M-point frame a list holds 19 entries -- a third of the lanes -- and the 2.3 M trips of 16 384 wavefronts were the
+// kernel's 0.79 ms.  Here a wavefront fetches offset, length and root of 64 points with one coalesced trip, lays their
+// entries end to end (an inclusive scan of the lengths, kept in LDS) and walks that stream 64 entries per step, four steps
+// in flight: every lane finds the point its entry belongs to by a binary search over the scan, every load is independent
+// of the one before.  An entry whose parent differs from its point's root is united right there, lane by lane
+// (uf_unite: stale reads only cost a retry).
+constexpr int CCF_WAVES = 4;
+constexpr int CCF_UNROLL = 4;
+__global__ __launch_bounds__(CCF_WAVES *WAVE) void cc_hook_flat_kernel(const FrameState *__restrict__ frame,
+                                                                         const uint32_t *__restrict__ off,
+                                                                         const uint32_t *__restrict__ len,
+                                                                         const uint32_t *__restrict__ nb_idx,
+                                                                         uint32_t *parent, uint64_t cap,
+                                                                         uint32_t roots_only, FV fv)
+{
+    const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
+    __shared__ uint32_t s_incl[CCF_WAVES][WAVE];
+    // values already known to lie in a point's set besides its root: the (possibly stale) roots it has been united with.
+    // Stale roots repeat all over a dense list; each distinct one costs ONE union instead of a find per entry.
+    __shared__ uint32_t s_acc[CCF_WAVES][2][WAVE];
+    frame = lpx_slot(frame, fv.fs);
+    off = lpx_slot(off, fv.fs);
+    len = lpx_slot(len, fv.fs);
+    parent = lpx_slot(parent, fv.fs);
+    nb_idx = lpx_slot(nb_idx, fv.fs_nb);
+    const uint32_t lane = threadIdx.x % WAVE, w = threadIdx.x / WAVE;
+    const uint32_t M = frame->n_obstacle;
+    if (frame->nb_total > cap)
+        return;
+    uint32_t *const incl_w = s_incl[w];
+    const uint32_t stride = gridDim.x * CCF_WAVES * WAVE;
+    for (uint32_t i0 = (lpx_blk.x * CCF_WAVES + w) * WAVE; i0 < M; i0 += stride)
+    {
+        const uint32_t i = i0 + lane;
+        const bool have = i < M;
+        const uint32_t o = have ? off[i] : 0u;
+        const uint32_t ri = have ? uf_ld(parent + i) : 0u;
+        // roots_only: a first, cheap round over the lists of the forest's roots alone (see cc_hook_kernel)
+        const uint32_t n = (have && !(roots_only && ri != i)) ? len[i] : 0u;
+        const uint32_t incl = lpx_wave_incl_scan_u32(n);
+        const uint32_t T = __shfl(incl, WAVE - 1, WAVE);
+        __builtin_amdgcn_wave_barrier();
+        incl_w[lane] = incl;
+        s_acc[w][0][lane] = ri;
+        s_acc[w][1][lane] = ri;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t e0 = 0; e0 < T; e0 += CCF_UNROLL * WAVE)
+        {
+            uint32_t jj[CCF_UNROLL], kk[CCF_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CCF_UNROLL; ++u)
+            {
+                const uint32_t e = e0 + u * WAVE + lane;
+                // the point whose list holds entry e: the first j with incl[j] > e (64 sorted values in LDS)
+                uint32_t lo = 0;
+#pragma unroll
+                for (uint32_t step = WAVE / 2; step > 0; step >>= 1)
+                    lo += (incl_w[lo + step - 1] <= e) ? step : 0u;
+                lo = lo < (uint32_t)WAVE ? lo : WAVE - 1u;
+                jj[u] = lo;
+                const uint32_t oj = __shfl(o, lo, WAVE);
+                const uint32_t ej = e - (__shfl(incl, lo, WAVE) - __shfl(n, lo, WAVE));
+                kk[u] = nb_idx[e < T ? oj + ej : 0u];
+            }
+            uint32_t pk[CCF_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CCF_UNROLL; ++u)
+            {
+                const uint32_t e = e0 + u * WAVE + lane;
+                const uint32_t k = kk[u] & 0x7fffffffu;
+                const uint32_t ij = i0 + jj[u];
+                // a root's neighbours all have larger indices; otherwise only the smaller end of an edge checks it
+                const bool ask = e < T && (roots_only || k < ij);
+                kk[u] = ask ? k : 0xffffffffu;
+                pk[u] = uf_ld(parent + (ask ? k : 0u));
+            }
+#pragma unroll
+            for (int u = 0; u < CCF_UNROLL; ++u)
+            {
+                const uint32_t rj = __shfl(ri, jj[u], WAVE);
+                if (kk[u] != 0xffffffffu && pk[u] != rj && pk[u] != s_acc[w][0][jj[u]] && pk[u] != s_acc[w][1][jj[u]])
+                {
+                    uf_unite(parent, i0 + jj[u], pk[u]);  // pk is an ancestor of a neighbour: same component
+                    // (lanes of one point may race here: any of their values is one the point has been united with)
+                    s_acc[w][1][jj[u]] = s_acc[w][0][jj[u]];
+                    s_acc[w][0][jj[u]] = pk[u];
+                }
+            }
+        }
+    }
+}
 }  // namespace
 
 int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hook)
@@ -567,11 +674,19 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
         hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
                            (uint32_t *)ctx->parent.p, ctx->fs_tag);
         const uint32_t hgrid = (m_max + 3) / 4 < 4096u ? (m_max + 3) / 4 : 4096u;
+        // LPX_CC_HOOK=list (development build): the one-list-per-wavefront form of rounds 1-5
+        static const bool per_list = LPX_KNOB("LPX_CC_HOOK") && strcmp(LPX_KNOB("LPX_CC_HOOK"), "list") == 0;
+        const uint32_t fgrid = (m_max + 255) / 256 < 4096u ? (m_max + 255) / 256 : 4096u;
         for (uint32_t roots_only = 1;; roots_only = 0)
         {
-            hipLaunchKernelGGL(cc_hook_kernel, dim3(hgrid, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
-                               (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
-                               (uint32_t *)ctx->parent.p, ctx->cap_nb, roots_only, lpx_fv(ctx));
+            if (per_list)
+                hipLaunchKernelGGL(cc_hook_kernel, dim3(hgrid, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
+                                   (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
+                                   (uint32_t *)ctx->parent.p, ctx->cap_nb, roots_only, lpx_fv(ctx));
+            else
+                hipLaunchKernelGGL(cc_hook_flat_kernel, dim3(fgrid, 1, ctx->cur_b), dim3(CCF_WAVES * WAVE), 0, ctx->stream,
+                                   frame, (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
+                                   (uint32_t *)ctx->parent.p, ctx->cap_nb, roots_only, lpx_fv(ctx));
             if (!roots_only)
                 break;
             hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream,
