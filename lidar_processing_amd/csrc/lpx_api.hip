@@ -265,6 +265,8 @@ static void lists_grow_on_evidence(lpx_ctx *ctx)
         if (e.seq != seq)
             continue;  // (being rewritten by a later call: that call's record will be looked at next time)
         newest = (int32_t)(seq - newest) > 0 ? seq : newest;
+        if (b == 0 && e.n_obstacle)
+            ctx->list_short = e.entries < 48ull * e.n_obstacle ? 1 : 0;  // (CC_FLAT_BELOW of lpx_lists.hip)
         const uint64_t stripe_cap = ctx->cap_rs / LPX_RS_STRIPES;
         if (e.stripe_max > stripe_cap && ctx->cap_rs)
         {

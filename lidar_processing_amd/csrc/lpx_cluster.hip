@@ -64,6 +64,10 @@ __global__ __launch_bounds__(256) void flatten_kernel(uint32_t *parent, const Fr
             mx = frame->rs_stripe[i].v > mx ? frame->rs_stripe[i].v : mx;
         o->nb_total = frame->nb_total;
         o->stripe_max = mx;
+        unsigned long long ent = frame->nb_entries;
+        for (uint32_t i = 0; i < LPX_RS_STRIPES; ++i)
+            ent += frame->ent_stripe[i].v;
+        o->entries = ent;
         o->status = frame->status;
         o->n_obstacle = M;
         __threadfence_system();

@@ -160,6 +160,8 @@ struct LpxListStat
     uint32_t status, n_obstacle;
     uint32_t seq;            // lpx_ctx::list_seq of the call that wrote the record
     uint32_t pad;
+    uint64_t entries;        // list entries written (what decides the form of the edge check: lpx_lists.hip)
+    uint64_t pad2;
 };
 
 struct Buf
@@ -232,6 +234,7 @@ struct lpx_ctx
     struct LpxListStat *h_liststat = nullptr;  // pinned, one record per frame slot
     uint32_t list_seq = 0;         // list-mode clusterings enqueued on this context
     uint32_t list_seq_seen = 0;    // ... whose demand has been looked at
+    int list_short = -1;           // the lists of the last frame looked at were short (1) / long (0); -1: not known yet
     uint32_t batch = 1;        // frame slots
     uint32_t cur_b = 1;        // frames of the call being enqueued (gridDim.z)
     uint32_t in_off[3] = {0, 4, 8};  // byte offsets of x, y, z inside a record of the call being enqueued

@@ -483,11 +483,24 @@ __global__ void cc_flatten_kernel(const FrameState *__restrict__ frame, uint32_t
     uf_st(parent + i, x);
 }
 
+// Which of the two edge checks serves a frame is a property of its lists: one wavefront per list (cc_hook_kernel) when
+// they are long -- the reference's frames at d = 0.5 m: ~140 entries -- the lists of 64 points end to end
+// (cc_hook_flat_kernel) when they are short -- BASELINE's 5M-point cloud: 19.  Both are launched; each leaves at once
+// when the frame's average is not its own (the average is on the device only, and an empty launch costs nothing).
+constexpr uint32_t CC_FLAT_BELOW = 48;  // entries per point
+__device__ __forceinline__ bool cc_lists_are_short(const FrameState *frame)
+{
+    unsigned long long e = frame->nb_entries;
+    for (uint32_t i = 0; i < LPX_RS_STRIPES; ++i)
+        e += frame->ent_stripe[i].v;
+    return e < (unsigned long long)CC_FLAT_BELOW * frame->n_obstacle;
+}
+
 __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restrict__ frame,
                                                        const uint32_t *__restrict__ off,
                                                        const uint32_t *__restrict__ len,
                                                        const uint32_t *__restrict__ nb_idx, uint32_t *parent,
-                                                       uint64_t cap, uint32_t roots_only, FV fv)
+                                                       uint64_t cap, uint32_t roots_only, uint32_t regime, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
     frame = lpx_slot(frame, fv.fs);
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
     nb_idx = lpx_slot(nb_idx, fv.fs_nb);
     const uint32_t lane = threadIdx.x % WAVE;
     const uint32_t M = frame->n_obstacle;
-    if (frame->nb_total > cap)
+    if (frame->nb_total > cap || (regime && cc_lists_are_short(frame)))
         return;
     const uint32_t stride = gridDim.x * (blockDim.x / WAVE);
     for (uint32_t i = (lpx_blk.x * blockDim.x + threadIdx.x) / WAVE; i < M; i += stride)
@@ -563,7 +576,7 @@ __global__ __launch_bounds__(CCF_WAVES *WAVE) void cc_hook_flat_kernel(const Fra
                                                                          const uint32_t *__restrict__ len,
                                                                          const uint32_t *__restrict__ nb_idx,
                                                                          uint32_t *parent, uint64_t cap,
-                                                                         uint32_t roots_only, FV fv)
+                                                                         uint32_t roots_only, uint32_t regime, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<4>(fv.fs);
     __shared__ uint32_t s_incl[CCF_WAVES][WAVE];
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(CCF_WAVES *WAVE) void cc_hook_flat_kernel(const Fra
     nb_idx = lpx_slot(nb_idx, fv.fs_nb);
     const uint32_t lane = threadIdx.x % WAVE, w = threadIdx.x / WAVE;
     const uint32_t M = frame->n_obstacle;
-    if (frame->nb_total > cap)
+    if (frame->nb_total > cap || (regime && !cc_lists_are_short(frame)))
         return;
     uint32_t *const incl_w = s_incl[w];
     const uint32_t stride = gridDim.x * CCF_WAVES * WAVE;
@@ -674,19 +687,25 @@ int lpx_neighbours(lpx_ctx *ctx, uint32_t m_max, float r2, float thr_f, bool hoo
         hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
                            (uint32_t *)ctx->parent.p, ctx->fs_tag);
         const uint32_t hgrid = (m_max + 3) / 4 < 4096u ? (m_max + 3) / 4 : 4096u;
-        // LPX_CC_HOOK=list (development build): the one-list-per-wavefront form of rounds 1-5
-        static const bool per_list = LPX_KNOB("LPX_CC_HOOK") && strcmp(LPX_KNOB("LPX_CC_HOOK"), "list") == 0;
+        // LPX_CC_HOOK=list / flat (development build) forces one form for every frame
+        static const char *hook_env = LPX_KNOB("LPX_CC_HOOK");
+        // A single frame launches only the form the context's LAST frame called for (two empty launches are ~15 us of a
+        // 1.7 ms frame); its first frame, and every launch chain, launches both and lets the device decide per frame.
+        const bool known = !hook_env && ctx->cur_b == 1 && ctx->list_short >= 0;
+        const bool only_list = hook_env ? strcmp(hook_env, "list") == 0 : (known && ctx->list_short == 0);
+        const bool only_flat = hook_env ? strcmp(hook_env, "flat") == 0 : (known && ctx->list_short == 1);
+        const uint32_t regime = (only_list || only_flat) ? 0u : 1u;
         const uint32_t fgrid = (m_max + 255) / 256 < 4096u ? (m_max + 255) / 256 : 4096u;
         for (uint32_t roots_only = 1;; roots_only = 0)
         {
-            if (per_list)
+            if (!only_flat)
                 hipLaunchKernelGGL(cc_hook_kernel, dim3(hgrid, 1, ctx->cur_b), dim3(256), 0, ctx->stream, frame,
                                    (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
-                                   (uint32_t *)ctx->parent.p, ctx->cap_nb, roots_only, lpx_fv(ctx));
-            else
+                                   (uint32_t *)ctx->parent.p, ctx->cap_nb, roots_only, regime, lpx_fv(ctx));
+            if (!only_list)
                 hipLaunchKernelGGL(cc_hook_flat_kernel, dim3(fgrid, 1, ctx->cur_b), dim3(CCF_WAVES * WAVE), 0, ctx->stream,
                                    frame, (const uint32_t *)off, (const uint32_t *)len, (const uint32_t *)ctx->nb_idx.p,
-                                   (uint32_t *)ctx->parent.p, ctx->cap_nb, roots_only, lpx_fv(ctx));
+                                   (uint32_t *)ctx->parent.p, ctx->cap_nb, roots_only, regime, lpx_fv(ctx));
             if (!roots_only)
                 break;
             hipLaunchKernelGGL(cc_flatten_kernel, dim3((m_max + 255) / 256, 1, ctx->cur_b), dim3(256), 0, ctx->stream,
