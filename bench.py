@@ -765,9 +765,12 @@ def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_lau
     groups = float((2 << D) - 1)
     kern = dict(STAGE_KERNEL)
     if plan.lists:
-        kern.update(cc_hook="cc_hook_kernel", neighbours="nb_group_kernel", components="cc_flatten_kernel",
-                    replay="replay_lds_kernel<true>" if Mm <= 393216 else "replay_lds_kernel<false>")  # LDS bitmap limit
-    kern["plane_passes"] = "plane_pass_kernel"
+        # (cc_hook: cc_hook_kernel for long lists, cc_hook_flat_kernel for short ones -- the prefix finds whichever moved
+        # the data; the list replay keeps its states in one LDS bitmap up to 393 216 points, per component beyond)
+        kern.update(cc_hook="cc_hook", neighbours="nb_group_kernel", components="cc_flatten_kernel",
+                    replay="replay_lds_kernel<0>" if Mm <= 393216 else "replay_lds_kernel<2>")
+    # launches of more blocks than the device holds run every pass in ONE launch (plane_chain_kernel, round 6)
+    kern["plane_passes"] = "plane_chain_kernel" if pmc_traffic("plane_passes", plan.name, "plane_chain_kernel") else "plane_pass_kernel"
 
     def stage_row(stage):
         algo = frames_per_launch * algorithmic_bytes(stage, Nn, Mm, E, I, P, E_replay, cand, groups)

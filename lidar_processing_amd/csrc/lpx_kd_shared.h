@@ -228,7 +228,10 @@ __device__ void uf_unite(uint32_t *parent, uint32_t a, uint32_t b)
 constexpr int NB_WAVES = 4;
 constexpr int NB_THREADS = NB_WAVES * WAVE;
 constexpr int NB_SEQ = 512;     // interval items in LDS per block (6 KiB)
-constexpr int NB_NODES = 1024;  // candidate nodes staged in LDS per block (16 KiB): 6 workgroups per CU
+#ifndef LPX_NB_NODES
+#define LPX_NB_NODES 1024
+#endif
+constexpr int NB_NODES = LPX_NB_NODES;  // candidate nodes staged in LDS per block (16 KiB): 6 workgroups per CU
 constexpr int NB_BUCKET = 64;
 constexpr int NB_GRAN = 16;     // candidates per cull granule: one row of 16 lanes
 constexpr uint32_t NB_FINAL = 0x80000000u;

@@ -33,7 +33,12 @@ namespace
 // BLOCK = false: one wavefront per node above the bucket level (a single query each)
 // Both count, allocate (64-bit atomic bump of frame->nb_total, one block of list storage per group)
 // and fill in the same launch; off[i] / len[i] locate the list of point i.
-__global__ __launch_bounds__(NB_THREADS) void nb_group_kernel(const Node *__restrict__ PR, FrameState *frame,
+#ifdef LPX_NB_WPE
+#define NB_GROUP_BOUNDS __launch_bounds__(NB_THREADS) __attribute__((amdgpu_waves_per_eu(LPX_NB_WPE, LPX_NB_WPE)))
+#else
+#define NB_GROUP_BOUNDS __launch_bounds__(NB_THREADS)
+#endif
+__global__ NB_GROUP_BOUNDS void nb_group_kernel(const Node *__restrict__ PR, FrameState *frame,
                                                                float r2, float rr, float thr_f,
                                                                uint32_t *__restrict__ len,
                                                                uint32_t *__restrict__ off,
