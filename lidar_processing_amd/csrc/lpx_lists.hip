@@ -89,11 +89,22 @@ __global__ NB_GROUP_BOUNDS void nb_group_kernel(const Node *__restrict__ PR, Fra
         level = 31 - __clz(u + 1);
         path = u + 1 - (1u << level);
     }
-    uint32_t gb = 0, ge = M, grank = 0;
+    // A split node above the bucket level is a query of its own -- 65 535 one-query groups beside the 61 440 buckets of a
+    // 5M-point frame, each a wavefront that walks the whole tree for ONE list (18 % of the kernel).  The nodes of the last
+    // NB_ADOPT levels above the buckets (15/16 of them) are adopted by a bucket instead: node u rides with its in-order
+    // predecessor bucket -- the rightmost bucket of its left subtree, which lies in the same small cell -- as that
+    // group's last query.  Both sides evaluate the same predicate: the bucket adopts its ancestor at level D - 1 - t (t =
+    // trailing ones of its path, the bit above them a zero) iff t < NB_ADOPT and it has a lane to spare; the node's own
+    // group leaves iff that bucket exists and adopts it.
+    constexpr uint32_t NB_ADOPT = 4;
+    const uint32_t tz = BLOCK ? (uint32_t)__builtin_ctz(~path) : 0u;  // (path == 2^D - 1: tz >= D, nothing above)
+    uint32_t gb = 0, ge = M, grank = 0, rank_up = 0xffffffffu;
     for (int d = (int)level - 1; d >= 0; --d)
     {
         if (gb >= ge)
             break;
+        if (BLOCK && (uint32_t)d == tz)
+            rank_up = grank;  // the node whose left subtree this bucket closes on the right
         const uint32_t mid = gb + (ge - gb) / 2;
         if ((path >> d) & 1u)
         {
@@ -108,9 +119,20 @@ __global__ NB_GROUP_BOUNDS void nb_group_kernel(const Node *__restrict__ PR, Fra
     }
     if (gb >= ge)
         return;
-    const uint32_t nq = __builtin_amdgcn_readfirstlane(BLOCK ? (ge - gb) : 1u);
+    if (!BLOCK && level < D && D - 1 - level < NB_ADOPT)
+    {
+        // this node's in-order predecessor bucket: left child, then right children down to the bucket level
+        uint32_t b1 = gb, e1 = gb + (ge - gb) / 2;
+        for (uint32_t l = level + 1; l < D && b1 < e1; ++l)
+            b1 = b1 + (e1 - b1) / 2 + 1;
+        if (b1 < e1 && e1 - b1 < (uint32_t)WAVE)
+            return;  // adopted: that bucket's group builds this node's list
+    }
+    const uint32_t nqb = BLOCK ? (ge - gb) : 1u;
+    const bool adopt = BLOCK && tz < NB_ADOPT && tz < D && rank_up != 0xffffffffu && nqb < (uint32_t)WAVE;
+    const uint32_t nq = __builtin_amdgcn_readfirstlane(nqb + (adopt ? 1u : 0u));
     const bool active = lane < nq;
-    const Node q = PR[grank + (active ? lane : 0u)];
+    const Node q = PR[(adopt && lane == nqb) ? rank_up : grank + (active ? lane : 0u)];
     const uint32_t qi = __float_as_uint(q.w);
 
     // LDS partition: BLOCK mode uses everything, wave mode a quarter each
