@@ -96,7 +96,10 @@ __global__ NB_GROUP_BOUNDS void nb_group_kernel(const Node *__restrict__ PR, Fra
     // group's last query.  Both sides evaluate the same predicate: the bucket adopts its ancestor at level D - 1 - t (t =
     // trailing ones of its path, the bit above them a zero) iff t < NB_ADOPT and it has a lane to spare; the node's own
     // group leaves iff that bucket exists and adopts it.
-    constexpr uint32_t NB_ADOPT = 4;
+#ifndef LPX_NB_ADOPT
+#define LPX_NB_ADOPT 4
+#endif
+    constexpr uint32_t NB_ADOPT = LPX_NB_ADOPT;
     const uint32_t tz = BLOCK ? (uint32_t)__builtin_ctz(~path) : 0u;  // (path == 2^D - 1: tz >= D, nothing above)
     uint32_t gb = 0, ge = M, grank = 0, rank_up = 0xffffffffu;
     for (int d = (int)level - 1; d >= 0; --d)

@@ -1944,14 +1944,14 @@ __global__ __launch_bounds__(PASS_THREADS, LPX_PASS_MINWAVES) void plane_chain_k
 // compaction: flags -> labels (original order), ground / obstacle index lists in output-cloud
 // order (:331-343, Q7) and the obstacle SoA handed to clustering.
 // ------------------------------------------------------------------------------------------------
-template <bool BYTE_LABELS>  // large frames: one byte per point into an L2-resident scratch (labels_widen_kernel follows)
+template <bool SCATTER_LABELS>  // small frames: the labels by original index from here (they merge in the frame's L2)
 __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__restrict__ flags,
                                                                const uint32_t *__restrict__ sidx,
                                                                const float *__restrict__ XS,
                                                                const float *__restrict__ YS,
                                                                const float *__restrict__ ZS, SegParams prm,
                                                                const uint32_t *__restrict__ blk_offs,
-                                                               uint8_t *__restrict__ lab8, uint32_t *__restrict__ labels,
+                                                               uint32_t *__restrict__ labels,
                                                                uint32_t *__restrict__ gidx, uint32_t *__restrict__ oidx,
                                                                float *__restrict__ OX, float *__restrict__ OY,
                                                                float *__restrict__ OZ, float4 *__restrict__ nodes,
@@ -1973,7 +1973,6 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     nodes = lpx_slot(nodes, fv.fs);
     st = lpx_slot(st, fv.fs);
     frame = lpx_slot(frame, fv.fs);
-    lab8 = lpx_slot(lab8, fv.fs);
     labels = lpx_user(labels, fv.upitch);
     gidx = lpx_user(gidx, fv.upitch);
     oidx = lpx_user(oidx, fv.upitch);
@@ -2084,10 +2083,8 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
             if (in)
             {
                 const uint32_t i = si[r];
-                if (BYTE_LABELS)
-                    lab8[i] = (uint8_t)f[r];  // one BYTE by original index: see labels_widen_kernel
-                else
-                    labels[i] = f[r];
+                if (SCATTER_LABELS)
+                    labels[i] = f[r];  // (large frames: labels_direct_kernel, no scatter)
                 if (f[r] == 1u)
                     gidx[gpos + __popcll(mg & lt)] = i;
                 else if (f[r] == 2u)
@@ -2121,13 +2118,9 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     if (s == 0 && b == 0)
     {
         // the N mod P highest-x points belong to no segment (Q2); written UNKNOWN (Q3)
-        for (uint32_t p = prm.P * prm.n_per + tid; p < prm.n; p += SEG_THREADS)
-        {
-            if (BYTE_LABELS)
-                lab8[sidx[p]] = (uint8_t)LPX_LABEL_UNKNOWN;
-            else
+        if (SCATTER_LABELS)
+            for (uint32_t p = prm.P * prm.n_per + tid; p < prm.n; p += SEG_THREADS)
                 labels[sidx[p]] = LPX_LABEL_UNKNOWN;
-        }
         if (tid == 0)
         {
             frame->n_ground = total_g;
@@ -2139,42 +2132,104 @@ __global__ __launch_bounds__(SEG_THREADS) void compact_kernel(const uint8_t *__r
     }
 }
 
-// The labels in ORIGINAL order.  The compaction walks the cloud in x-sorted order and knows a point's label there; its
-// original index is random with respect to that order, so writing the caller's 4-byte label from there touched a
-// different line with every store -- a 1M-point frame's 4 MB label array does not stay in an XCD's L2 beside the other
-// frames of a chain, every store went out as a partial line and the kernel moved 3.5 x its algorithmic bytes (round 5:
-// 15 % of the HBM roofline).  Frames of more than LABEL_BYTES_FROM points now scatter ONE BYTE per point into a
-// frame-sized scratch (1 MB per million points: resident in the frame's L2, where the partial stores merge and every
-// line leaves once), and this kernel streams the bytes out as the caller's 32-bit labels (1M-point chains: 583 -> 408 +
-// 45 us; a 120k-point frame's 0.5 MB of labels merge in L2 as they are, there the second launch would only cost): 16 points per thread, one 16-byte load, four 16-byte
-// stores (VEC: the caller's array and pitch are 16-byte aligned; otherwise word stores).
-constexpr uint32_t LABEL_BYTES_FROM = 262144u;  // points of the largest frame of a call
-template <bool VEC>
-__global__ __launch_bounds__(256) void labels_widen_kernel(const uint8_t *__restrict__ lab8, uint32_t *__restrict__ labels,
-                                                           const FrameState *__restrict__ frame, FV fv)
+// The labels in ORIGINAL order, WITHOUT a scatter (round 6).  The compaction walks the cloud in x-sorted order and knows a
+// point's label there; its original index is random with respect to that order, so writing the caller's label from
+// there was one memory request per point whatever its width (4-byte stores: 3.5 x the algorithmic bytes moved, 15 % of
+// the HBM roofline on 1M-point frames; one byte per point into an L2-resident scratch plus a widening pass: 19 % -- the
+// lines merge, the requests stay: 11.6 M L2 requests per 8 M points, 8 M of them this scatter).  A label is a function
+// of the point alone once the planes are final: its segment follows from its x key and index against the P segment
+// boundaries of the sorted order -- (key, index) pairs, compared the way the stable sort orders them -- and its side of
+// the segment's plane from final_label(), the very expression the final plane pass evaluates.  So this kernel streams the
+// caller's records once more in input order (16 of every 32 bytes, coalesced) and stores the labels coalesced.
+// Identical results by construction (same floats, same expressions, -ffp-contract=off); the N mod P points beyond the
+// last segment are UNKNOWN (Q2, Q3) as before.
+__device__ __forceinline__ uint32_t final_label(float lo_excl, float hi_incl, float pa, float pb, float pc, float pd, float thr,
+                                                uint32_t code, uint32_t I, float x, float y, float z)
+{
+    // code: bit 0 nothing is labelled (failed == 2), bit 1 dead (failed != 0), bit 2 the segment has seeds
+    const bool skip = code & 1u, dead = code & 2u, seeds_ok = code & 4u;
+    bool member;
+    if (I == 0)
+        member = seeds_ok && (z > lo_excl) && (z <= hi_incl);  // the only pass is pass 0: the seed window (:243)
+    else
+    {
+        const float dist = ((x * pa + y * pb) + z * pc) - pd;   // pass_quad_lean / pass_block_generic, bit for bit
+        member = dist < thr;
+    }
+    member = member && !dead;
+    // number_of_iterations == 0: seeds are ground, the rest stays UNKNOWN (:243-247)
+    return skip ? LPX_LABEL_UNKNOWN : (member ? LPX_LABEL_GROUND : ((I == 0 && !dead) ? LPX_LABEL_UNKNOWN : LPX_LABEL_OBSTACLE));
+}
+
+constexpr int LBL_THREADS = 256, LBL_PER = 4;
+constexpr uint32_t LABELS_DIRECT_FROM = 262144u;  // points of the largest frame of a call
+__global__ __launch_bounds__(LBL_THREADS) void labels_direct_kernel(const float4 *__restrict__ rec, LpxRecLayout lay,
+                                                                    const float *__restrict__ XS,
+                                                                    const uint32_t *__restrict__ sidx, SegParams prm,
+                                                                    const SegState *__restrict__ st,
+                                                                    uint32_t *__restrict__ labels,
+                                                                    const FrameState *__restrict__ frame, FV fv)
 {
     const LpxBlock lpx_blk = lpx_block<0>(fv.fs);
-    lab8 = lpx_slot(lab8, fv.fs);
+    __shared__ unsigned long long s_bound[LPX_MAX_PARTITIONS];  // (key << 32 | index) of the first point of segments 1 .. P
+    __shared__ float s_pl[LPX_MAX_PARTITIONS][7];
+    __shared__ uint32_t s_code[LPX_MAX_PARTITIONS];
+    if (lay.stride == 0)
+        rec = lpx_slot(rec, fv.fs);  // the arena's copy of the cloud
+    else
+        rec = (const float4 *)((const char *)rec + (size_t)lpx_blk.z * lay.pitch * lay.stride);  // the records of the call
+    XS = lpx_slot(XS, fv.fs);
+    sidx = lpx_slot(sidx, fv.fs);
+    st = lpx_slot(st, fv.fs);
     frame = lpx_slot(frame, fv.fs);
     labels = lpx_user(labels, fv.upitch);
-    const uint32_t n = frame->n_in;
-    const uint32_t p0 = (lpx_blk.x * 256u + threadIdx.x) * 16u;
-    if (p0 >= n)
+    seg_bind(prm, frame);
+    const uint32_t n = prm.n, P = prm.P, n_per = prm.n_per;
+    if (lpx_blk.x * (uint32_t)(LBL_THREADS * LBL_PER) >= n)
         return;
-    const uint4 b = *(const uint4 *)(lab8 + p0);  // (the scratch is padded to a multiple of 16 bytes)
-    const uint32_t w[4] = {b.x, b.y, b.z, b.w};
-    if (VEC && p0 + 16u <= n)
+    for (uint32_t sgm = threadIdx.x; sgm < P; sgm += LBL_THREADS)
     {
+        // boundary sgm + 1: the first sorted position that no longer belongs to segment sgm
+        const uint32_t pos = (sgm + 1u) * n_per;
+        s_bound[sgm] = (n_per && pos < n) ? (((unsigned long long)lpx_float_key(XS[pos]) << 32) | sidx[pos]) : ~0ull;
+        const SegState ss = st[sgm];
+        s_pl[sgm][0] = ss.lo_excl, s_pl[sgm][1] = ss.hi_incl;
+        s_pl[sgm][2] = ss.plane[0], s_pl[sgm][3] = ss.plane[1], s_pl[sgm][4] = ss.plane[2], s_pl[sgm][5] = ss.plane[3];
+        s_pl[sgm][6] = ss.thr;
+        s_code[sgm] = (ss.failed == 2 ? 1u : 0u) | (ss.failed != 0 ? 2u : 0u) | (ss.has_seeds ? 4u : 0u);
+    }
+    __syncthreads();
+    const uint32_t i0 = lpx_blk.x * (uint32_t)(LBL_THREADS * LBL_PER) + threadIdx.x;
+    float4 q[LBL_PER];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *(uint4 *)(labels + p0 + 4 * q) =
-                make_uint4(w[q] & 255u, (w[q] >> 8) & 255u, (w[q] >> 16) & 255u, w[q] >> 24);
-        return;
+    for (int u = 0; u < LBL_PER; ++u)
+    {
+        const uint32_t i = i0 + u * LBL_THREADS;
+        q[u] = lpx_rec_xyz(rec, i < n ? i : 0u, lay);
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-        if (p0 + q < n)
-            labels[p0 + q] = (w[q >> 2] >> (8 * (q & 3))) & 255u;
+    for (int u = 0; u < LBL_PER; ++u)
+    {
+        const uint32_t i = i0 + u * LBL_THREADS;
+        if (i >= n)
+            continue;
+        const unsigned long long me = ((unsigned long long)lpx_float_key(q[u].x) << 32) | i;
+        // the segment: how many boundaries lie at or before this point in (key, index) order
+        uint32_t lo = 0, hi = P;  // first sgm in [lo, hi) with s_bound[sgm] > me
+        while (lo < hi)
+        {
+            const uint32_t mid = (lo + hi) / 2;
+            if (s_bound[mid] <= me)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        uint32_t lab = LPX_LABEL_UNKNOWN;  // lo == P: one of the N mod P highest-x points (or n < P: no segment at all)
+        if (lo < P && n_per)
+            lab = final_label(s_pl[lo][0], s_pl[lo][1], s_pl[lo][2], s_pl[lo][3], s_pl[lo][4], s_pl[lo][5], s_pl[lo][6],
+                              s_code[lo], prm.I, q[u].x, q[u].y, q[u].z);
+        labels[i] = lab;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2586,28 +2641,31 @@ int lpx_run_segment(lpx_ctx *ctx, const void *d_pts, size_t stride, const uint32
     }
     {
         StageTimer tm(ctx, ST_COMPACT);
-        // (the byte labels live in the second key buffer of the x sort: free from the sort's last pass to the clustering)
-        uint8_t *const lab8 = (uint8_t *)ctx->key_b.p;
-        const bool byte_labels = n > LABEL_BYTES_FROM;
+        // The labels by original index.  Frames above LABELS_DIRECT_FROM points: recomputed from the records in input order
+        // (labels_direct_kernel: no scatter; 32 x 1M chain: compaction 583 -> 198 + 234 us).  Smaller frames: scattered from
+        // the compaction as 4-byte stores -- a 123k-point frame's 0.5 MB of labels merge in its L2, and the second launch and
+        // the second pass over the records would only cost (64-frame stream chain: 0.090 against 0.118 ms).
+        static const char *ld_env = LPX_KNOB("LPX_LABELS_DIRECT");  // development build: 1 / 0 forces the form (tests)
+        const bool labels_direct = ld_env ? ld_env[0] == '1' : n > LABELS_DIRECT_FROM;
 #define LPX_COMPACT_ARGS                                                                                               \
-    dim3(prm.bps, P, B), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p, sidx, XS, YS, ZS, prm, blk_counts, lab8, \
+    dim3(prm.bps, P, B), dim3(SEG_THREADS), 0, st, (const uint8_t *)ctx->flags.p, sidx, XS, YS, ZS, prm, blk_counts,      \
         d_labels, d_gidx, d_oidx, (float *)ctx->OX.p, (float *)ctx->OY.p, (float *)ctx->OZ.p, (float4 *)ctx->nodes.p,     \
         sst + (size_t)(I & 1u) * LPX_MAX_PARTITIONS, /* the state the head of the final pass published */               \
         d_planes, frame, fv
-        if (!byte_labels)
+        if (labels_direct)
             hipLaunchKernelGGL(compact_kernel<false>, LPX_COMPACT_ARGS);
         else
-        {
             hipLaunchKernelGGL(compact_kernel<true>, LPX_COMPACT_ARGS);
-            const dim3 gw((n + 4095u) / 4096u, 1, B);
-            if ((((uintptr_t)d_labels | ((size_t)fv.upitch * sizeof(uint32_t))) & 15u) == 0)
-                hipLaunchKernelGGL(labels_widen_kernel<true>, gw, dim3(256), 0, st, (const uint8_t *)lab8, d_labels,
-                                   (const FrameState *)frame, fv);
-            else
-                hipLaunchKernelGGL(labels_widen_kernel<false>, gw, dim3(256), 0, st, (const uint8_t *)lab8, d_labels,
-                                   (const FrameState *)frame, fv);
-        }
 #undef LPX_COMPACT_ARGS
+        static const uint32_t table_off[3] = {0, 4, 8};
+        const LpxRecLayout lay = direct ? lpx_rec_layout(d_pts, stride, ctx->in_off, ctx->upitch)
+                                        : lpx_rec_layout(P4, 0, table_off, 0);
+        if (labels_direct)
+            hipLaunchKernelGGL(labels_direct_kernel, dim3((n + LBL_THREADS * LBL_PER - 1) / (LBL_THREADS * LBL_PER), 1, B),
+                           dim3(LBL_THREADS), 0, st, (const float4 *)(direct ? d_pts : (const void *)P4), lay,
+                           (const float *)XS, (const uint32_t *)sidx, prm,
+                           (const SegState *)(sst + (size_t)(I & 1u) * LPX_MAX_PARTITIONS), d_labels,
+                           (const FrameState *)frame, fv);
     }
     LPX_HIP(ctx, hipGetLastError());
     return LPX_OK;

@@ -166,7 +166,7 @@ def test_plane_bit_exact(ctx, n):
     assert got[2] > 0.99
 
 
-@pytest.mark.parametrize("form", ["head", "tail", "chain"])
+@pytest.mark.parametrize("form", ["head", "tail", "chain", "labels_direct"])
 def test_plane_solve_at_the_head_and_at_the_tail_agree_with_the_oracle(form):
     """plane_pass_kernel solves the 3x3 problem of a pass either at the head of every block (launches resident all at
     once) or once per segment at the tail of the block that draws the segment's last ticket (larger launches); the
@@ -180,7 +180,15 @@ def test_plane_solve_at_the_head_and_at_the_tail_agree_with_the_oracle(form):
     here = os.path.dirname(os.path.abspath(__file__))
     # "chain": ALL passes of a call in one launch (plane_chain_kernel: blocks of pass t + 1 wait for the state a block of
     # pass t publishes), forced for every launch shape by LPX_PASS_CHAIN=1
-    knobs = dict(LPX_PASS_CHAIN="1", LPX_PASS_SOLVE="tail") if form == "chain" else dict(LPX_PASS_SOLVE=form, LPX_PASS_CHAIN="0")
+    # "labels_direct": the labels by original index recomputed from the records in input order (labels_direct_kernel, the
+    # form of frames above 262 144 points), forced for every frame by LPX_LABELS_DIRECT=1 -- fewer points than partitions,
+    # the N mod P leftover points, zero iterations, dead segments, far points, 200 segments
+    if form == "chain":
+        knobs = dict(LPX_PASS_CHAIN="1", LPX_PASS_SOLVE="tail")
+    elif form == "labels_direct":
+        knobs = dict(LPX_LABELS_DIRECT="1")
+    else:
+        knobs = dict(LPX_PASS_SOLVE=form, LPX_PASS_CHAIN="0")
     env = dict(os.environ, **knobs, LPX_LIB=_lib.DEV_LIB_PATH,
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get("PYTHONPATH", "")]))
     r = subprocess.run([sys.executable, os.path.join(here, "solve_form_check.py")], env=env, capture_output=True, text=True,
