@@ -1322,6 +1322,13 @@ __device__ __forceinline__ bool plane_from_moment_lanes(long long v, uint32_t la
     return true;
 }
 
+// signed distance of a point to a plane, scaled by |normal| (Q1): ONE definition for every kernel that classifies a point
+// (plane passes lean and general, labels_direct_kernel) -- no FMA (-ffp-contract=off), this order of operations
+__device__ __forceinline__ float plane_dist(float x, float y, float z, float pa, float pb, float pc, float pd)
+{
+    return ((x * pa + y * pb) + z * pc) - pd;
+}
+
 // ---- the general form of the loop, for frames that hold a point beyond +-2048 m (rare: a spurious far return, a cloud in
 // a map frame): member points that do not fit the int32 lanes go to the segment's far accumulator one by one.  Kept out
 // of line, loading for itself, so that its registers and its call do not shape the allocation of the lean loop.
@@ -1369,7 +1376,7 @@ __device__ __noinline__ void pass_block_generic(const float *XS, const float *YS
                     member = seeds_ok && (z > sst.lo_excl) && (z <= sst.hi_incl);
                 else
                 {
-                    const float dist = ((x * pa + y * pb) + z * pc) - pd;
+                    const float dist = plane_dist(x, y, z, pa, pb, pc, pd);
                     member = dist < thr;
                 }
                 member = member && !dead && in;
@@ -1483,7 +1490,7 @@ __device__ __forceinline__ void pass_quad_lean(const pass_v4f x4, const pass_v4f
             member = (z > U.lo_excl) && (z <= U.hi_incl);
         else
         {
-            const float dist = ((x * U.pa + y * U.pb) + z * U.pc) - U.pd;
+            const float dist = plane_dist(x, y, z, U.pa, U.pb, U.pc, U.pd);
             member = dist < U.thr;
         }
         bool in = true;
@@ -2153,7 +2160,7 @@ __device__ __forceinline__ uint32_t final_label(float lo_excl, float hi_incl, fl
         member = seeds_ok && (z > lo_excl) && (z <= hi_incl);  // the only pass is pass 0: the seed window (:243)
     else
     {
-        const float dist = ((x * pa + y * pb) + z * pc) - pd;   // pass_quad_lean / pass_block_generic, bit for bit
+        const float dist = plane_dist(x, y, z, pa, pb, pc, pd);  // what pass_quad_lean / pass_block_generic evaluate
         member = dist < thr;
     }
     member = member && !dead;
