@@ -168,7 +168,10 @@ def binding_resources(workload, chain_ms, frames_per_chain, frames_per_s):
     measured in this run; `traffic_stale` says whether the profiles were made by the library that is loaded."""
     out = {"what": "committed PMC summaries of ONE launch chain alone on the device, priced at this run's rate"}
     try:
-        r = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_requests.json")))
+        rpath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload}_requests.json")
+        if not os.path.exists(rpath) and workload == "kitti":  # (the stream's frames and chain shape)
+            rpath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_stream_requests.json")
+        r = json.load(open(rpath))
         per_chain = float(r["fabric_requests_per_chain"])
         burn = json.load(open(os.path.join(ROOT, "profiles", "r04_stream_burners.json")))
         lines = 1024 * 256 * 96  # LPX_BURN_MEM=96: loads of one launch, each its own 64-byte line
@@ -181,7 +184,7 @@ def binding_resources(workload, chain_ms, frames_per_chain, frames_per_s):
                            "ceiling_per_s": round(ceiling), "frac": round(per_frame * frames_per_s / ceiling, 4),
                            "ceiling_what": "scattered 64-byte line requests per second of burn_mem_kernel alone on the "
                                            "device (profiles/r04_stream_burners.json)",
-                           "source": f"profiles/{PROFILE_ROUND}_{workload}_requests.json"}
+                           "source": os.path.relpath(rpath, ROOT)}
     except Exception as e:
         out["requests"] = {"error": repr(e)[:160]}
     try:
@@ -772,7 +775,10 @@ def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_lau
         kern.update(cc_hook="cc_hook", neighbours="nb_group_kernel", components="cc_flatten_kernel",
                     replay="replay_lds_kernel<0>" if Mm <= 393216 else "replay_lds_kernel<2>")
     # launches of more blocks than the device holds run every pass in ONE launch (plane_chain_kernel, round 6)
+    # (which of the two a launch is follows from its block count inside the library; the committed counter runs of
+    # configs[2] use 8-frame chains -- separate launches -- so their traffic is looked up under plane_pass_kernel)
     kern["plane_passes"] = "plane_chain_kernel" if pmc_traffic("plane_passes", plan.name, "plane_chain_kernel") else "plane_pass_kernel"
+    plane_name = "plane_chain_kernel (all passes in one launch)" if plan.name == "synth1m" and plan.B >= 16 else "plane_pass_kernel"
 
     def stage_row(stage):
         algo = frames_per_launch * algorithmic_bytes(stage, Nn, Mm, E, I, P, E_replay, cand, groups)
@@ -822,7 +828,7 @@ def roofline_of(plan, counts, elapsed, steps, world, stage_ms, launches, per_lau
                       "frac_of_copy_bandwidth": round(frame_gbs / copy_gbs, 5) if copy_gbs else None},
             # the kernels that ARE plain HBM streams, each alone on the device, their own algorithmic bytes
             "streaming_kernels": {s: stage_row(s) for s in STREAMING if per_launch.get(s, 0) > 0},
-            "plane_passes": stage_row("plane_passes") if per_launch.get("plane_passes", 0) > 0 else None,
+            "plane_passes": dict(stage_row("plane_passes"), kernel=plane_name) if per_launch.get("plane_passes", 0) > 0 else None,
             "hbm_copy_kernel_gbs": round(copy_gbs, 1),
             # the resources that DO bind (requests against the burner's ceiling, vector-ALU busy) and whether the
             # committed profiles `traffic` and these come from were made by the loaded library

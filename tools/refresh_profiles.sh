@@ -32,7 +32,7 @@ for W in $WORKLOADS; do
   # counter passes: one context, one chain per step (synth5m: two frames, rocprofv3 --pmc crashed with eight resident)
   (cd $R && tools/probe.sh traffic $TAG $W > $O/traffic_$W.log 2>&1)
   cp $O/${W}_pmc_fetch_write_per_kernel.json $O/${TAG}_${W}_pmc_fetch_write_per_kernel.json
-  if [ $W = stream ] || [ $W = synth1m ]; then
+  if [ $W = stream ] || [ $W = synth1m ] || [ $W = synth5m ]; then
     (cd $R && tools/probe.sh requests $TAG $W > $O/requests_$W.log 2>&1)
     python3 - $O/requests_$W.json > $O/${TAG}_${W}_requests.json <<'PY'
 import json, sys
