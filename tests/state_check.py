@@ -32,6 +32,23 @@ for mode in ("lists", "search"):
                 checked += 1
     finally:
         ctx.close()
+# one component of more members than the component-local bitmap holds (65 536): 120 000 points scattered over a
+# 90 m x 90 m sheet (12.6 per m2, far above the percolation density for d = 0.5 m: the largest component has 119 993
+# members) -- LPX_RP_STATE=2 sends it through the HBM form INSIDE the local-state kernel
+rng = np.random.default_rng(11)
+lattice = np.zeros((120_000, 4), np.float32)
+lattice[:, 0] = rng.uniform(0, 90, lattice.shape[0]).astype(np.float32)
+lattice[:, 1] = rng.uniform(0, 90, lattice.shape[0]).astype(np.float32)
+lattice[:, 2] = rng.uniform(-0.05, 0.05, lattice.shape[0]).astype(np.float32)
+want_l, want_n = oracle.cluster(lattice, oracle.CluCfg(0.25, 0.5))
+ctx = Context(0)
+ctx.set_neighbour_mode("lists")
+try:
+    lab, nc = ctx.cluster(lattice, ClusteringConfiguration(0.25, 0.5))
+    assert nc == want_n and np.array_equal(lab, want_l), "sheet: one component of 119 993 members"
+    checked += 1
+finally:
+    ctx.close()
 seg_kw = dict(number_of_planar_partitions=4, number_of_iterations=3)
 clu_kw = dict(distance_squared=0.36, cluster_quality=0.3, min_cluster_size=3)
 sizes = [30_000, 0, 3, 11_111, 8_193, 64, 20_001, 5_000, 257]
