@@ -89,12 +89,16 @@ int lpx_create_on_stream(int device, void *hip_stream, lpx_ctx **out);
 void lpx_destroy(lpx_ctx *ctx);
 /* Segmenter::reserve_memory / Clusterer::reserve_memory (src/segmentation.cpp:44-60,
  * src/clustering.cpp:37-45): pre-size all device scratch for n points.  Scratch also grows on
- * demand.  neighbours_per_point sizes the radius-neighbour lists, one 32-bit word per neighbour (0 = default
- * 256); the host entry points grow this workspace and retry when a frame needs more, the device entry points
- * report LPX_ERR_CAPACITY in the frame's status word. */
+ * demand.  neighbours_per_point sizes the exact-length region of the radius-neighbour lists of LPX_NEIGHBOURS_LISTS, one
+ * 32-bit word per neighbour (0 = keep the default: 64, times ceil(distance_squared / 0.25) up to 4).  The list workspace
+ * GROWS ON EVIDENCE: every list-mode clustering records what it asked for, and the next call on the context sizes both
+ * regions to 1.25 x the largest demand seen (a 123k-point frame at d = 0.5 m: 126 MB).  A frame that outgrows the
+ * workspace before that: the host entry points grow it and repeat the frame themselves, the device entry points report
+ * LPX_ERR_CAPACITY in that frame's status word (the next call finds the workspace grown; reserve ahead for dense scenes). */
 int lpx_reserve(lpx_ctx *ctx, uint32_t n_points, uint32_t neighbours_per_point);
-/* Extra neighbour workspace (32-bit words per point, default 512) in which the neighbour kernel may keep
- * lists reserved by an upper bound of their length, which saves its counting pass.  It never changes what
+/* Extra neighbour workspace (32-bit words per point, default 192, scaled and grown like the above) in which the
+ * neighbour kernel may keep lists reserved by an upper bound of their length, which saves its counting pass.  It never
+ * changes what
  * fits: a kd group that finds no room there counts first and uses the lpx_reserve workspace.  0 disables. */
 int lpx_reserve_single_pass(lpx_ctx *ctx, uint32_t words_per_point);
 /* Device memory the context holds right now, in bytes: bytes2[0] = the frame-slot arenas (~400 B per reserved point and

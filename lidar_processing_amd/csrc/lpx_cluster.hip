@@ -518,7 +518,7 @@ __device__ __forceinline__ void replay_component(const ReplayArrays &A, const Re
                         const uint32_t sid = MODE == RP_STATE_LOCAL ? (in ? pw : 0u) : k;
                         const uint32_t sk = in ? ST_GET(sid) : 2u;
                         const bool vis = in && !(sk & 2u);
-                        touches += __popcll(__ballot(vis));
+                        touches += __popcll(__ballot(vis));  // (an early way out for steps without a visible entry: 1.72 -> 1.75 ms)
                         const bool absorb = vis && (kw >> 31);
                         const bool push = vis && !absorb && sk == 0u;
                         const unsigned long long pmask = __ballot(push);

@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const FrameState *__restri
 // entries end to end (an inclusive scan of the lengths, kept in LDS) and walks that stream 64 entries per step, four steps
 // in flight: every lane finds the point its entry belongs to by a binary search over the scan, every load is independent
 // of the one before.  An entry whose parent differs from its point's root is united right there, lane by lane
-// (uf_unite: stale reads only cost a retry).
+// (uf_unite: stale reads only cost a retry).  (The cheap first round over the roots' lists alone stays: without it the
+// full round costs more than both together -- 5M: 0.465 against 0.397 ms.)
 constexpr int CCF_WAVES = 4;
 constexpr int CCF_UNROLL = 4;
 __global__ __launch_bounds__(CCF_WAVES *WAVE) void cc_hook_flat_kernel(const FrameState *__restrict__ frame,
