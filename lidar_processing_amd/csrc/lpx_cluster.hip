@@ -783,31 +783,40 @@ struct RsBatch
     uint32_t cnt[RS_BATCH], rk[RS_BATCH];
 };
 
-// requests the next (up to RS_BATCH) chunks named by the bits of `km` (lane c of `ch` describes chunk c), in order
+// requests the next (up to RS_BATCH) chunks named by the bits of `km` (lane c of `ch` describes chunk c), in order; a
+// LONG chunk (the tail of a group with more chunks than lanes: more than 64 ranks) closes its batch, so that the rest of
+// it is always the last thing rs_consume tests
 __device__ __forceinline__ void rs_issue(RsBatch &b, const KdNode *__restrict__ PR, const ChunkRec &ch,
                                          unsigned long long &km, uint32_t lane)
 {
+    bool closed = false;
 #pragma unroll
     for (int u = 0; u < RS_BATCH; ++u)
     {
         b.cnt[u] = 0u;
         b.rk[u] = 0u;
-        if (km)
+        if (km && !closed)
         {
             const int c = __ffsll((long long)km) - 1;
             km &= km - 1;
             b.rk[u] = (uint32_t)__builtin_amdgcn_readlane((int)ch.rank, c);
             b.cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)ch.count, c);
+            closed = b.cnt[u] > 64u;
         }
         b.nd[u] = PR[lane < b.cnt[u] ? b.rk[u] + lane : 0u];  // unconditional: the loads of a batch go out back to back
     }
 }
 
-// distance-tests the chunks of a batch in order; SINK(word) gets the per-lane list words of every chunk step
-template <class Sink>
-__device__ __forceinline__ void rs_consume(const RsBatch &b, const KdNode *__restrict__ PR, float qx, float qy, float qz,
+// distance-tests the chunks of a batch in order; SINK(word) gets the per-lane list words of every chunk step.
+// TAIL8: the rest of a long chunk is fetched up to eight steps at a time -- the dense-scene kernels, where a sequencer's
+// slowest expansions were thirty-odd DEPENDENT round trips through one tail (synth1m: 85 k cycles per expansion on the
+// slowest wavefront, 92 % of them here).  After the batch itself, so that the eight rows take the registers of the batch
+// (inside the loop over the batch they were 31 registers more: 129, one wavefront per SIMD less).
+template <bool TAIL8, class Sink>
+__device__ __forceinline__ void rs_consume(RsBatch &b, const KdNode *__restrict__ PR, float qx, float qy, float qz,
                                            float r2, float thr_f, uint32_t lane, unsigned long long &cand, Sink &&sink)
 {
+    uint32_t t_cnt = 0u, t_rk = 0u;
 #pragma unroll
     for (int u = 0; u < RS_BATCH; ++u)
     {
@@ -815,15 +824,39 @@ __device__ __forceinline__ void rs_consume(const RsBatch &b, const KdNode *__res
             break;
         cand += min(b.cnt[u], 64u);
         sink(rs_test(b.nd[u], lane < b.cnt[u], qx, qy, qz, r2, thr_f));
-        // the long tail chunk of a group with more than 64 chunks: the rest of its ranks, 64 at a time
-        for (uint32_t o = 64; o < b.cnt[u]; o += 64)
+        if (b.cnt[u] > 64u)
         {
-            const bool v = o + lane < b.cnt[u];
-            const KdNode n2 = PR[v ? b.rk[u] + o + lane : 0u];
-            cand += min(b.cnt[u] - o, 64u);
-            sink(rs_test(n2, v, qx, qy, qz, r2, thr_f));
+            t_cnt = b.cnt[u];
+            t_rk = b.rk[u];
         }
     }
+    // the long tail chunk of a group with more than 64 chunks: the rest of its ranks
+    if (TAIL8)
+    {
+        static_assert(RS_BATCH == 8, "the rest of a long chunk is fetched into the rows of its (finished) batch");
+        for (uint32_t o = 64; o < t_cnt; o += RS_BATCH * 64)
+        {
+#pragma unroll
+            for (int k = 0; k < RS_BATCH; ++k)  // (unconditional: independent loads, see the vmcnt rules)
+                b.nd[k] = PR[o + k * 64 + lane < t_cnt ? t_rk + o + k * 64 + lane : 0u];
+#pragma unroll
+            for (int k = 0; k < RS_BATCH; ++k)
+            {
+                if (o + k * 64 >= t_cnt)
+                    break;
+                cand += min(t_cnt - (o + k * 64), 64u);
+                sink(rs_test(b.nd[k], o + k * 64 + lane < t_cnt, qx, qy, qz, r2, thr_f));
+            }
+        }
+    }
+    else
+        for (uint32_t o = 64; o < t_cnt; o += 64)
+        {
+            const bool v = o + lane < t_cnt;
+            const KdNode n2 = PR[v ? t_rk + o + lane : 0u];
+            cand += min(t_cnt - o, 64u);
+            sink(rs_test(n2, v, qx, qy, qz, r2, thr_f));
+        }
 }
 
 // LPX_RS_PROF (tools/replay_prof.py, a variant build): cycles of every sequencer by phase, one record per wavefront
@@ -1159,13 +1192,13 @@ __global__ RS_BOUNDS void replay_search_kernel(
                 for (;;)
                 {
                     ++st_exp;
-                    rs_consume(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
+                    rs_consume<REUSE>(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
                     if (staged)
                         stores_out();  // the stores the apply of the expansion before this one owes (its hits are all applied)
                     while (km)
                     {
                         rs_issue(bt, PR, ch, km, lane);
-                        rs_consume(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
+                        rs_consume<REUSE>(bt, PR, qx, qy, qz, r2, thr_f, lane, st_cand, collect);
                     }
                     RS_LAP(pf_cand, pf_t);
                     const bool more = e_next >= 0;
