@@ -833,7 +833,6 @@ __device__ __forceinline__ void rs_consume(RsBatch &b, const KdNode *__restrict_
     // the long tail chunk of a group with more than 64 chunks: the rest of its ranks
     if (TAIL8)
     {
-        static_assert(RS_BATCH == 8, "the rest of a long chunk is fetched into the rows of its (finished) batch");
         for (uint32_t o = 64; o < t_cnt; o += RS_BATCH * 64)
         {
 #pragma unroll
