@@ -90,7 +90,8 @@ void lpx_destroy(lpx_ctx *ctx);
 /* Segmenter::reserve_memory / Clusterer::reserve_memory (src/segmentation.cpp:44-60,
  * src/clustering.cpp:37-45): pre-size all device scratch for n points.  Scratch also grows on
  * demand.  neighbours_per_point sizes the exact-length region of the radius-neighbour lists of LPX_NEIGHBOURS_LISTS, one
- * 32-bit word per neighbour (0 = keep the default: 64, times ceil(distance_squared / 0.25) up to 4).  The list workspace
+ * 32-bit word per neighbour (0 = keep the default: 64, times ceil(distance_squared / 0.25) up to 4; a context of
+ * lpx_create_batch with more than one frame slot starts at the 4 x, because nothing repeats its calls).  The list workspace
  * GROWS ON EVIDENCE: every list-mode clustering records what it asked for, and the next call on the context sizes both
  * regions to 1.25 x the largest demand seen (a 123k-point frame at d = 0.5 m: 126 MB).  A frame that outgrows the
  * workspace before that: the host entry points grow it and repeat the frame themselves, the device entry points report

@@ -268,7 +268,9 @@ static void lists_grow_on_evidence(lpx_ctx *ctx)
         if (b == 0 && e.n_obstacle)
             ctx->list_short = e.entries < 48ull * e.n_obstacle ? 1 : 0;  // (CC_FLAT_BELOW of lpx_lists.hip)
         const uint64_t stripe_cap = ctx->cap_rs / LPX_RS_STRIPES;
-        if (e.stripe_max > stripe_cap && ctx->cap_rs)
+        // (a context with more than one frame slot keeps its single-pass region as it is: an overflowing stripe costs a
+        // counting pass, growing costs a reallocation of tens of GB -- more than a second during which the chain waits)
+        if (e.stripe_max > stripe_cap && ctx->cap_rs && ctx->batch == 1)
         {
             const uint64_t want = (e.stripe_max + e.stripe_max / 4) * LPX_RS_STRIPES;
             const uint64_t per = (want + ctx->cap_n - 1) / ctx->cap_n;
@@ -294,7 +296,10 @@ static void lists_grow_on_evidence(lpx_ctx *ctx)
 static int ensure_for(lpx_ctx *ctx, uint32_t n)
 {
     lists_grow_on_evidence(ctx);
-    uint64_t nb = (uint64_t)n * ctx->nb_per_point;
+    // sized by the points the context is RESERVED for, not by this call's largest frame: a chain whose largest frame has a
+    // few points more than the last chain's must not move a 16 GB arena (it did: lpx_reserve comes before the first
+    // configuration, and the radius prior of check_clu after it)
+    uint64_t nb = (uint64_t)(n > ctx->cap_n ? n : ctx->cap_n) * ctx->nb_per_point;
     if (nb > 0xfffffff0ull)
         nb = 0xfffffff0ull;  // offsets are 32-bit
     const int rc = lpx_ensure_capacity(ctx, n, nb);
@@ -938,10 +943,14 @@ static int check_clu(lpx_ctx *ctx, const lpx_clu_cfg *c, size_t stride, bool pcl
     // defaults (64 + 192 words per point) are sized for the reference's d = 0.5 m; a larger radius scales them before the
     // first frame is seen -- up to 4 x, the 256 + 768 words of rounds 1-5, which carried every d = 1 m scene of
     // tools/fuzz.py -- and the evidence of the frames themselves takes over from there (lists_grow_on_evidence).
+    // A context with MORE THAN ONE frame slot starts at the 4 x: its chains are device calls, which the library cannot
+    // repeat -- a frame that outgrows the workspace comes back with LPX_ERR_CAPACITY in its status word -- and the small
+    // start cost the reference's own frames exactly that (chains of 32 of the 154 data/ frames, d = 0.5 m: 17 frames
+    // refused over the first ten chains while two contexts grew, tools/r6_lists_chain.py).  With the 4 x none is.
     if (ctx->use_lists)
     {
         const float scale = c->distance_squared / 0.25f;
-        const uint32_t k = scale <= 1.0f ? 1u : (scale >= 4.0f ? 4u : (uint32_t)ceilf(scale));
+        const uint32_t k = ctx->batch > 1 ? 4u : (scale <= 1.0f ? 1u : (scale >= 4.0f ? 4u : (uint32_t)ceilf(scale)));
         for (lpx_ctx *t = ctx; t; t = (t == ctx ? ctx->twin : nullptr))
         {
             if (64u * k > t->nb_per_point)

@@ -101,6 +101,42 @@ def test_stream_154_frames_match_reference_goldens(stream, cname):
     assert not bad, bad[:3]
 
 
+def test_list_mode_chains_of_a_fresh_context_refuse_no_frame(stream):
+    """the 154 frames in chains of 32 through a FRESH batch context in LIST mode, the order a closed loop of two
+    contexts walks them: a chain is a device call, which nothing repeats, so its list workspace must carry the
+    reference's own frames from the first call on (round 6's small start refused 17 of them with LPX_ERR_CAPACITY
+    while the workspace grew; contexts with more than one frame slot keep the reserve of rounds 1-5) -- every frame's
+    status word and outputs against the goldens of the reference build"""
+    cname = "p6i5_d025q05"
+    skw, ckw = STREAM_CONFIGS[cname]
+    scfg, ccfg = SegmentationConfiguration(**skw), ClusteringConfiguration(**ckw)
+    g = stream_gold()
+    buf = Pitched(stream, skw["number_of_planar_partitions"])
+    bad, chains = [], 0
+    for first in (0, 32):
+        buf.clear()
+        bctx = Context(0, batch=32)
+        try:
+            bctx.set_neighbour_mode("lists")
+            bctx.reserve(buf.pitch)
+            k, seen = first, []
+            for chain in range(8):
+                lo = k % (buf.F - 32 + 1)
+                buf.enqueue(bctx, lo, lo + 32, scfg, ccfg)
+                bctx.synchronize()
+                for j in range(lo, lo + 32):
+                    res = buf.frame(j)
+                    if res["status"] != 0 or golden_row(res) != [int(v) for v in g[cname][j]]:
+                        bad.append((chain, stream_names()[j], res["status"]))
+                k += 64
+                chains += 1
+            grown = bctx.workspace_bytes()[1]
+        finally:
+            bctx.close()
+        assert grown < 16 << 30, grown  # (32 x 379 MB as in rounds 1-5, not a runaway growth)
+    assert not bad and chains == 16, bad[:5]
+
+
 @pytest.mark.parametrize("mode", ["lists", "search"])
 def test_stream_through_the_two_calls_of_the_node(stream, mode):
     """the unchanged node's form on all 154 frames in order: segment(), then cluster() on the obstacle cloud it returned,
